@@ -1,0 +1,136 @@
+/*
+ * pseg.h -- C ABI of libpseg.so, the MI355X (gfx950) engine for the per-pixel
+ * page-segmentation hot path of ocr4all_pixel_classifier.
+ *
+ * The reference (pure Python over TensorFlow/OpenCV) has no FFI layer; the boundary this
+ * library sits behind is the Python API of ocr4all_pixel_classifier.lib.
+ * Each entry point names the reference interface it replaces.  Signatures carry plain
+ * pointers and sizes only -- no torch / numpy types.  Every function returns 0 on success
+ * and a negative PSEG_E* code on failure; pseg_last_error() returns a thread-local message
+ * (the Python shim raises it as Exception, the reference's error style).
+ *
+ * Ownership: the library never retains a caller pointer past the call.  Device buffers are
+ * owned by the opaque pseg_engine.  "_device" variants take pointers that are already
+ * resident in HBM on the engine's device and enqueue on the given hipStream_t (passed as
+ * void*; NULL = the engine's own stream) without synchronising.
+ */
+#ifndef PSEG_H
+#define PSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSEG_ABI_VERSION 1
+
+/* lib/architecture.py:6-11 -- the in-scope Architecture members. */
+enum { PSEG_ARCH_FCN_SKIP = 0, PSEG_ARCH_FCN = 1, PSEG_ARCH_UNET = 2, PSEG_ARCH_RES_UNET = 3 };
+
+/* Arithmetic mode.  F32_EXACT: float32 tensors, sequential-fmaf accumulation in (ky,kx,ci)
+ * order -- bit-identical to oracle/pseg_oracle.c.  BF16: bf16 activations + bf16 kernels,
+ * float32 MFMA accumulation (throughput mode, BASELINE.json configs[1]). */
+enum { PSEG_MODE_F32_EXACT = 0, PSEG_MODE_BF16 = 1 };
+
+enum {
+    PSEG_OK = 0,
+    PSEG_EINVAL = -1,   /* bad argument / shape */
+    PSEG_ENOTFOUND = -2, /* unknown weight name */
+    PSEG_EHIP = -3,     /* HIP runtime error (message has the hipError string) */
+    PSEG_ENOMEM = -4,
+    PSEG_EUNSUPPORTED = -5
+};
+
+typedef struct pseg_engine pseg_engine;
+
+int pseg_abi_version(void);
+const char* pseg_last_error(void);
+
+/* Number of visible HIP devices (0 when none; never fails). */
+int pseg_device_count(void);
+
+/* ---- Network: lib/network.py:18-107 (graph construction + weight loading) ------------- */
+
+/* Replaces model_constructor.model()([input, binary], n_classes) (lib/network.py:89) for
+ * lib/model.py:45 (fcn_skip), :206 (fcn), :151 (unet), :237 (res_unet). */
+int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
+                pseg_engine** out);
+int pseg_destroy(pseg_engine* e);
+
+/* Weight table in Keras creation order; names are Keras' default layer names plus
+ * "/kernel" or "/bias" ("conv2d/kernel", "conv2d_transpose_1/bias", "logits/kernel", ...).
+ * Layouts are Keras': Conv2D (kh,kw,Cin,Cout), Conv2DTranspose (kh,kw,Cout,Cin), bias (Cout). */
+int pseg_num_weights(const pseg_engine* e);
+int pseg_weight_info(const pseg_engine* e, int index, char* name, size_t name_cap,
+                     int64_t shape[4], int* ndim);
+/* Replaces model.load_weights (lib/network.py:106-107) / model.set_weights. */
+int pseg_set_weights(pseg_engine* e, const char* name, const float* data, const int64_t* shape,
+                     int ndim);
+int pseg_get_weights(const pseg_engine* e, const char* name, float* out, int64_t count);
+
+/* ---- Predict: lib/network.py:248-260 (Network.predict_single_data) -------------------- */
+
+/* img: uint8 (H,W) network input (inverted, line-height normalised page).  Computes
+ * x/255 -> pad to 32 -> FCN -> crop -> logits -> softmax / argmax.  Any of logits (H,W,C f32),
+ * probs (H,W,C f32), labels (H,W int64) may be NULL.  Host pointers; synchronous. */
+int pseg_predict(pseg_engine* e, const uint8_t* img, int H, int W, float* logits, float* probs,
+                 int64_t* labels);
+
+/* Same with device-resident buffers; asynchronous on `stream`.  labels_u8 is an optional
+ * compact label map (n_classes <= 256). */
+int pseg_predict_device(pseg_engine* e, const uint8_t* d_img, int H, int W, float* d_logits,
+                        float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8, void* stream);
+
+/* Copy an intermediate activation to the host as float32 NHWC (true channel count) --
+ * layer-by-layer parity tests.  `layer` is the Keras layer name.  dims[3] = {H,W,C} of the
+ * padded canvas at that layer.  Valid after a predict call. */
+int pseg_get_activation(pseg_engine* e, const char* layer, float* out, int64_t cap, int dims[3]);
+
+/* Algorithmic forward FLOPs per canvas pixel (2 per MAC, true channel counts): the figure
+ * SURVEY.md 8(d) quotes (113 700 for fcn_skip C=3). */
+double pseg_flops_per_pixel(const pseg_engine* e);
+
+/* Average duration in ms of the `slot`-th kernel class over the launches since the last
+ * reset, measured with HIP events on the launch stream (bench.py roofline).  Timing is off
+ * unless enabled; enabling inserts events around every launch. */
+int pseg_timing_enable(pseg_engine* e, int on);
+int pseg_timing_reset(pseg_engine* e);
+int pseg_timing_num_slots(const pseg_engine* e);
+int pseg_timing_get(pseg_engine* e, int slot, char* name, size_t name_cap, double* total_ms,
+                    int64_t* launches, double* flops);
+
+/* ---- Post-process: lib/postprocess.py, lib/output.py ---------------------------------- */
+
+/* vote_connected_component_class (lib/postprocess.py:9-26): 4-connected components of
+ * `binary` (non-zero = ink); each takes its most frequent class in pred (ties -> lowest).
+ * pred int64 (H,W) is updated in place, as the reference does. Host pointers. */
+int pseg_cc_vote(int device, int64_t* pred, const uint8_t* binary, int H, int W, int n_classes);
+int pseg_cc_vote_device(int device, int64_t* d_pred, const uint8_t* d_binary, int H, int W,
+                        int n_classes, void* stream);
+
+/* add_bounding_boxes (lib/postprocess.py:29-42): every 4-connected component of each class
+ * paints its bounding box; higher classes overwrite lower. out may alias nothing. */
+int pseg_bbox_fill(int device, const int64_t* pred, int64_t* out, int H, int W, int n_classes);
+
+/* generate_output_masks (lib/output.py:44-60).  lut: n_lut x 3 uint8 label->RGB
+ * (ColorMap.to_rgb_array).  Outputs (H,W,3) uint8; any may be NULL. */
+int pseg_masks(int device, const int64_t* pred, const uint8_t* binary, const uint8_t* lut,
+               int n_lut, int H, int W, uint8_t* color, uint8_t* overlay, uint8_t* inverted,
+               uint8_t* fg_color);
+int pseg_masks_device(int device, const int64_t* d_pred, const uint8_t* d_binary,
+                      const uint8_t* d_lut, int n_lut, int H, int W, uint8_t* d_color,
+                      uint8_t* d_overlay, uint8_t* d_inverted, uint8_t* d_fg_color, void* stream);
+
+/* compute_char_height (lib/image_ops.py:58-82) minus the file read: Otsu threshold, invert
+ * unless `inverse`, 4-connected components, keep glyph-shaped ones, upper median of heights.
+ * *height = -1 when no component qualifies (the reference returns None). *otsu gets the
+ * threshold (may be NULL). */
+int pseg_otsu_char_height(int device, const uint8_t* gray, int H, int W, int inverse,
+                          int* height, int* otsu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSEG_H */

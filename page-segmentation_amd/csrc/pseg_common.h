@@ -1,0 +1,129 @@
+// pseg_common.h -- shared declarations of the libpseg.so sources (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/pseg.h"
+
+namespace pseg {
+
+// ---- error plumbing (thread-local message, int status: SURVEY.md 8b "Errors") -------------
+std::string& last_error();
+int fail(int code, const char* fmt, ...);
+
+#define PSEG_HIP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::pseg::fail(PSEG_EHIP, "%s failed: %s (%s:%d)", #expr,                     \
+                                hipGetErrorString(_e), __FILE__, __LINE__);                    \
+    } while (0)
+
+#define PSEG_TRY(expr)                                                                         \
+    do {                                                                                       \
+        int _rc = (expr);                                                                      \
+        if (_rc != PSEG_OK) return _rc;                                                        \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ---- graph description ---------------------------------------------------------------------
+enum OpType { OP_CONV = 0, OP_DECONV2 = 1, OP_POOL = 2, OP_LOGITS = 3 };
+
+struct Tensor {
+    std::string name;   // producing Keras layer name ("input", "conv2d", "max_pooling2d", ...)
+    int s = 0;          // log2 down-scale relative to the padded canvas
+    int C = 0;          // true channel count
+    int Cs = 0;         // storage channels: C (f32 mode) or round_up(C, 8) (bf16 mode)
+    void* d = nullptr;  // device buffer, NHWC, (Hp>>s) x (Wp>>s) x Cs
+    size_t bytes = 0;
+};
+
+struct Param {
+    std::string name;   // "conv2d/kernel", ...
+    int64_t shape[4] = {0, 0, 0, 0};
+    int ndim = 0;
+    std::vector<float> host;  // Keras layout
+    bool set = false;
+};
+
+struct Op {
+    int type = OP_CONV;
+    std::string layer;   // Keras layer name
+    int k = 1, stride = 1;
+    bool transposed = false;  // Conv2DTranspose stride 1: flip + swap channels at upload
+    int src0 = -1, src1 = -1; // concat [src0, src1]
+    int up0 = 0, up1 = 0;     // nearest x2 upsample folded into the gather
+    int in_relu = 0, relu = 0;
+    int add = -1;             // residual addend tensor (Add()), applied after bias
+    int dst = -1;
+    int pool_dst = -1;        // bf16 mode: fused 2x2 max-pool output
+    int kparam = -1, bparam = -1;
+    int Cin = 0, Cout = 0;
+    // device weights
+    float* d_w = nullptr;     // f32 correlation form [KH][KW][Cin][Cout] (+slack) / [2][2][Cin][Cout]
+    float* d_b = nullptr;     // f32 bias
+    void* d_wp = nullptr;     // bf16 packed MFMA B-fragments (pseg_mfma.hip)
+    size_t wp_bytes = 0;
+    int mfma_cfg[8] = {0};    // kernel-specific packing geometry
+    double flops_per_canvas_px = 0;  // algorithmic, true channels
+    int timing_slot = -1;
+};
+
+// ---- bf16 MFMA path (pseg_mfma.hip) ----------------------------------------------------------
+struct Engine;
+int mfma_pack_op(Engine& e, Op& op);                         // host-side packing + upload
+int mfma_launch_conv(Engine& e, Op& op, hipStream_t st);     // OP_CONV
+int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st);  // OP_DECONV2
+int mfma_launch_pool(Engine& e, Op& op, hipStream_t st);     // OP_POOL (unfused fallback)
+int mfma_launch_logits(Engine& e, Op& op, float* d_logits, float* d_probs, int64_t* d_labels,
+                       uint8_t* d_labels_u8, hipStream_t st);
+int mfma_preprocess(Engine& e, const uint8_t* d_img, hipStream_t st);
+
+struct TimingSlot {
+    std::string name;
+    double flops = 0;   // algorithmic flops of one launch at the current canvas
+    double total_ms = 0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct Engine {
+    int arch = 0, n_classes = 0, in_ch = 1, device = 0, mode = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Tensor> tensors;
+    std::vector<Param> params;
+    std::vector<Op> ops;
+    int input_tensor = 0;
+    // canvas
+    int H = 0, W = 0, Hp = 0, Wp = 0;
+    bool weights_dirty = true;
+    float* d_lut = nullptr;        // 256-entry u/255 table (f32)
+    float* d_logits_tmp = nullptr; // H*W*C f32 when the caller does not want logits
+    size_t logits_tmp_bytes = 0;
+    uint8_t* d_img_stage = nullptr;
+    size_t img_stage_bytes = 0;
+    int64_t* d_lab_stage = nullptr;
+    float* d_prob_stage = nullptr;
+    float* d_logit_stage = nullptr;
+    size_t lab_stage_bytes = 0, prob_stage_bytes = 0, logit_stage_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<TimingSlot> slots;
+    std::vector<hipEvent_t> event_pool;
+
+    int tH(const Tensor& t) const { return Hp >> t.s; }
+    int tW(const Tensor& t) const { return Wp >> t.s; }
+};
+
+int time_begin(Engine& e, Op& op, hipStream_t st, hipEvent_t* ev0);
+int time_end(Engine& e, Op& op, hipStream_t st, hipEvent_t ev0);
+
+}  // namespace pseg

@@ -1,0 +1,697 @@
+// pseg_engine.hip -- engine object, f32-exact kernels, and the C ABI of include/pseg.h.
+//
+// F32_EXACT mode: every tensor is dense NHWC float32 with its true channel count.  Each output
+// element is one sequential fmaf chain in (ky, kx, ci) order starting from +0, then "+ bias",
+// then the optional residual add and ReLU -- the same operation sequence as
+// oracle/pseg_oracle.c, so logits (and therefore label maps) are bit-identical to the oracle.
+// This mode is the parity referee; the throughput mode lives in pseg_mfma.hip.
+#include <algorithm>
+#include <cstring>
+
+#include "pseg_common.h"
+
+namespace pseg {
+
+int build_graph(Engine& e);
+
+std::string& last_error() {
+    thread_local std::string msg;
+    return msg;
+}
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+// =============================================================================================
+// f32-exact kernels
+// =============================================================================================
+constexpr int COT = 16;  // output channels per thread in the exact conv kernels
+
+struct ConvArgs {
+    const float* src0;
+    const float* src1;
+    int C0, C1;
+    int up0, up1;
+    int Hin, Win;  // logical input dims (after the folded upsample)
+    const float* w;
+    const float* bias;
+    const float* add;
+    float* dst;
+    int KH, KW, stride, pt, pl, Hout, Wout, Cout, in_relu, relu;
+};
+
+// One thread = one output pixel x COT consecutive output channels.  Weights are indexed only by
+// loop counters and blockIdx, i.e. wave-uniform: hipcc serves them through the scalar cache.
+__global__ __launch_bounds__(256) void conv_exact_kernel(ConvArgs a) {
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= a.Hout * a.Wout) return;
+    const int co0 = blockIdx.y * COT;
+    const int y = pix / a.Wout, x = pix - y * a.Wout;
+    const int Cin = a.C0 + a.C1;
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = 0.0f;
+
+    for (int ky = 0; ky < a.KH; ++ky) {
+        const int iy = y * a.stride + ky - a.pt;
+        if (iy < 0 || iy >= a.Hin) continue;
+        for (int kx = 0; kx < a.KW; ++kx) {
+            const int ix = x * a.stride + kx - a.pl;
+            if (ix < 0 || ix >= a.Win) continue;
+            const float* wt = a.w + (size_t)((ky * a.KW + kx) * Cin) * a.Cout + co0;
+            {
+                const float* p = a.src0 + ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0;
+                for (int ci = 0; ci < a.C0; ++ci) {
+                    float xv = p[ci];
+                    if (a.in_relu) xv = xv > 0.0f ? xv : 0.0f;
+                    const float* wr = wt + (size_t)ci * a.Cout;
+#pragma unroll
+                    for (int j = 0; j < COT; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
+                }
+            }
+            if (a.C1 > 0) {
+                const float* p = a.src1 + ((size_t)(iy >> a.up1) * (a.Win >> a.up1) + (ix >> a.up1)) * a.C1;
+                const float* wt1 = wt + (size_t)a.C0 * a.Cout;
+                for (int ci = 0; ci < a.C1; ++ci) {
+                    float xv = p[ci];
+                    if (a.in_relu) xv = xv > 0.0f ? xv : 0.0f;
+                    const float* wr = wt1 + (size_t)ci * a.Cout;
+#pragma unroll
+                    for (int j = 0; j < COT; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
+                }
+            }
+        }
+    }
+    float* o = a.dst + (size_t)pix * a.Cout;
+    const float* ad = a.add ? a.add + (size_t)pix * a.Cout : nullptr;
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+        const int co = co0 + j;
+        if (co < a.Cout) {
+            float v = acc[j] + a.bias[co];
+            if (ad) v = v + ad[co];
+            if (a.relu) v = v > 0.0f ? v : 0.0f;
+            o[co] = v;
+        }
+    }
+}
+
+struct DeconvArgs {
+    const float* src0;
+    const float* src1;
+    int C0, C1;
+    int Hin, Win;
+    const float* w;  // [2][2][Cin][Cout]
+    const float* bias;
+    float* dst;      // (2Hin) x (2Win) x Cout
+    int Cout, relu;
+};
+
+// blockIdx.z = a*2+b keeps the tap (and with it the weight row) wave-uniform.
+__global__ __launch_bounds__(256) void deconv2_exact_kernel(DeconvArgs a) {
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= a.Hin * a.Win) return;
+    const int co0 = blockIdx.y * COT;
+    const int ab = blockIdx.z;
+    const int i = pix / a.Win, j0 = pix - i * a.Win;
+    const int Cin = a.C0 + a.C1;
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = 0.0f;
+    const float* wt = a.w + (size_t)ab * Cin * a.Cout + co0;
+    const float* p0 = a.src0 + (size_t)pix * a.C0;
+    for (int ci = 0; ci < a.C0; ++ci) {
+        const float xv = p0[ci];
+        const float* wr = wt + (size_t)ci * a.Cout;
+#pragma unroll
+        for (int j = 0; j < COT; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
+    }
+    if (a.C1 > 0) {
+        const float* p1 = a.src1 + (size_t)pix * a.C1;
+        const float* wt1 = wt + (size_t)a.C0 * a.Cout;
+        for (int ci = 0; ci < a.C1; ++ci) {
+            const float xv = p1[ci];
+            const float* wr = wt1 + (size_t)ci * a.Cout;
+#pragma unroll
+            for (int j = 0; j < COT; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
+        }
+    }
+    const int oy = 2 * i + (ab >> 1), ox = 2 * j0 + (ab & 1);
+    float* o = a.dst + ((size_t)oy * (2 * a.Win) + ox) * a.Cout;
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+        const int co = co0 + j;
+        if (co < a.Cout) {
+            float v = acc[j] + a.bias[co];
+            if (a.relu) v = v > 0.0f ? v : 0.0f;
+            o[co] = v;
+        }
+    }
+}
+
+__global__ void pool_exact_kernel(const float* in, int H, int W, int C, float* out) {
+    const size_t n = (size_t)(H / 2) * (W / 2) * C;
+    const int Wo = W / 2;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const size_t p = t / C;
+        const int x = (int)(p % Wo), y = (int)(p / Wo);
+        const float* b = in + ((size_t)(2 * y) * W + 2 * x) * C + c;
+        const float v0 = b[0], v1 = b[C], v2 = b[(size_t)W * C], v3 = b[(size_t)W * C + C];
+        float m = v0 > v1 ? v0 : v1;
+        const float n2 = v2 > v3 ? v2 : v3;
+        out[t] = m > n2 ? m : n2;
+    }
+}
+
+// x/255 via the host-built LUT (bit-identical to the oracle's float division), zero pad to the
+// 32-multiple canvas (lib/model.py:20-26).
+__global__ void preprocess_exact_kernel(const uint8_t* img, int H, int W, int C, const float* lut,
+                                        float* dst, int Hp, int Wp) {
+    const size_t n = (size_t)Hp * Wp * C;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const size_t p = t / C;
+        const int x = (int)(p % Wp), y = (int)(p / Wp);
+        dst[t] = (y < H && x < W) ? lut[img[((size_t)y * W + x) * C + c]] : 0.0f;
+    }
+}
+
+// softmax(-1) and argmax(-1) of the float32 logits (lib/network.py:258-259): max-subtracted
+// exp / sum in f32 (scipy.special.softmax on f32 input); argmax first-maximum-wins.
+__global__ void softmax_argmax_kernel(const float* logits, size_t n, int C, float* probs,
+                                      int64_t* labels, uint8_t* labels_u8) {
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (size_t)gridDim.x * blockDim.x) {
+        const float* z = logits + p * C;
+        int best = 0;
+        float bv = z[0];
+        for (int c = 1; c < C; ++c) {
+            const float v = z[c];
+            if (v > bv) { bv = v; best = c; }
+        }
+        if (labels) labels[p] = best;
+        if (labels_u8) labels_u8[p] = (uint8_t)best;
+        if (probs) {
+            float s = 0.0f;
+            for (int c = 0; c < C; ++c) s += expf(z[c] - bv);
+            for (int c = 0; c < C; ++c) probs[p * C + c] = expf(z[c] - bv) / s;
+        }
+    }
+}
+
+// =============================================================================================
+// timing helpers (HIP events on the launch stream)
+// =============================================================================================
+static int get_event(Engine& e, hipEvent_t* ev) {
+    if (!e.event_pool.empty()) {
+        *ev = e.event_pool.back();
+        e.event_pool.pop_back();
+        return PSEG_OK;
+    }
+    PSEG_HIP(hipEventCreate(ev));
+    return PSEG_OK;
+}
+
+int time_begin(Engine& e, Op& op, hipStream_t st, hipEvent_t* ev0) {
+    *ev0 = nullptr;
+    if (!e.timing || op.timing_slot < 0) return PSEG_OK;
+    PSEG_TRY(get_event(e, ev0));
+    PSEG_HIP(hipEventRecord(*ev0, st));
+    return PSEG_OK;
+}
+
+int time_end(Engine& e, Op& op, hipStream_t st, hipEvent_t ev0) {
+    if (!ev0) return PSEG_OK;
+    hipEvent_t ev1;
+    PSEG_TRY(get_event(e, &ev1));
+    PSEG_HIP(hipEventRecord(ev1, st));
+    e.slots[op.timing_slot].pending.emplace_back(ev0, ev1);
+    return PSEG_OK;
+}
+
+static int timing_collect(Engine& e) {
+    for (auto& s : e.slots) {
+        for (auto& pr : s.pending) {
+            PSEG_HIP(hipEventSynchronize(pr.second));
+            float ms = 0;
+            PSEG_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            s.total_ms += ms;
+            s.launches += 1;
+            e.event_pool.push_back(pr.first);
+            e.event_pool.push_back(pr.second);
+        }
+        s.pending.clear();
+    }
+    return PSEG_OK;
+}
+
+// =============================================================================================
+// engine: weights, canvas, run
+// =============================================================================================
+static void free_dev(void*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+static int ensure(void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p) return PSEG_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    PSEG_HIP(hipMalloc(p, bytes));
+    *cap = bytes;
+    return PSEG_OK;
+}
+
+// Upload weights in correlation form.  Conv2D: as is.  Conv2DTranspose s1 (kh,kw,Cout,Cin):
+// Wc[ky][kx][ci][co] = K[KH-1-ky][KW-1-kx][co][ci].  Conv2DTranspose k2 s2: [a][b][ci][co] =
+// K[a][b][co][ci].
+static int upload_weights(Engine& e) {
+    for (auto& op : e.ops) {
+        if (op.kparam < 0) continue;
+        const Param& kp = e.params[op.kparam];
+        const Param& bp = e.params[op.bparam];
+        const int k = op.k, Cin = op.Cin, Cout = op.Cout;
+        std::vector<float> w((size_t)k * k * Cin * Cout + COT, 0.0f);
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx)
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (int co = 0; co < Cout; ++co) {
+                        float v;
+                        if (!op.transposed)
+                            v = kp.host[(((size_t)ky * k + kx) * Cin + ci) * Cout + co];
+                        else if (op.type == OP_DECONV2)
+                            v = kp.host[(((size_t)ky * k + kx) * Cout + co) * Cin + ci];
+                        else
+                            v = kp.host[(((size_t)(k - 1 - ky) * k + (k - 1 - kx)) * Cout + co) * Cin + ci];
+                        w[(((size_t)ky * k + kx) * Cin + ci) * Cout + co] = v;
+                    }
+        free_dev((void*&)op.d_w);
+        free_dev((void*&)op.d_b);
+        PSEG_HIP(hipMalloc((void**)&op.d_w, w.size() * sizeof(float)));
+        PSEG_HIP(hipMemcpy(op.d_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+        PSEG_HIP(hipMalloc((void**)&op.d_b, (size_t)round_up(Cout, COT) * sizeof(float)));
+        PSEG_HIP(hipMemset(op.d_b, 0, (size_t)round_up(Cout, COT) * sizeof(float)));
+        PSEG_HIP(hipMemcpy(op.d_b, bp.host.data(), (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
+        if (e.mode == PSEG_MODE_BF16) PSEG_TRY(mfma_pack_op(e, op));
+    }
+    e.weights_dirty = false;
+    return PSEG_OK;
+}
+
+static int set_canvas(Engine& e, int H, int W) {
+    if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
+    const int Hp = round_up(H, 32), Wp = round_up(W, 32);
+    e.H = H;
+    e.W = W;
+    if (Hp == e.Hp && Wp == e.Wp) return PSEG_OK;
+    e.Hp = Hp;
+    e.Wp = Wp;
+    const size_t esz = e.mode == PSEG_MODE_BF16 ? 2 : 4;
+    for (auto& t : e.tensors) {
+        const size_t bytes = (size_t)e.tH(t) * e.tW(t) * t.Cs * esz;
+        if (bytes > t.bytes) {
+            free_dev(t.d);
+            t.bytes = 0;
+            PSEG_HIP(hipMalloc(&t.d, bytes));
+            t.bytes = bytes;
+        }
+    }
+    const double px = (double)Hp * Wp;
+    for (auto& op : e.ops) e.slots[op.timing_slot].flops = op.flops_per_canvas_px * px;
+    return PSEG_OK;
+}
+
+static int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
+                     int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st) {
+    Tensor& in = e.tensors[e.input_tensor];
+    {
+        const size_t n = (size_t)e.Hp * e.Wp * in.C;
+        const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+        preprocess_exact_kernel<<<grid, 256, 0, st>>>(d_img, e.H, e.W, in.C, e.d_lut, (float*)in.d,
+                                                      e.Hp, e.Wp);
+    }
+    for (auto& op : e.ops) {
+        hipEvent_t ev0;
+        PSEG_TRY(time_begin(e, op, st, &ev0));
+        const Tensor& s0 = e.tensors[op.src0];
+        const Tensor* s1 = op.src1 >= 0 ? &e.tensors[op.src1] : nullptr;
+        if (op.type == OP_CONV || op.type == OP_LOGITS) {
+            ConvArgs a{};
+            a.src0 = (const float*)s0.d;
+            a.src1 = s1 ? (const float*)s1->d : nullptr;
+            a.C0 = s0.C;
+            a.C1 = s1 ? s1->C : 0;
+            a.up0 = op.up0;
+            a.up1 = op.up1;
+            a.Hin = e.tH(s0) << op.up0;
+            a.Win = e.tW(s0) << op.up0;
+            a.w = op.d_w;
+            a.bias = op.d_b;
+            a.KH = a.KW = op.k;
+            a.stride = op.stride;
+            a.in_relu = op.in_relu;
+            a.relu = op.relu;
+            a.Cout = op.Cout;
+            if (op.type == OP_LOGITS) {
+                // crop (lib/model.py:29-42) folded into the output extent
+                a.Hout = e.H;
+                a.Wout = e.W;
+                a.pt = a.pl = 0;
+                float* zl = d_logits;
+                if (!zl) {
+                    PSEG_TRY(ensure((void**)&e.d_logits_tmp, &e.logits_tmp_bytes,
+                                    (size_t)e.H * e.W * op.Cout * sizeof(float)));
+                    zl = e.d_logits_tmp;
+                }
+                a.dst = zl;
+                // the kernel indexes src rows with Win: rows of the padded canvas
+                dim3 grid(cdiv(a.Hout * a.Wout, 256), cdiv(op.Cout, COT));
+                // logical input dims stay the canvas; output (y,x) reads input (y,x)
+                conv_exact_kernel<<<grid, 256, 0, st>>>(a);
+                if (d_probs || d_labels || d_labels_u8) {
+                    const size_t n = (size_t)e.H * e.W;
+                    const int g2 = (int)std::min<size_t>((n + 255) / 256, 8192);
+                    softmax_argmax_kernel<<<g2, 256, 0, st>>>(zl, n, op.Cout, d_probs, d_labels,
+                                                             d_labels_u8);
+                }
+            } else {
+                const Tensor& d = e.tensors[op.dst];
+                a.Hout = e.tH(d);
+                a.Wout = e.tW(d);
+                // TF SAME: pad_total = max((out-1)*s + k - in, 0); before = total / 2
+                const int tot_h = std::max((a.Hout - 1) * op.stride + op.k - a.Hin, 0);
+                const int tot_w = std::max((a.Wout - 1) * op.stride + op.k - a.Win, 0);
+                a.pt = tot_h / 2;
+                a.pl = tot_w / 2;
+                if (op.transposed) {  // flipped kernel: "before" and "after" swap (odd k: equal)
+                    a.pt = tot_h - a.pt;
+                    a.pl = tot_w - a.pl;
+                }
+                a.add = op.add >= 0 ? (const float*)e.tensors[op.add].d : nullptr;
+                a.dst = (float*)d.d;
+                dim3 grid(cdiv(a.Hout * a.Wout, 256), cdiv(op.Cout, COT));
+                conv_exact_kernel<<<grid, 256, 0, st>>>(a);
+            }
+        } else if (op.type == OP_DECONV2) {
+            DeconvArgs a{};
+            a.src0 = (const float*)s0.d;
+            a.src1 = s1 ? (const float*)s1->d : nullptr;
+            a.C0 = s0.C;
+            a.C1 = s1 ? s1->C : 0;
+            a.Hin = e.tH(s0);
+            a.Win = e.tW(s0);
+            a.w = op.d_w;
+            a.bias = op.d_b;
+            a.dst = (float*)e.tensors[op.dst].d;
+            a.Cout = op.Cout;
+            a.relu = op.relu;
+            dim3 grid(cdiv(a.Hin * a.Win, 256), cdiv(op.Cout, COT), 4);
+            deconv2_exact_kernel<<<grid, 256, 0, st>>>(a);
+        } else if (op.type == OP_POOL) {
+            const size_t n = (size_t)(e.tH(s0) / 2) * (e.tW(s0) / 2) * s0.C;
+            const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+            pool_exact_kernel<<<grid, 256, 0, st>>>((const float*)s0.d, e.tH(s0), e.tW(s0), s0.C,
+                                                    (float*)e.tensors[op.dst].d);
+        }
+        PSEG_HIP(hipGetLastError());
+        PSEG_TRY(time_end(e, op, st, ev0));
+    }
+    return PSEG_OK;
+}
+
+static int run_bf16(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
+                    int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st) {
+    PSEG_TRY(mfma_preprocess(e, d_img, st));
+    for (auto& op : e.ops) {
+        hipEvent_t ev0;
+        PSEG_TRY(time_begin(e, op, st, &ev0));
+        switch (op.type) {
+            case OP_CONV: PSEG_TRY(mfma_launch_conv(e, op, st)); break;
+            case OP_DECONV2: PSEG_TRY(mfma_launch_deconv2(e, op, st)); break;
+            case OP_POOL: PSEG_TRY(mfma_launch_pool(e, op, st)); break;
+            case OP_LOGITS:
+                PSEG_TRY(mfma_launch_logits(e, op, d_logits, d_probs, d_labels, d_labels_u8, st));
+                break;
+        }
+        PSEG_HIP(hipGetLastError());
+        PSEG_TRY(time_end(e, op, st, ev0));
+    }
+    return PSEG_OK;
+}
+
+static int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* d_logits,
+                          float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8,
+                          hipStream_t st) {
+    PSEG_HIP(hipSetDevice(e.device));
+    for (auto& p : e.params)
+        if (!p.set) return fail(PSEG_EINVAL, "weight '%s' was never set", p.name.c_str());
+    if (e.weights_dirty) PSEG_TRY(upload_weights(e));
+    PSEG_TRY(set_canvas(e, H, W));
+    if (e.mode == PSEG_MODE_BF16)
+        return run_bf16(e, d_img, d_logits, d_probs, d_labels, d_labels_u8, st);
+    return run_exact(e, d_img, d_logits, d_probs, d_labels, d_labels_u8, st);
+}
+
+}  // namespace pseg
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace pseg;
+
+struct pseg_engine {
+    Engine e;
+};
+
+extern "C" {
+
+int pseg_abi_version(void) { return PSEG_ABI_VERSION; }
+
+const char* pseg_last_error(void) { return last_error().c_str(); }
+
+int pseg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
+                pseg_engine** out) {
+    if (!out) return fail(PSEG_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_classes < 1 || n_classes > 256) return fail(PSEG_EINVAL, "n_classes %d out of range", n_classes);
+    if (in_channels != 1 && in_channels != 3) return fail(PSEG_EINVAL, "in_channels must be 1 or 3");
+    if (mode != PSEG_MODE_F32_EXACT && mode != PSEG_MODE_BF16) return fail(PSEG_EINVAL, "bad mode %d", mode);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(PSEG_EHIP, "no HIP device visible: libpseg has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(PSEG_EINVAL, "device %d of %d", device, ndev);
+    PSEG_HIP(hipSetDevice(device));
+    auto* h = new pseg_engine();
+    Engine& e = h->e;
+    e.arch = arch;
+    e.n_classes = n_classes;
+    e.in_ch = in_channels;
+    e.device = device;
+    e.mode = mode;
+    int rc = build_graph(e);
+    if (rc != PSEG_OK) { delete h; return rc; }
+    if (hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(PSEG_EHIP, "hipStreamCreate failed");
+    }
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = (float)i / 255.0f;  // lib/architecture.py:67-68
+    if (hipMalloc((void**)&e.d_lut, sizeof lut) != hipSuccess ||
+        hipMemcpy(e.d_lut, lut, sizeof lut, hipMemcpyHostToDevice) != hipSuccess) {
+        delete h;
+        return fail(PSEG_EHIP, "LUT upload failed");
+    }
+    *out = h;
+    return PSEG_OK;
+}
+
+int pseg_destroy(pseg_engine* h) {
+    if (!h) return PSEG_OK;
+    Engine& e = h->e;
+    (void)hipSetDevice(e.device);
+    if (e.stream) (void)hipStreamSynchronize(e.stream);
+    for (auto& t : e.tensors) free_dev(t.d);
+    for (auto& op : e.ops) {
+        free_dev((void*&)op.d_w);
+        free_dev((void*&)op.d_b);
+        free_dev(op.d_wp);
+    }
+    free_dev((void*&)e.d_lut);
+    free_dev((void*&)e.d_logits_tmp);
+    free_dev((void*&)e.d_img_stage);
+    free_dev((void*&)e.d_lab_stage);
+    free_dev((void*&)e.d_prob_stage);
+    free_dev((void*&)e.d_logit_stage);
+    for (auto& s : e.slots)
+        for (auto& pr : s.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto ev : e.event_pool) (void)hipEventDestroy(ev);
+    if (e.stream) (void)hipStreamDestroy(e.stream);
+    delete h;
+    return PSEG_OK;
+}
+
+int pseg_num_weights(const pseg_engine* h) { return h ? (int)h->e.params.size() : 0; }
+
+int pseg_weight_info(const pseg_engine* h, int index, char* name, size_t name_cap,
+                     int64_t shape[4], int* ndim) {
+    if (!h || index < 0 || index >= (int)h->e.params.size()) return fail(PSEG_EINVAL, "bad weight index %d", index);
+    const Param& p = h->e.params[index];
+    if (name && name_cap) {
+        strncpy(name, p.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = i < p.ndim ? p.shape[i] : 1;
+    if (ndim) *ndim = p.ndim;
+    return PSEG_OK;
+}
+
+static Param* find_param(Engine& e, const char* name) {
+    for (auto& p : e.params)
+        if (p.name == name) return &p;
+    return nullptr;
+}
+
+int pseg_set_weights(pseg_engine* h, const char* name, const float* data, const int64_t* shape,
+                     int ndim) {
+    if (!h || !name || !data || !shape) return fail(PSEG_EINVAL, "NULL argument");
+    Param* p = find_param(h->e, name);
+    if (!p) return fail(PSEG_ENOTFOUND, "no weight named '%s'", name);
+    if (ndim != p->ndim) return fail(PSEG_EINVAL, "weight '%s': rank %d, expected %d", name, ndim, p->ndim);
+    for (int i = 0; i < ndim; ++i)
+        if (shape[i] != p->shape[i])
+            return fail(PSEG_EINVAL, "weight '%s': dim %d is %lld, expected %lld", name, i,
+                        (long long)shape[i], (long long)p->shape[i]);
+    std::copy(data, data + p->host.size(), p->host.begin());
+    p->set = true;
+    h->e.weights_dirty = true;
+    return PSEG_OK;
+}
+
+int pseg_get_weights(const pseg_engine* h, const char* name, float* out, int64_t count) {
+    if (!h || !name || !out) return fail(PSEG_EINVAL, "NULL argument");
+    Param* p = find_param(const_cast<Engine&>(h->e), name);
+    if (!p) return fail(PSEG_ENOTFOUND, "no weight named '%s'", name);
+    if (count != (int64_t)p->host.size()) return fail(PSEG_EINVAL, "weight '%s' has %zu elements", name, p->host.size());
+    std::copy(p->host.begin(), p->host.end(), out);
+    return PSEG_OK;
+}
+
+int pseg_predict_device(pseg_engine* h, const uint8_t* d_img, int H, int W, float* d_logits,
+                        float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8, void* stream) {
+    if (!h || !d_img) return fail(PSEG_EINVAL, "NULL argument");
+    hipStream_t st = stream ? (hipStream_t)stream : h->e.stream;
+    return predict_device(h->e, d_img, H, W, d_logits, d_probs, d_labels, d_labels_u8, st);
+}
+
+int pseg_predict(pseg_engine* h, const uint8_t* img, int H, int W, float* logits, float* probs,
+                 int64_t* labels) {
+    if (!h || !img) return fail(PSEG_EINVAL, "NULL argument");
+    if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
+    Engine& e = h->e;
+    PSEG_HIP(hipSetDevice(e.device));
+    const size_t npx = (size_t)H * W, C = e.n_classes;
+    PSEG_TRY(ensure((void**)&e.d_img_stage, &e.img_stage_bytes, npx * e.in_ch));
+    if (labels) PSEG_TRY(ensure((void**)&e.d_lab_stage, &e.lab_stage_bytes, npx * 8));
+    if (probs) PSEG_TRY(ensure((void**)&e.d_prob_stage, &e.prob_stage_bytes, npx * C * 4));
+    if (logits) PSEG_TRY(ensure((void**)&e.d_logit_stage, &e.logit_stage_bytes, npx * C * 4));
+    PSEG_HIP(hipMemcpyAsync(e.d_img_stage, img, npx * e.in_ch, hipMemcpyHostToDevice, e.stream));
+    PSEG_TRY(predict_device(e, e.d_img_stage, H, W, logits ? e.d_logit_stage : nullptr,
+                            probs ? e.d_prob_stage : nullptr, labels ? e.d_lab_stage : nullptr,
+                            nullptr, e.stream));
+    if (logits) PSEG_HIP(hipMemcpyAsync(logits, e.d_logit_stage, npx * C * 4, hipMemcpyDeviceToHost, e.stream));
+    if (probs) PSEG_HIP(hipMemcpyAsync(probs, e.d_prob_stage, npx * C * 4, hipMemcpyDeviceToHost, e.stream));
+    if (labels) PSEG_HIP(hipMemcpyAsync(labels, e.d_lab_stage, npx * 8, hipMemcpyDeviceToHost, e.stream));
+    PSEG_HIP(hipStreamSynchronize(e.stream));
+    return PSEG_OK;
+}
+
+// bf16 -> f32 helper for activation read-back
+static inline float bf16_to_f32(uint16_t v) {
+    uint32_t u = (uint32_t)v << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int pseg_get_activation(pseg_engine* h, const char* layer, float* out, int64_t cap, int dims[3]) {
+    if (!h || !layer) return fail(PSEG_EINVAL, "NULL argument");
+    Engine& e = h->e;
+    PSEG_HIP(hipSetDevice(e.device));
+    for (auto& t : e.tensors) {
+        if (t.name != layer) continue;
+        if (!t.d || e.Hp == 0) return fail(PSEG_EINVAL, "no predict call has run yet");
+        const int H = e.tH(t), W = e.tW(t);
+        if (dims) { dims[0] = H; dims[1] = W; dims[2] = t.C; }
+        const int64_t n = (int64_t)H * W * t.C;
+        if (!out) return PSEG_OK;
+        if (cap < n) return fail(PSEG_EINVAL, "activation '%s' needs %lld floats", layer, (long long)n);
+        PSEG_HIP(hipStreamSynchronize(e.stream));
+        if (e.mode == PSEG_MODE_F32_EXACT) {
+            PSEG_HIP(hipMemcpy(out, t.d, (size_t)n * 4, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<uint16_t> tmp((size_t)H * W * t.Cs);
+            PSEG_HIP(hipMemcpy(tmp.data(), t.d, tmp.size() * 2, hipMemcpyDeviceToHost));
+            for (int64_t p = 0; p < (int64_t)H * W; ++p)
+                for (int c = 0; c < t.C; ++c) out[p * t.C + c] = bf16_to_f32(tmp[(size_t)p * t.Cs + c]);
+        }
+        return PSEG_OK;
+    }
+    return fail(PSEG_ENOTFOUND, "no layer named '%s'", layer);
+}
+
+double pseg_flops_per_pixel(const pseg_engine* h) {
+    if (!h) return 0;
+    double f = 0;
+    for (auto& op : h->e.ops) f += op.flops_per_canvas_px;
+    return f;
+}
+
+int pseg_timing_enable(pseg_engine* h, int on) {
+    if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    h->e.timing = on != 0;
+    return PSEG_OK;
+}
+
+int pseg_timing_reset(pseg_engine* h) {
+    if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    PSEG_TRY(timing_collect(h->e));
+    for (auto& s : h->e.slots) { s.total_ms = 0; s.launches = 0; }
+    return PSEG_OK;
+}
+
+int pseg_timing_num_slots(const pseg_engine* h) { return h ? (int)h->e.slots.size() : 0; }
+
+int pseg_timing_get(pseg_engine* h, int slot, char* name, size_t name_cap, double* total_ms,
+                    int64_t* launches, double* flops) {
+    if (!h || slot < 0 || slot >= (int)h->e.slots.size()) return fail(PSEG_EINVAL, "bad slot %d", slot);
+    PSEG_HIP(hipSetDevice(h->e.device));
+    PSEG_TRY(timing_collect(h->e));
+    const TimingSlot& s = h->e.slots[slot];
+    if (name && name_cap) {
+        strncpy(name, s.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = s.total_ms;
+    if (launches) *launches = s.launches;
+    if (flops) *flops = s.flops;
+    return PSEG_OK;
+}
+
+}  // extern "C"

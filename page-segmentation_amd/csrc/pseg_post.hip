@@ -1,0 +1,554 @@
+// pseg_post.hip -- integer pre/post-process kernels: 4-connected component labelling
+// (lock-free union-find, roots = minimum linear index, hence deterministic), majority vote,
+// bounding-box painting, colour/overlay masks, Otsu histogram + glyph-height statistics.
+//
+// All of it is HBM-bound byte/integer work: one thread per pixel (or per 4 pixels), coalesced
+// row-major access, wave-aggregated atomics where many lanes hit one counter.
+#include <algorithm>
+#include <cstring>
+
+#include "pseg_common.h"
+
+namespace pseg {
+
+// ---------------------------------------------------------------------------------------------
+// connected components (4-connectivity)
+// ---------------------------------------------------------------------------------------------
+// MODE 0: foreground = bin != 0, neighbours connect when both are foreground
+//         (cv2.connectedComponentsWithStats(binary, connectivity=4), lib/postprocess.py:10).
+// MODE 1: every pixel is foreground, neighbours connect when their class is equal
+//         (the per-class labelling of lib/postprocess.py:33 done for all classes at once).
+template <int MODE>
+__device__ __forceinline__ bool is_fg(const uint8_t* bin, const int64_t* cls, int p) {
+    return MODE == 0 ? bin[p] != 0 : true;
+}
+template <int MODE>
+__device__ __forceinline__ bool connects(const uint8_t* bin, const int64_t* cls, int p, int q) {
+    return MODE == 0 ? (bin[q] != 0) : (cls[p] == cls[q]);
+}
+
+__device__ __forceinline__ int uf_find(const int* L, int x) {
+    int r = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (r != x) {
+        x = r;
+        r = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return x;
+}
+
+// Labels only ever decrease and always point at a member of the same component, so a stale
+// read costs extra iterations, never correctness.
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+    while (true) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        const int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+template <int MODE>
+__global__ void ccl_init_kernel(const uint8_t* bin, const int64_t* cls, int* L, int n) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) L[p] = is_fg<MODE>(bin, cls, p) ? p : -1;
+}
+
+// Row pass first (left neighbour) keeps most unions inside a cache line; then the column pass.
+template <int MODE>
+__global__ void ccl_merge_kernel(const uint8_t* bin, const int64_t* cls, int* L, int H, int W,
+                                 int vertical) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    if (!is_fg<MODE>(bin, cls, p)) return;
+    const int y = p / W, x = p - y * W;
+    if (!vertical) {
+        if (x > 0 && connects<MODE>(bin, cls, p, p - 1)) uf_union(L, p, p - 1);
+    } else {
+        if (y > 0 && connects<MODE>(bin, cls, p, p - W)) uf_union(L, p, p - W);
+    }
+}
+
+__global__ void ccl_compress_kernel(int* L, int n) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && L[p] >= 0) L[p] = uf_find(L, p);
+}
+
+template <int MODE>
+static int ccl_run(const uint8_t* d_bin, const int64_t* d_cls, int* d_L, int H, int W,
+                   hipStream_t st) {
+    const int n = H * W;
+    const int grid = cdiv(n, 256);
+    ccl_init_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, n);
+    ccl_merge_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W, 0);
+    ccl_merge_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W, 1);
+    ccl_compress_kernel<<<grid, 256, 0, st>>>(d_L, n);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// majority vote (lib/postprocess.py:9-26)
+// ---------------------------------------------------------------------------------------------
+// hist[root * ncls + class] += 1 with the adds of one wave to one counter merged into a single
+// atomic (neighbouring pixels almost always share root and class).
+__global__ void vote_count_kernel(const int* L, const int64_t* pred, int* hist, int n, int ncls) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int key = -1;
+    if (p < n) {
+        const int r = L[p];
+        const int64_t c = pred[p];
+        if (r >= 0 && c >= 0 && c < ncls) key = r * ncls + (int)c;
+    }
+    unsigned long long todo = __ballot(key >= 0);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lkey = __shfl(key, leader);
+        const unsigned long long same = __ballot(key == lkey);
+        if (lane == leader) atomicAdd(&hist[lkey], (int)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+// The root pixel of every component reduces its histogram: np.argmax(bins[1:]) = lowest class
+// among the most frequent (lib/postprocess.py:22-23).  The winner overwrites slot 0.
+__global__ void vote_winner_kernel(const int* L, int* hist, int n, int ncls) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || L[p] != p) return;
+    int* h = hist + (size_t)p * ncls;
+    int best = 0, bv = h[0];
+    for (int c = 1; c < ncls; ++c)
+        if (h[c] > bv) { bv = h[c]; best = c; }
+    h[0] = best;
+}
+
+__global__ void vote_apply_kernel(const int* L, const int* hist, int64_t* pred, int n, int ncls) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int r = L[p];
+    if (r >= 0) pred[p] = hist[(size_t)r * ncls];
+}
+
+static int cc_vote_device(int64_t* d_pred, const uint8_t* d_bin, int H, int W, int ncls,
+                          hipStream_t st) {
+    if (H <= 0 || W <= 0) return PSEG_OK;
+    if ((int64_t)H * W * std::max(ncls, 1) > 0x7fffffffLL)
+        return fail(PSEG_EUNSUPPORTED, "page too large for 32-bit component indices");
+    const int n = H * W;
+    int* d_L = nullptr;
+    int* d_hist = nullptr;
+    PSEG_HIP(hipMalloc((void**)&d_L, (size_t)n * 4));
+    hipError_t he = hipMalloc((void**)&d_hist, (size_t)n * ncls * 4);
+    if (he != hipSuccess) { (void)hipFree(d_L); return fail(PSEG_ENOMEM, "hipMalloc(hist) failed"); }
+    int rc = ccl_run<0>(d_bin, nullptr, d_L, H, W, st);
+    if (rc == PSEG_OK) {
+        (void)hipMemsetAsync(d_hist, 0, (size_t)n * ncls * 4, st);
+        const int grid = cdiv(n, 256);
+        vote_count_kernel<<<grid, 256, 0, st>>>(d_L, d_pred, d_hist, n, ncls);
+        vote_winner_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, n, ncls);
+        vote_apply_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, d_pred, n, ncls);
+        if (hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "vote kernel launch failed");
+    }
+    (void)hipStreamSynchronize(st);  // workspace is freed below
+    (void)hipFree(d_L);
+    (void)hipFree(d_hist);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bounding boxes of components (shared by bbox fill and char-height statistics)
+// ---------------------------------------------------------------------------------------------
+// box[r] = {min x, min y, max x, max y} for root r; initialised to {INT_MAX, INT_MAX, -1, -1}.
+__global__ void bbox_init_kernel(int4* box, int n) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) box[p] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
+}
+
+// One wave covers 64 consecutive pixels; lanes that share the leader's root first reduce their
+// extent inside the wave so that a large component costs four atomics per wave, not per pixel.
+__global__ void bbox_reduce_kernel(const int* L, const int64_t* cls, int skip_class0, int4* box,
+                                   int H, int W) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = H * W;
+    int r = -1, x = 0, y = 0;
+    if (p < n) {
+        r = L[p];
+        if (skip_class0 && cls && cls[p] == 0) r = -1;
+        y = p / W;
+        x = p - y * W;
+    }
+    unsigned long long todo = __ballot(r >= 0);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lr = __shfl(r, leader);
+        const bool mine = (r == lr);
+        int x0 = mine ? x : 0x7fffffff, y0 = mine ? y : 0x7fffffff;
+        int x1 = mine ? x : -1, y1 = mine ? y : -1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            x0 = min(x0, __shfl_xor(x0, off));
+            y0 = min(y0, __shfl_xor(y0, off));
+            x1 = max(x1, __shfl_xor(x1, off));
+            y1 = max(y1, __shfl_xor(y1, off));
+        }
+        if (lane == leader) {
+            int* b = (int*)&box[lr];
+            atomicMin(b + 0, x0);
+            atomicMin(b + 1, y0);
+            atomicMax(b + 2, x1);
+            atomicMax(b + 3, y1);
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
+struct Comp {
+    int x0, y0, x1, y1, cls;
+};
+
+__global__ void comp_compact_kernel(const int* L, const int64_t* cls, const int4* box, int n,
+                                    Comp* comps, int* count, int cap) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || L[p] != p) return;
+    const int4 b = box[p];
+    if (b.z < 0) return;  // skipped (class 0) component
+    const int i = atomicAdd(count, 1);
+    if (i < cap) comps[i] = Comp{b.x, b.y, b.z, b.w, cls ? (int)cls[p] : 1};
+}
+
+// one workgroup per component paints its box: atomicMax == "later (higher) classes overwrite"
+__global__ void bbox_paint_kernel(const Comp* comps, int* out, int W) {
+    const Comp c = comps[blockIdx.x];
+    const int bw = c.x1 - c.x0 + 1, bh = c.y1 - c.y0 + 1;
+    for (int t = threadIdx.x; t < bw * bh; t += blockDim.x) {
+        const int yy = c.y0 + t / bw, xx = c.x0 + t % bw;
+        atomicMax(&out[(size_t)yy * W + xx], c.cls);
+    }
+}
+
+__global__ void widen_kernel(const int* in, int64_t* out, int n) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = in[p];
+}
+
+static int bbox_fill_device(const int64_t* d_pred, int64_t* d_out, int H, int W, hipStream_t st) {
+    if (H <= 0 || W <= 0) return PSEG_OK;
+    const int n = H * W;
+    const int grid = cdiv(n, 256);
+    int *d_L = nullptr, *d_tmp = nullptr, *d_count = nullptr;
+    int4* d_box = nullptr;
+    Comp* d_comps = nullptr;
+    int rc = PSEG_OK;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d_L); (void)hipFree(d_tmp); (void)hipFree(d_count); (void)hipFree(d_box);
+        (void)hipFree(d_comps);
+    };
+    if (hipMalloc((void**)&d_L, (size_t)n * 4) != hipSuccess ||
+        hipMalloc((void**)&d_tmp, (size_t)n * 4) != hipSuccess ||
+        hipMalloc((void**)&d_count, 4) != hipSuccess ||
+        hipMalloc((void**)&d_box, (size_t)n * sizeof(int4)) != hipSuccess ||
+        hipMalloc((void**)&d_comps, (size_t)n * sizeof(Comp)) != hipSuccess) {
+        cleanup();
+        return fail(PSEG_ENOMEM, "hipMalloc failed in bbox_fill");
+    }
+    rc = ccl_run<1>(nullptr, d_pred, d_L, H, W, st);
+    if (rc != PSEG_OK) { cleanup(); return rc; }
+    (void)hipMemsetAsync(d_tmp, 0, (size_t)n * 4, st);
+    (void)hipMemsetAsync(d_count, 0, 4, st);
+    bbox_init_kernel<<<grid, 256, 0, st>>>(d_box, n);
+    // class 0 paints zeros into a zero image: skip it (and with it the page-sized background)
+    bbox_reduce_kernel<<<grid, 256, 0, st>>>(d_L, d_pred, 1, d_box, H, W);
+    comp_compact_kernel<<<grid, 256, 0, st>>>(d_L, d_pred, d_box, n, d_comps, d_count, n);
+    int count = 0;
+    if (hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        cleanup();
+        return fail(PSEG_EHIP, "bbox_fill: count read-back failed");
+    }
+    if (count > 0) bbox_paint_kernel<<<count, 256, 0, st>>>(d_comps, d_tmp, W);
+    widen_kernel<<<grid, 256, 0, st>>>(d_tmp, d_out, n);
+    if (hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "bbox kernel launch failed");
+    cleanup();
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// colour / overlay masks (lib/output.py:44-60): 4 pixels per thread, 12-byte stores
+// ---------------------------------------------------------------------------------------------
+__global__ void masks_kernel(const int64_t* pred, const uint8_t* bin, const uint8_t* lut, int n_lut,
+                             int n, uint8_t* color, uint8_t* overlay, uint8_t* inverted,
+                             uint8_t* fgc) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 pixels
+    const int p0 = q * 4;
+    if (p0 >= n) return;
+    uint8_t c[12], ov[12], iv[12], fg[12];
+    const int cnt = min(4, n - p0);
+    for (int i = 0; i < 4; ++i) {
+        uint8_t r = 0, g = 0, b = 0, bb = 0;
+        if (i < cnt) {
+            const int64_t l = pred[p0 + i];
+            if (l >= 0 && l < n_lut) { r = lut[l * 3]; g = lut[l * 3 + 1]; b = lut[l * 3 + 2]; }
+            bb = bin[p0 + i];
+        }
+        const uint8_t fgd = (uint8_t)(1 - bb);  // uint8 wrap-around as numpy does
+        c[3 * i] = r; c[3 * i + 1] = g; c[3 * i + 2] = b;
+        const bool ko = fgd == 0, ki = bb == 0, kf = fgd != 0;
+        ov[3 * i] = ko ? 0 : r; ov[3 * i + 1] = ko ? 0 : g; ov[3 * i + 2] = ko ? 0 : b;
+        iv[3 * i] = ki ? 0 : r; iv[3 * i + 1] = ki ? 0 : g; iv[3 * i + 2] = ki ? 0 : b;
+        fg[3 * i] = kf ? 0 : r; fg[3 * i + 1] = kf ? 0 : g; fg[3 * i + 2] = kf ? 0 : b;
+    }
+    auto put = [&](uint8_t* dst, const uint8_t* v) {
+        if (!dst) return;
+        if (cnt == 4) {
+            uint32_t w[3];
+            memcpy(w, v, 12);
+            uint32_t* d = (uint32_t*)(dst + (size_t)p0 * 3);
+            d[0] = w[0]; d[1] = w[1]; d[2] = w[2];
+        } else {
+            for (int i = 0; i < cnt * 3; ++i) dst[(size_t)p0 * 3 + i] = v[i];
+        }
+    };
+    put(color, c);
+    put(overlay, ov);
+    put(inverted, iv);
+    put(fgc, fg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Otsu histogram + binarise (lib/image_ops.py:62-65)
+// ---------------------------------------------------------------------------------------------
+__global__ void hist256_kernel(const uint8_t* img, int n, unsigned* hist) {
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
+        atomicAdd(&h[img[p]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// fg = (pixel > t) != !inverse   (threshold -> 255, then 255 - img unless inverse)
+__global__ void binarize_kernel(const uint8_t* img, int n, int t, int inverse, uint8_t* out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) {
+        const bool above = img[p] > t;
+        out[p] = (above == (inverse != 0)) ? 1 : 0;
+    }
+}
+
+// cv2 getThreshVal_Otsu_8u restated (OpenCV 4.5.5 modules/imgproc/src/thresh.cpp, published
+// algorithm): first maximum of q1*q2*(mu1-mu2)^2, double precision.
+static int otsu_from_hist(const unsigned* h, int64_t n) {
+    const double scale = 1.0 / (double)n;
+    double mu = 0;
+    for (int i = 0; i < 256; ++i) mu += i * (double)h[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0;
+    int max_val = 0;
+    const double eps = 1.1920928955078125e-07;  // FLT_EPSILON
+    for (int i = 0; i < 256; ++i) {
+        const double p_i = h[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1.0 - q1;
+        if (std::min(q1, q2) < eps || std::max(q1, q2) > 1.0 - eps) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+    }
+    return max_val;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+static int set_dev(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return fail(PSEG_EHIP, "no HIP device visible: libpseg has no CPU fallback");
+    if (device < 0 || device >= n) return fail(PSEG_EINVAL, "device %d of %d", device, n);
+    PSEG_HIP(hipSetDevice(device));
+    return PSEG_OK;
+}
+
+extern "C" {
+
+int pseg_cc_vote_device(int device, int64_t* d_pred, const uint8_t* d_binary, int H, int W,
+                        int n_classes, void* stream) {
+    if (!d_pred || !d_binary) return fail(PSEG_EINVAL, "NULL argument");
+    if (n_classes < 1) return fail(PSEG_EINVAL, "n_classes must be >= 1");
+    PSEG_TRY(set_dev(device));
+    return cc_vote_device(d_pred, d_binary, H, W, n_classes, (hipStream_t)stream);
+}
+
+int pseg_cc_vote(int device, int64_t* pred, const uint8_t* binary, int H, int W, int n_classes) {
+    if (!pred || !binary) return fail(PSEG_EINVAL, "NULL argument");
+    if (H < 0 || W < 0) return fail(PSEG_EINVAL, "negative shape");
+    if (H == 0 || W == 0) return PSEG_OK;
+    const size_t n = (size_t)H * W;
+    if (n_classes < 1) {  // derive from the data, as np.bincount does
+        int64_t m = 0;
+        for (size_t i = 0; i < n; ++i) m = std::max(m, pred[i]);
+        n_classes = (int)m + 1;
+    }
+    PSEG_TRY(set_dev(device));
+    int64_t* d_pred = nullptr;
+    uint8_t* d_bin = nullptr;
+    PSEG_HIP(hipMalloc((void**)&d_pred, n * 8));
+    if (hipMalloc((void**)&d_bin, n) != hipSuccess) { (void)hipFree(d_pred); return fail(PSEG_ENOMEM, "hipMalloc failed"); }
+    int rc = PSEG_OK;
+    if (hipMemcpy(d_pred, pred, n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_bin, binary, n, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(PSEG_EHIP, "H2D copy failed");
+    if (rc == PSEG_OK) rc = cc_vote_device(d_pred, d_bin, H, W, n_classes, nullptr);
+    if (rc == PSEG_OK && hipMemcpy(pred, d_pred, n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(PSEG_EHIP, "D2H copy failed");
+    (void)hipFree(d_pred);
+    (void)hipFree(d_bin);
+    return rc;
+}
+
+int pseg_bbox_fill(int device, const int64_t* pred, int64_t* out, int H, int W, int n_classes) {
+    (void)n_classes;
+    if (!pred || !out) return fail(PSEG_EINVAL, "NULL argument");
+    if (H < 0 || W < 0) return fail(PSEG_EINVAL, "negative shape");
+    if (H == 0 || W == 0) return PSEG_OK;
+    if ((int64_t)H * W > 0x7fffffffLL) return fail(PSEG_EUNSUPPORTED, "page too large");
+    const size_t n = (size_t)H * W;
+    PSEG_TRY(set_dev(device));
+    int64_t *d_pred = nullptr, *d_out = nullptr;
+    PSEG_HIP(hipMalloc((void**)&d_pred, n * 8));
+    if (hipMalloc((void**)&d_out, n * 8) != hipSuccess) { (void)hipFree(d_pred); return fail(PSEG_ENOMEM, "hipMalloc failed"); }
+    int rc = PSEG_OK;
+    if (hipMemcpy(d_pred, pred, n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = fail(PSEG_EHIP, "H2D copy failed");
+    if (rc == PSEG_OK) rc = bbox_fill_device(d_pred, d_out, H, W, nullptr);
+    if (rc == PSEG_OK && hipMemcpy(out, d_out, n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(PSEG_EHIP, "D2H copy failed");
+    (void)hipFree(d_pred);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int pseg_masks_device(int device, const int64_t* d_pred, const uint8_t* d_binary,
+                      const uint8_t* d_lut, int n_lut, int H, int W, uint8_t* d_color,
+                      uint8_t* d_overlay, uint8_t* d_inverted, uint8_t* d_fg_color, void* stream) {
+    if (!d_pred || !d_binary || !d_lut) return fail(PSEG_EINVAL, "NULL argument");
+    if (H <= 0 || W <= 0) return PSEG_OK;
+    PSEG_TRY(set_dev(device));
+    const int n = H * W;
+    masks_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, (hipStream_t)stream>>>(
+        d_pred, d_binary, d_lut, n_lut, n, d_color, d_overlay, d_inverted, d_fg_color);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+int pseg_masks(int device, const int64_t* pred, const uint8_t* binary, const uint8_t* lut,
+               int n_lut, int H, int W, uint8_t* color, uint8_t* overlay, uint8_t* inverted,
+               uint8_t* fg_color) {
+    if (!pred || !binary || !lut || n_lut < 1) return fail(PSEG_EINVAL, "bad argument");
+    if (H < 0 || W < 0) return fail(PSEG_EINVAL, "negative shape");
+    if (H == 0 || W == 0) return PSEG_OK;
+    PSEG_TRY(set_dev(device));
+    const size_t n = (size_t)H * W;
+    // one slab: pred | 4 outputs (16-byte aligned each: the kernel stores dwords) | binary | lut
+    uint8_t* d = nullptr;
+    const size_t ostride = (n * 3 + 15) & ~(size_t)15;
+    const size_t off_out = n * 8, off_bin = off_out + 4 * ostride;
+    const size_t off_lut_al = (off_bin + n + 15) & ~(size_t)15;
+    PSEG_HIP(hipMalloc((void**)&d, off_lut_al + (size_t)n_lut * 3));
+    int rc = PSEG_OK;
+    if (hipMemcpy(d, pred, n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + off_bin, binary, n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + off_lut_al, lut, (size_t)n_lut * 3, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(PSEG_EHIP, "H2D copy failed");
+    uint8_t* o[4] = {color, overlay, inverted, fg_color};
+    uint8_t* dv[4];
+    for (int i = 0; i < 4; ++i) dv[i] = o[i] ? d + off_out + (size_t)i * ostride : nullptr;
+    if (rc == PSEG_OK)
+        rc = pseg_masks_device(device, (const int64_t*)d, d + off_bin, d + off_lut_al, n_lut, H, W,
+                               dv[0], dv[1], dv[2], dv[3], nullptr);
+    for (int i = 0; i < 4 && rc == PSEG_OK; ++i)
+        if (o[i] && hipMemcpy(o[i], dv[i], n * 3, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(PSEG_EHIP, "D2H copy failed");
+    (void)hipFree(d);
+    return rc;
+}
+
+int pseg_otsu_char_height(int device, const uint8_t* gray, int H, int W, int inverse, int* height,
+                          int* otsu) {
+    if (!gray || !height) return fail(PSEG_EINVAL, "NULL argument");
+    if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty image");
+    if ((int64_t)H * W > 0x7fffffffLL) return fail(PSEG_EUNSUPPORTED, "image too large");
+    PSEG_TRY(set_dev(device));
+    const int n = H * W;
+    const int grid = cdiv(n, 256);
+    uint8_t *d_img = nullptr, *d_bin = nullptr;
+    unsigned* d_hist = nullptr;
+    int *d_L = nullptr, *d_count = nullptr;
+    int4* d_box = nullptr;
+    Comp* d_comps = nullptr;
+    int rc = PSEG_OK;
+    auto cleanup = [&]() {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(d_img); (void)hipFree(d_bin); (void)hipFree(d_hist); (void)hipFree(d_L);
+        (void)hipFree(d_count); (void)hipFree(d_box); (void)hipFree(d_comps);
+    };
+    if (hipMalloc((void**)&d_img, n) != hipSuccess || hipMalloc((void**)&d_bin, n) != hipSuccess ||
+        hipMalloc((void**)&d_hist, 256 * 4) != hipSuccess || hipMalloc((void**)&d_L, (size_t)n * 4) != hipSuccess ||
+        hipMalloc((void**)&d_count, 4) != hipSuccess || hipMalloc((void**)&d_box, (size_t)n * sizeof(int4)) != hipSuccess ||
+        hipMalloc((void**)&d_comps, (size_t)n * sizeof(Comp)) != hipSuccess) {
+        cleanup();
+        return fail(PSEG_ENOMEM, "hipMalloc failed in otsu_char_height");
+    }
+    unsigned hist[256];
+    if (hipMemcpy(d_img, gray, n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(d_hist, 0, 256 * 4) != hipSuccess) {
+        cleanup();
+        return fail(PSEG_EHIP, "H2D copy failed");
+    }
+    hist256_kernel<<<std::min(grid, 2048), 256>>>(d_img, n, d_hist);
+    if (hipMemcpy(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost) != hipSuccess) {
+        cleanup();
+        return fail(PSEG_EHIP, "histogram read-back failed");
+    }
+    const int t = otsu_from_hist(hist, n);
+    if (otsu) *otsu = t;
+    binarize_kernel<<<grid, 256>>>(d_img, n, t, inverse, d_bin);
+    rc = ccl_run<0>(d_bin, nullptr, d_L, H, W, nullptr);
+    if (rc != PSEG_OK) { cleanup(); return rc; }
+    (void)hipMemset(d_count, 0, 4);
+    bbox_init_kernel<<<grid, 256>>>(d_box, n);
+    bbox_reduce_kernel<<<grid, 256>>>(d_L, nullptr, 0, d_box, H, W);
+    comp_compact_kernel<<<grid, 256>>>(d_L, nullptr, d_box, n, d_comps, d_count, n);
+    int count = 0;
+    if (hipMemcpy(&count, d_count, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        cleanup();
+        return fail(PSEG_EHIP, "count read-back failed");
+    }
+    std::vector<Comp> comps((size_t)count);
+    if (count > 0 && hipMemcpy(comps.data(), d_comps, (size_t)count * sizeof(Comp), hipMemcpyDeviceToHost) != hipSuccess) {
+        cleanup();
+        return fail(PSEG_EHIP, "component read-back failed");
+    }
+    cleanup();
+    // lib/image_ops.py:70-79: glyph-shaped components, upper median of heights
+    std::vector<int> hs;
+    for (auto& c : comps) {
+        const int w = c.x1 - c.x0 + 1, h = c.y1 - c.y0 + 1;
+        const double ar = (double)w / (double)h;
+        if (0.5 < ar && ar < 2 && 10 < h && h < 60 && 5 < w && w < 50) hs.push_back(h);
+    }
+    if (hs.empty()) { *height = -1; return PSEG_OK; }
+    std::sort(hs.begin(), hs.end());
+    *height = hs[hs.size() / 2];
+    return PSEG_OK;
+}
+
+}  // extern "C"

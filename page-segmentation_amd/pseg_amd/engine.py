@@ -1,0 +1,238 @@
+"""ctypes binding of include/pseg.h.  No compute happens in Python; there is no CPU fallback:
+every call raises PsegError when libpseg.so or a HIP device is missing."""
+import ctypes
+import os
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+
+ARCH_IDS = {"fcn_skip": 0, "fcn": 1, "unet": 2, "res_unet": 3}
+MODE_F32_EXACT = 0
+MODE_BF16 = 1
+
+# every symbol include/pseg.h declares (tests check that the library exports each one)
+EXPORTED_SYMBOLS = (
+    "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_destroy",
+    "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
+    "pseg_predict", "pseg_predict_device", "pseg_get_activation", "pseg_flops_per_pixel",
+    "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
+    "pseg_cc_vote", "pseg_cc_vote_device", "pseg_bbox_fill", "pseg_masks", "pseg_masks_device",
+    "pseg_otsu_char_height",
+)
+
+
+class PsegError(Exception):
+    """The reference raises bare Exception(...) (lib/dataset.py:67, lib/trainer.py:133)."""
+
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(_CSRC, "libpseg.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise PsegError("libpseg.so is not built (%s); run __graft_entry__.build() -- there is "
+                        "no CPU fallback" % path)
+    L = ctypes.CDLL(path)
+    c = ctypes
+    vp, i, i64 = c.c_void_p, c.c_int, c.c_int64
+    L.pseg_last_error.restype = c.c_char_p
+    L.pseg_create.argtypes = [i, i, i, i, i, c.POINTER(vp)]
+    L.pseg_destroy.argtypes = [vp]
+    L.pseg_num_weights.argtypes = [vp]
+    L.pseg_weight_info.argtypes = [vp, i, c.c_char_p, c.c_size_t, c.POINTER(i64), c.POINTER(i)]
+    L.pseg_set_weights.argtypes = [vp, c.c_char_p, vp, c.POINTER(i64), i]
+    L.pseg_get_weights.argtypes = [vp, c.c_char_p, vp, i64]
+    L.pseg_predict.argtypes = [vp, vp, i, i, vp, vp, vp]
+    L.pseg_predict_device.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp]
+    L.pseg_get_activation.argtypes = [vp, c.c_char_p, vp, i64, c.POINTER(i)]
+    L.pseg_flops_per_pixel.argtypes = [vp]
+    L.pseg_flops_per_pixel.restype = c.c_double
+    L.pseg_timing_enable.argtypes = [vp, i]
+    L.pseg_timing_reset.argtypes = [vp]
+    L.pseg_timing_num_slots.argtypes = [vp]
+    L.pseg_timing_get.argtypes = [vp, i, c.c_char_p, c.c_size_t, c.POINTER(c.c_double),
+                                  c.POINTER(i64), c.POINTER(c.c_double)]
+    L.pseg_cc_vote.argtypes = [i, vp, vp, i, i, i]
+    L.pseg_cc_vote_device.argtypes = [i, vp, vp, i, i, i, vp]
+    L.pseg_bbox_fill.argtypes = [i, vp, vp, i, i, i]
+    L.pseg_masks.argtypes = [i, vp, vp, vp, i, i, i, vp, vp, vp, vp]
+    L.pseg_masks_device.argtypes = [i, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp]
+    L.pseg_otsu_char_height.argtypes = [i, vp, i, i, i, c.POINTER(i), c.POINTER(i)]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise PsegError(lib().pseg_last_error().decode("utf-8", "replace") or "pseg error %d" % rc)
+
+
+def device_count():
+    return int(lib().pseg_device_count())
+
+
+def _ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    """Opaque pseg_engine handle: one FCN graph + its weights resident on one GPU."""
+
+    def __init__(self, arch="fcn_skip", n_classes=3, in_channels=1, device=0, mode=MODE_BF16):
+        self._h = None
+        L = lib()
+        arch_id = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
+        h = ctypes.c_void_p()
+        _check(L.pseg_create(arch_id, int(n_classes), int(in_channels), int(device), int(mode),
+                             ctypes.byref(h)))
+        self._h = h
+        self.arch = arch
+        self.n_classes = int(n_classes)
+        self.in_channels = int(in_channels)
+        self.device = int(device)
+        self.mode = int(mode)
+
+    def close(self):
+        if self._h is not None:
+            lib().pseg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights -------------------------------------------------------------------------------
+    def weight_specs(self):
+        L = lib()
+        out = []
+        name = ctypes.create_string_buffer(128)
+        shape = (ctypes.c_int64 * 4)()
+        nd = ctypes.c_int()
+        for i in range(L.pseg_num_weights(self._h)):
+            _check(L.pseg_weight_info(self._h, i, name, 128, shape, ctypes.byref(nd)))
+            out.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value))))
+        return out
+
+    def set_weights(self, weights):
+        """weights: mapping name -> ndarray in Keras layout."""
+        L = lib()
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shp = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+            _check(L.pseg_set_weights(self._h, name.encode(), _ptr(a), shp, a.ndim))
+
+    def get_weights(self):
+        L = lib()
+        out = {}
+        for name, shp in self.weight_specs():
+            a = np.empty(shp, np.float32)
+            _check(L.pseg_get_weights(self._h, name.encode(), _ptr(a), a.size))
+            out[name] = a
+        return out
+
+    # -- predict -------------------------------------------------------------------------------
+    def predict(self, image, want_logits=True, want_probs=True, want_labels=True):
+        """uint8 (H,W) [or (H,W,3)] -> (logits f32 (H,W,C) | None, probs | None, labels int64 | None).
+        Mirrors Network.predict_single_data (lib/network.py:248-260)."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        if img.ndim == 3 and img.shape[2] == 1:
+            img = img[..., 0]
+        if img.ndim != (2 if self.in_channels == 1 else 3):
+            raise PsegError("image of shape %r does not match in_channels=%d" % (img.shape, self.in_channels))
+        H, W = img.shape[:2]
+        C = self.n_classes
+        logits = np.empty((H, W, C), np.float32) if want_logits else None
+        probs = np.empty((H, W, C), np.float32) if want_probs else None
+        labels = np.empty((H, W), np.int64) if want_labels else None
+        _check(lib().pseg_predict(self._h, _ptr(img), H, W, _ptr(logits), _ptr(probs), _ptr(labels)))
+        return logits, probs, labels
+
+    def predict_device(self, d_img, H, W, d_logits=0, d_probs=0, d_labels=0, d_labels_u8=0, stream=0):
+        """Raw device pointers (ints, e.g. torch.Tensor.data_ptr()); asynchronous."""
+        _check(lib().pseg_predict_device(self._h, ctypes.c_void_p(d_img), int(H), int(W),
+                                         ctypes.c_void_p(d_logits or None), ctypes.c_void_p(d_probs or None),
+                                         ctypes.c_void_p(d_labels or None), ctypes.c_void_p(d_labels_u8 or None),
+                                         ctypes.c_void_p(stream or None)))
+
+    def activation(self, layer):
+        dims = (ctypes.c_int * 3)()
+        _check(lib().pseg_get_activation(self._h, layer.encode(), None, 0, dims))
+        out = np.empty((dims[0], dims[1], dims[2]), np.float32)
+        _check(lib().pseg_get_activation(self._h, layer.encode(), _ptr(out), out.size, dims))
+        return out
+
+    def flops_per_pixel(self):
+        return float(lib().pseg_flops_per_pixel(self._h))
+
+    # -- per-kernel timing (HIP events on the launch stream) -------------------------------------
+    def timing_enable(self, on=True):
+        _check(lib().pseg_timing_enable(self._h, int(bool(on))))
+
+    def timing_reset(self):
+        _check(lib().pseg_timing_reset(self._h))
+
+    def timing(self):
+        """[(layer, total_ms, launches, algorithmic_flops_per_launch)]"""
+        L = lib()
+        out = []
+        name = ctypes.create_string_buffer(128)
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        for i in range(L.pseg_timing_num_slots(self._h)):
+            _check(L.pseg_timing_get(self._h, i, name, 128, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+            out.append((name.value.decode(), ms.value, n.value, fl.value))
+        return out
+
+
+# -- post-process (host arrays) ----------------------------------------------------------------
+def cc_vote(pred, binary, n_classes=0, device=0):
+    """vote_connected_component_class (lib/postprocess.py:9-26); `pred` int64 is updated IN PLACE
+    (as the reference does) and returned."""
+    if pred.dtype != np.int64 or not pred.flags.c_contiguous:
+        raise PsegError("pred must be a C-contiguous int64 array")
+    b = np.ascontiguousarray(binary, dtype=np.uint8)
+    if b.shape != pred.shape:
+        raise PsegError("binary shape %r != pred shape %r" % (b.shape, pred.shape))
+    H, W = pred.shape
+    _check(lib().pseg_cc_vote(int(device), _ptr(pred), _ptr(b), H, W, int(n_classes)))
+    return pred
+
+
+def bbox_fill(pred, n_classes=0, device=0):
+    p = np.ascontiguousarray(pred, dtype=np.int64)
+    out = np.zeros_like(p)
+    H, W = p.shape
+    _check(lib().pseg_bbox_fill(int(device), _ptr(p), _ptr(out), H, W, int(n_classes)))
+    return out
+
+
+def masks(pred, binary, lut, device=0):
+    """generate_output_masks (lib/output.py:44-60) -> (color, overlay, inverted, fg_color)."""
+    p = np.ascontiguousarray(pred, dtype=np.int64)
+    b = np.ascontiguousarray(binary, dtype=np.uint8)
+    t = np.ascontiguousarray(lut, dtype=np.uint8).reshape(-1, 3)
+    H, W = p.shape
+    outs = [np.empty((H, W, 3), np.uint8) for _ in range(4)]
+    _check(lib().pseg_masks(int(device), _ptr(p), _ptr(b), _ptr(t), t.shape[0], H, W,
+                            *[_ptr(o) for o in outs]))
+    return tuple(outs)
+
+
+def otsu_char_height(gray, inverse=False, device=0):
+    """(char_height or None, otsu_threshold) -- lib/image_ops.py:58-82 without the file read."""
+    g = np.ascontiguousarray(gray, dtype=np.uint8)
+    H, W = g.shape
+    h, t = ctypes.c_int(), ctypes.c_int()
+    _check(lib().pseg_otsu_char_height(int(device), _ptr(g), H, W, int(bool(inverse)),
+                                       ctypes.byref(h), ctypes.byref(t)))
+    return (None if h.value < 0 else h.value), t.value

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "page-segmentation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.build()
+    return oracle
+
+
+def _have_gpu():
+    try:
+        import pseg_amd
+        return pseg_amd.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """GPU tests fail loudly (never skip silently) when the HIP extension or device is missing."""
+    import pseg_amd
+    n = pseg_amd.device_count()
+    assert n > 0, "no HIP device visible: -m gpu tests need the MI355X box"
+    return pseg_amd

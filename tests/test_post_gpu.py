@@ -1,0 +1,80 @@
+"""Integer post-process kernels (CC vote, bbox fill, masks, Otsu/char height) vs the oracle:
+bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng, H, W, C, density=0.35):
+    pred = rng.integers(0, C, size=(H, W)).astype(np.int64)
+    # blocky class regions + noisy binary with blobs
+    yy, xx = np.mgrid[0:H, 0:W]
+    pred = ((yy // 7 + xx // 11 + pred // max(C - 1, 1)) % C).astype(np.int64)
+    binary = (rng.random((H, W)) < density).astype(np.uint8)
+    return pred, binary
+
+
+@pytest.mark.parametrize("H,W,C", [(1, 1, 3), (5, 64, 3), (64, 5, 6), (97, 131, 3), (256, 192, 6), (300, 517, 4)])
+def test_cc_vote(gpu, oracle_mod, H, W, C):
+    rng = np.random.default_rng(H * 1000 + W)
+    pred, binary = _case(rng, H, W, C)
+    want = oracle_mod.vote_connected_component_class(pred, binary)
+    got = gpu.cc_vote(pred.copy(), binary, C)
+    assert np.array_equal(got, want)
+
+
+def test_cc_vote_ties_and_edges(gpu, oracle_mod):
+    # tie -> lowest class; all-ink; no ink; binary with values > 1 (non-zero = ink for cv2)
+    pred = np.array([[2, 1, 1, 2], [0, 0, 0, 0]], np.int64)
+    binary = np.array([[1, 1, 1, 1], [0, 0, 0, 0]], np.uint8)
+    assert np.array_equal(gpu.cc_vote(pred.copy(), binary, 3), oracle_mod.vote_connected_component_class(pred, binary))
+    assert gpu.cc_vote(pred.copy(), binary, 3)[0].tolist() == [1, 1, 1, 1]
+    ones = np.ones((40, 70), np.uint8)
+    p2 = np.random.default_rng(0).integers(0, 5, (40, 70)).astype(np.int64)
+    assert np.array_equal(gpu.cc_vote(p2.copy(), ones, 5), oracle_mod.vote_connected_component_class(p2, ones))
+    assert np.array_equal(gpu.cc_vote(p2.copy(), ones * 0, 5), p2)
+    assert np.array_equal(gpu.cc_vote(p2.copy(), ones * 255, 5), oracle_mod.vote_connected_component_class(p2, ones * 255))
+    # spiral / snake component stresses the union-find
+    snake = np.zeros((65, 65), np.uint8)
+    snake[::2, :] = 1
+    snake[1::4, -1] = 1
+    snake[3::4, 0] = 1
+    p3 = np.ascontiguousarray(np.tile(p2, (2, 1))[:65, :65])
+    assert np.array_equal(gpu.cc_vote(p3.copy(), snake, 5), oracle_mod.vote_connected_component_class(p3, snake))
+
+
+@pytest.mark.parametrize("H,W,C", [(1, 1, 2), (37, 64, 3), (128, 97, 6)])
+def test_bbox_fill(gpu, oracle_mod, H, W, C):
+    rng = np.random.default_rng(H + W)
+    pred = np.zeros((H, W), np.int64)
+    for _ in range(12):
+        y, x = rng.integers(0, H), rng.integers(0, W)
+        h, w = rng.integers(1, max(2, H // 3)), rng.integers(1, max(2, W // 3))
+        pred[y:y + h, x:x + w] = rng.integers(0, C)
+    pred[rng.random((H, W)) < 0.02] = C - 1
+    assert np.array_equal(gpu.bbox_fill(pred, C), oracle_mod.add_bounding_boxes(pred))
+
+
+@pytest.mark.parametrize("H,W", [(1, 1), (3, 5), (64, 64), (97, 131)])
+def test_masks(gpu, oracle_mod, H, W):
+    rng = np.random.default_rng(H * W)
+    pred = rng.integers(0, 6, (H, W)).astype(np.int64)
+    binary = rng.integers(0, 2, (H, W)).astype(np.uint8)
+    lut = rng.integers(0, 256, (6, 3)).astype(np.uint8)
+    want = oracle_mod.generate_output_masks(pred, binary, lut)
+    got = gpu.masks(pred, binary, lut)
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+
+
+def test_otsu_char_height(gpu, oracle_mod):
+    import pseg_amd.synth as synth
+    img, binary, mask = synth.synth_page(0, 512, 512)
+    gray = 255 - img                      # the un-inverted scan
+    h, t = gpu.otsu_char_height(gray, inverse=False)
+    assert t == oracle_mod.otsu_threshold(gray)
+    assert h == oracle_mod.compute_char_height_from_gray(gray, inverse=False)
+    flat = np.full((64, 64), 200, np.uint8)
+    h2, _ = gpu.otsu_char_height(flat)
+    assert h2 is None and oracle_mod.compute_char_height_from_gray(flat) is None

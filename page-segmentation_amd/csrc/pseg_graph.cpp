@@ -31,16 +31,34 @@ struct Builder {
         e.tensors.push_back(t);
         return (int)e.tensors.size() - 1;
     }
+    // Reserve the weight-table slots of a layer whose op is created later than its Keras
+    // name (residual blocks): the table stays in Keras creation order.
+    std::string reserve(const std::string& base) {
+        std::string name = nm(base);
+        for (const char* suf : {"/kernel", "/bias"}) {
+            Param p;
+            p.name = name + suf;
+            e.params.push_back(p);
+        }
+        return name;
+    }
     int param(const std::string& name, std::initializer_list<int64_t> shp) {
-        Param p;
-        p.name = name;
+        int idx = -1;
+        for (size_t j = 0; j < e.params.size(); ++j)
+            if (e.params[j].name == name) idx = (int)j;
+        if (idx < 0) {
+            Param p;
+            p.name = name;
+            e.params.push_back(p);
+            idx = (int)e.params.size() - 1;
+        }
+        Param& p = e.params[idx];
         p.ndim = (int)shp.size();
         int i = 0;
         int64_t n = 1;
         for (auto v : shp) { p.shape[i++] = v; n *= v; }
         p.host.assign((size_t)n, 0.0f);
-        e.params.push_back(p);
-        return (int)e.params.size() - 1;
+        return idx;
     }
     int cin_of(int src0, int src1) const {
         return e.tensors[src0].C + (src1 >= 0 ? e.tensors[src1].C : 0);
@@ -198,15 +216,15 @@ void build_res_unet(Engine& e) {
     // residual_block: names allocated in Keras creation order (conv_block1, conv_block2, shortcut)
     auto residual = [&](int s0, int s1, int up0, int filters, int stride) {
         int r = b.conv(s0, s1, filters, 3, false, stride, "", /*in_relu=*/true, -1, up0, 0);
-        std::string n2 = b.nm("conv2d");
-        std::string nsc = b.nm("conv2d");
+        std::string n2 = b.reserve("conv2d");
+        std::string nsc = b.reserve("conv2d");
         int sc = b.conv(s0, s1, filters, 3, false, stride, nsc, false, -1, up0, 0);
         return b.conv(r, -1, filters, 3, false, 1, n2, /*in_relu=*/true, /*add=*/sc);
     };
     // stem :251-257
     int s = b.conv(x, -1, f[0], 3, false);
-    std::string n2 = b.nm("conv2d");
-    int sc = b.conv(x, -1, f[0], 1, false, 1, b.nm("conv2d"));
+    std::string n2 = b.reserve("conv2d");
+    int sc = b.conv(x, -1, f[0], 1, false, 1, b.reserve("conv2d"));
     int e1 = b.conv(s, -1, f[0], 3, false, 1, n2, true, sc);
     int e2 = residual(e1, -1, 0, f[1], 2);
     int e3 = residual(e2, -1, 0, f[2], 2);

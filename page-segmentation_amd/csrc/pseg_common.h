@@ -70,16 +70,18 @@ struct Op {
     // device weights
     float* d_w = nullptr;     // f32 correlation form [KH][KW][Cin][Cout] (+slack) / [2][2][Cin][Cout]
     float* d_b = nullptr;     // f32 bias
-    void* d_wp = nullptr;     // bf16 packed MFMA B-fragments (pseg_mfma.hip)
-    size_t wp_bytes = 0;
-    int mfma_cfg[8] = {0};    // kernel-specific packing geometry
+    void* plan = nullptr;     // bf16 mode: MfmaPlan (pseg_mfma.hip), owned by the op
+    bool fused_away = false;  // bf16 mode: OP_POOL folded into the producing conv's epilogue
     double flops_per_canvas_px = 0;  // algorithmic, true channels
     int timing_slot = -1;
 };
 
 // ---- bf16 MFMA path (pseg_mfma.hip) ----------------------------------------------------------
 struct Engine;
-int mfma_pack_op(Engine& e, Op& op);                         // host-side packing + upload
+// host-side packing + upload; w = correlation-form f32 weights as uploaded for the exact path
+int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vector<float>& bias);
+void mfma_free_op(Op& op);
+int mfma_plan_graph(Engine& e);                              // pool fusion etc., once per engine
 int mfma_launch_conv(Engine& e, Op& op, hipStream_t st);     // OP_CONV
 int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st);  // OP_DECONV2
 int mfma_launch_pool(Engine& e, Op& op, hipStream_t st);     // OP_POOL (unfused fallback)
@@ -106,6 +108,7 @@ struct Engine {
     int H = 0, W = 0, Hp = 0, Wp = 0;
     bool weights_dirty = true;
     float* d_lut = nullptr;        // 256-entry u/255 table (f32)
+    const uint8_t* cur_img = nullptr;  // bf16 mode: the uint8 page of the running predict call
     float* d_logits_tmp = nullptr; // H*W*C f32 when the caller does not want logits
     size_t logits_tmp_bytes = 0;
     uint8_t* d_img_stage = nullptr;

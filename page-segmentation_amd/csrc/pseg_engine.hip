@@ -303,7 +303,7 @@ static int upload_weights(Engine& e) {
         PSEG_HIP(hipMalloc((void**)&op.d_b, (size_t)round_up(Cout, COT) * sizeof(float)));
         PSEG_HIP(hipMemset(op.d_b, 0, (size_t)round_up(Cout, COT) * sizeof(float)));
         PSEG_HIP(hipMemcpy(op.d_b, bp.host.data(), (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
-        if (e.mode == PSEG_MODE_BF16) PSEG_TRY(mfma_pack_op(e, op));
+        if (e.mode == PSEG_MODE_BF16) PSEG_TRY(mfma_pack_op(e, op, w, bp.host));
     }
     e.weights_dirty = false;
     return PSEG_OK;
@@ -325,8 +325,13 @@ static int set_canvas(Engine& e, int H, int W) {
             t.bytes = 0;
             PSEG_HIP(hipMalloc(&t.d, bytes));
             t.bytes = bytes;
+            PSEG_HIP(hipMemset(t.d, 0, bytes));
         }
     }
+    // bf16 pad channels that no kernel writes must read as zero after a layout change
+    if (e.mode == PSEG_MODE_BF16)
+        for (auto& t : e.tensors)
+            if (t.d) PSEG_HIP(hipMemset(t.d, 0, t.bytes));
     const double px = (double)Hp * Wp;
     for (auto& op : e.ops) e.slots[op.timing_slot].flops = op.flops_per_canvas_px * px;
     return PSEG_OK;
@@ -434,6 +439,7 @@ static int run_bf16(Engine& e, const uint8_t* d_img, float* d_logits, float* d_p
                     int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st) {
     PSEG_TRY(mfma_preprocess(e, d_img, st));
     for (auto& op : e.ops) {
+        if (op.fused_away) continue;
         hipEvent_t ev0;
         PSEG_TRY(time_begin(e, op, st, &ev0));
         switch (op.type) {
@@ -506,6 +512,7 @@ int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
     e.device = device;
     e.mode = mode;
     int rc = build_graph(e);
+    if (rc == PSEG_OK && mode == PSEG_MODE_BF16) rc = mfma_plan_graph(e);
     if (rc != PSEG_OK) { delete h; return rc; }
     if (hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -531,7 +538,7 @@ int pseg_destroy(pseg_engine* h) {
     for (auto& op : e.ops) {
         free_dev((void*&)op.d_w);
         free_dev((void*&)op.d_b);
-        free_dev(op.d_wp);
+        mfma_free_op(op);
     }
     free_dev((void*&)e.d_lut);
     free_dev((void*&)e.d_logits_tmp);

@@ -1,15 +1,807 @@
-// pseg_mfma.hip -- bf16 throughput mode (placeholder until the MFMA kernels land).
+// pseg_mfma.hip -- bf16 throughput mode: NHWC bf16 activations (channels padded to 8), bf16
+// kernels, float32 MFMA accumulation (v_mfma_f32_16x16x32_bf16), gfx950 only.
+//
+// conv_mfma_kernel: implicit GEMM.  D[cout][pixel] += W[cout][k] * X[k][pixel] with
+//   k = (tap, channel-chunk of 8) in a host-chosen order.  Per workgroup (256 threads = 4 waves):
+//   * the input halo tile of one channel block is staged once into LDS as [row][pixel][chunk];
+//     the pixel stride is sigma*16 B with sigma = 2 (mod 4) and the row pitch an odd number of
+//     16-B slots, which makes every ds_read_b128 im2col fragment read bank-conflict-free when
+//     the two k-chunks a lane-group pair reads differ by an odd slot count (tools/lds_conflicts.py);
+//     the host orders the chunks to satisfy that (pair_chunks()).
+//   * weights are pre-packed on the host in MFMA A-fragment order and streamed through LDS in
+//     groups of GK k-steps by LDS-DMA (global_load_lds_dwordx4), double-buffered.
+//   * each wave owns MT pixel tiles (16 consecutive x) x NT cout tiles (16) of accumulators.
+//   * epilogue: +bias, (+residual), ReLU, bf16, transpose through LDS, coalesced 16-B NHWC
+//     stores, optional fused 2x2 max-pool output.
+//   The same kernel runs Conv2DTranspose k2 s2 as a 1x1 GEMM with N = 4*Cout and a scatter
+//   epilogue.
+#include <algorithm>
+#include <cstring>
+
 #include "pseg_common.h"
 
 namespace pseg {
 
-int mfma_pack_op(Engine&, Op&) { return fail(PSEG_EUNSUPPORTED, "bf16 mode not built yet"); }
-int mfma_launch_conv(Engine&, Op&, hipStream_t) { return fail(PSEG_EUNSUPPORTED, "bf16 mode not built yet"); }
-int mfma_launch_deconv2(Engine&, Op&, hipStream_t) { return fail(PSEG_EUNSUPPORTED, "bf16 mode not built yet"); }
-int mfma_launch_pool(Engine&, Op&, hipStream_t) { return fail(PSEG_EUNSUPPORTED, "bf16 mode not built yet"); }
-int mfma_launch_logits(Engine&, Op&, float*, float*, int64_t*, uint8_t*, hipStream_t) {
-    return fail(PSEG_EUNSUPPORTED, "bf16 mode not built yet");
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int TW = 32;          // output tile width (two 16-pixel MFMA column tiles)
+constexpr int MAX_TAB = 1024;   // k-chunks per channel block (KS*KS*nc + padding)
+
+// ---- host bf16 helpers -----------------------------------------------------------------------
+static inline uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u = u + 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
 }
-int mfma_preprocess(Engine&, const uint8_t*, hipStream_t) { return fail(PSEG_EUNSUPPORTED, "bf16 mode not built yet"); }
+static inline float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+__device__ __forceinline__ float d_bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t d_f2bf(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even
+    return __builtin_bit_cast(uint16_t, b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic MFMA conv
+// ---------------------------------------------------------------------------------------------
+struct MConv {
+    const uint16_t* src0;
+    const uint16_t* src1;
+    int nch0, nch1;      // 16-byte chunks per pixel of src0 / src1 (Cs / 8)
+    int up0, up1;
+    int Hin, Win, Hout, Wout;
+    int stride, pt, pl, in_relu, relu;
+    // K structure: nblk channel blocks of nc_full chunks (last: nc_last)
+    int nblk, nc_full, nc_last, ks_full, ks_last;
+    const int* tab_full;  // [ks_full*4] byte offsets of the k-chunks in the LDS input tile
+    const int* tab_last;
+    const uint16_t* wpk;  // [kstep][NTtot][64 lanes][8] bf16
+    int NTtot;
+    const float* bias;    // [NTtot*16]
+    // LDS geometry
+    int PS2, row_pitch, THH, TWH, GK, lds_w_off, lds_tab_off;
+    // output
+    uint16_t* dst;
+    int nch_out;
+    uint16_t* pool_dst;
+    const uint16_t* add;
+    int deconv, CoP;
+};
+
+__device__ __forceinline__ uint4 relu_bf16x8(uint4 v) {
+    auto f = [](uint32_t w) -> uint32_t {
+        if (w & 0x8000u) w &= 0xffff0000u;
+        if (w & 0x80000000u) w &= 0x0000ffffu;
+        return w;
+    };
+    return make_uint4(f(v.x), f(v.y), f(v.z), f(v.w));
+}
+
+__device__ __forceinline__ uint4 max_bf16x8(uint4 a, uint4 b) {
+    auto m = [](uint32_t x, uint32_t y) -> uint32_t {
+        const float xl = __uint_as_float(x << 16), yl = __uint_as_float(y << 16);
+        const float xh = __uint_as_float(x & 0xffff0000u), yh = __uint_as_float(y & 0xffff0000u);
+        const uint32_t lo = (xl > yl ? x : y) & 0xffffu;
+        const uint32_t hi = (xh > yh ? x : y) & 0xffff0000u;
+        return hi | lo;
+    };
+    return make_uint4(m(a.x, b.x), m(a.y, b.y), m(a.z, b.z), m(a.w, b.w));
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TH = 2 * MT;  // 4 waves x (MT/2) rows
+    char* in_t = smem;
+    char* w_t = smem + a.lds_w_off;
+    int* tab_l = (int*)(smem + a.lds_tab_off);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p16 = lane & 15, g = lane >> 4;
+    const int tiles_x = (a.Wout + TW - 1) / TW;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, nb = blockIdx.y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * a.stride - a.pt, ix0 = ox0 * a.stride - a.pl;
+    const int WBUF = a.GK * NT * 1024;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int pixbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = wave * (MT / 2) + (m >> 1), col = (m & 1) * 16 + p16;
+        pixbase[m] = row * a.stride * a.row_pitch + col * a.stride * a.PS2;
+    }
+
+    const int npix = a.THH * a.TWH;
+    const int W0 = a.Win >> a.up0, W1 = a.Win >> a.up1;
+
+    // weight group -> LDS by LDS-DMA: piece pi = (kstep-in-group, n-tile) is 1 KiB, lane-linear
+    auto stage_w = [&](int buf, int k0, int n) {
+        const int pieces = n * NT;
+        for (int pi = wave; pi < pieces; pi += 4) {
+            const int ks = pi / NT, t = pi - ks * NT;
+            const uint16_t* src = a.wpk + ((size_t)(k0 + ks) * a.NTtot + nb * NT + t) * 512 + lane * 8;
+            char* dstl = w_t + buf * WBUF + pi * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dstl, 16, 0, 0);
+        }
+    };
+
+    for (int b = 0; b < a.nblk; ++b) {
+        const bool last = (b == a.nblk - 1);
+        const int nc = last ? a.nc_last : a.nc_full;
+        const int ks = last ? a.ks_last : a.ks_full;
+        const int c0 = b * a.nc_full;
+        const int kbase = b * a.ks_full;
+        __syncthreads();  // previous block fully consumed
+        {
+            const int* tg = last ? a.tab_last : a.tab_full;
+            for (int i = tid; i < ks * 4; i += 256) tab_l[i] = tg[i];
+        }
+        // ---- stage the input halo tile of this channel block (zero outside the image) -------
+        const int items = npix * nc;
+        for (int it0 = 0; it0 < items; it0 += 256 * 4) {
+            uint4 v[4];
+            int dsto[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = it0 + u * 256 + tid;
+                v[u] = make_uint4(0, 0, 0, 0);
+                dsto[u] = -1;
+                if (it < items) {
+                    const int pix = it / nc, cc = it - pix * nc;
+                    const int py = pix / a.TWH, px = pix - py * a.TWH;
+                    const int iy = iy0 + py, ix = ix0 + px;
+                    dsto[u] = py * a.row_pitch + px * a.PS2 + cc * 16;
+                    if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                        const int gc = c0 + cc;
+                        const uint16_t* s = gc < a.nch0
+                            ? a.src0 + ((size_t)(iy >> a.up0) * W0 + (ix >> a.up0)) * (a.nch0 * 8) + gc * 8
+                            : a.src1 + ((size_t)(iy >> a.up1) * W1 + (ix >> a.up1)) * (a.nch1 * 8) + (gc - a.nch0) * 8;
+                        v[u] = *(const uint4*)s;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dsto[u] >= 0) *(uint4*)(in_t + dsto[u]) = a.in_relu ? relu_bf16x8(v[u]) : v[u];
+        }
+        // ---- weight pipeline prologue ----------------------------------------------------------
+        stage_w(0, kbase, min(a.GK, ks));
+        __syncthreads();  // also waits vmcnt(0): tile, table and first weight group are in LDS
+        int cur = 0;
+        for (int g0 = 0; g0 < ks; g0 += a.GK) {
+            const int n = min(a.GK, ks - g0);
+            if (g0 + a.GK < ks) stage_w(cur ^ 1, kbase + g0 + a.GK, min(a.GK, ks - g0 - a.GK));
+            const char* wb = w_t + cur * WBUF + lane * 16;
+            for (int s = 0; s < n; ++s) {
+                const int off = tab_l[(g0 + s) * 4 + g];
+                bf16x8 xf[MT], wf[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xf[m] = *(const bf16x8*)(in_t + pixbase[m] + off);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wf[t] = *(const bf16x8*)(wb + (s * NT + t) * 1024);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[m], acc[m][t], 0, 0, 0);
+            }
+            __syncthreads();  // next group landed (vmcnt(0)) and this buffer is free
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    // D layout: lane holds pixel (lane & 15) x couts 4*(lane>>4) .. +3 of each 16x16 tile.
+    if (a.deconv) {
+        // Conv2DTranspose k2 s2: n = ab*CoP + co; scatter to (2y + a, 2x + b).  8-byte stores.
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int y = oy0 + wave * (MT / 2) + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+            if (y >= a.Hout || x >= a.Wout) continue;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = (nb * NT + t) * 16 + 4 * g;
+                const int ab = n / a.CoP, co = n - ab * a.CoP;
+                if (ab >= 4) continue;
+                const float4 bv = *(const float4*)(a.bias + n);
+                float v0 = acc[m][t][0] + bv.x, v1 = acc[m][t][1] + bv.y;
+                float v2 = acc[m][t][2] + bv.z, v3 = acc[m][t][3] + bv.w;
+                if (a.relu) {
+                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+                    v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                }
+                const uint2 pk = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16),
+                                            (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
+                const size_t o = ((size_t)(2 * y + (ab >> 1)) * (2 * a.Wout) + (2 * x + (ab & 1))) * (a.nch_out * 8) + co;
+                *(uint2*)(a.dst + o) = pk;
+            }
+        }
+        return;
+    }
+
+    constexpr int OS = NT * 16 + 4;  // out-tile pixel stride (elements): conflict-free b64 writes
+    __syncthreads();                 // everyone is done reading in_t / w_t
+    uint16_t* out_t = (uint16_t*)smem;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int prow = wave * (MT / 2) + (m >> 1), pcol = (m & 1) * 16 + p16;
+        const int y = oy0 + prow, x = ox0 + pcol;
+        const bool inb = (y < a.Hout && x < a.Wout);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = (nb * NT + t) * 16 + 4 * g;
+            const float4 bv = *(const float4*)(a.bias + n);
+            float v0 = acc[m][t][0] + bv.x, v1 = acc[m][t][1] + bv.y;
+            float v2 = acc[m][t][2] + bv.z, v3 = acc[m][t][3] + bv.w;
+            if (a.add && inb && n < a.nch_out * 8) {
+                const uint2 ad = *(const uint2*)(a.add + ((size_t)y * a.Wout + x) * (a.nch_out * 8) + n);
+                v0 += d_bf2f((uint16_t)(ad.x & 0xffff)); v1 += d_bf2f((uint16_t)(ad.x >> 16));
+                v2 += d_bf2f((uint16_t)(ad.y & 0xffff)); v3 += d_bf2f((uint16_t)(ad.y >> 16));
+            }
+            if (a.relu) {
+                v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+                v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+            }
+            const uint2 pk = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16),
+                                        (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
+            *(uint2*)(out_t + (prow * TW + pcol) * OS + t * 16 + 4 * g) = pk;
+        }
+    }
+    __syncthreads();
+    constexpr int NCH = NT * 2;  // 16-byte chunks per pixel in this N block
+    for (int it = tid; it < TH * TW * NCH; it += 256) {
+        const int pix = it / NCH, ch = it - pix * NCH;
+        const int prow = pix / TW, pcol = pix - prow * TW;
+        const int y = oy0 + prow, x = ox0 + pcol, gch = nb * NCH + ch;
+        if (y < a.Hout && x < a.Wout && gch < a.nch_out) {
+            const uint2* s = (const uint2*)(out_t + pix * OS + ch * 8);
+            const uint2 lo = s[0], hi = s[1];
+            *(uint4*)(a.dst + ((size_t)y * a.Wout + x) * (a.nch_out * 8) + gch * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+    if (a.pool_dst) {
+        const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
+        for (int it = tid; it < (TH / 2) * (TW / 2) * NCH; it += 256) {
+            const int pp = it / NCH, ch = it - pp * NCH;
+            const int qy = pp / (TW / 2), qx = pp - qy * (TW / 2);
+            const int y = (oy0 >> 1) + qy, x = (ox0 >> 1) + qx, gch = nb * NCH + ch;
+            if (y < Ho2 && x < Wo2 && gch < a.nch_out) {
+                uint4 r[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int pix = (2 * qy + (q >> 1)) * TW + 2 * qx + (q & 1);
+                    const uint2* s = (const uint2*)(out_t + pix * OS + ch * 8);
+                    const uint2 lo = s[0], hi = s[1];
+                    r[q] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+                const uint4 mx = max_bf16x8(max_bf16x8(r[0], r[1]), max_bf16x8(r[2], r[3]));
+                *(uint4*)(a.pool_dst + ((size_t)y * Wo2 + x) * (a.nch_out * 8) + gch * 8) = mx;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// first layer, Cin = 1: VALU direct conv straight from the uint8 page (fuses x/255 and the
+// pad-to-32).  0.9 % of the FLOPs; K = 25 is too short for MFMA.  Sequential fmaf chain in tap
+// order over bf16-rounded operands == the bf16-mode oracle bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int COUT>
+__global__ __launch_bounds__(256) void conv1_bf16_kernel(const uint8_t* img, int H, int W, int Hp,
+                                                         int Wp, const float* lut, const float* w,
+                                                         const float* bias, uint16_t* dst, int relu) {
+    constexpr int CS = (COUT + 7) / 8 * 8;
+    constexpr int BW = 32, BH = 8, P = KS / 2;
+    __shared__ float tile[(BH + KS - 1) * (BW + KS - 1)];
+    const int ox0 = blockIdx.x * BW, oy0 = blockIdx.y * BH;
+    for (int i = threadIdx.x; i < (BH + KS - 1) * (BW + KS - 1); i += 256) {
+        const int py = i / (BW + KS - 1), px = i - py * (BW + KS - 1);
+        const int y = oy0 + py - P, x = ox0 + px - P;
+        tile[i] = (y >= 0 && y < H && x >= 0 && x < W) ? lut[img[(size_t)y * W + x]] : 0.0f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = ox0 + lx, y = oy0 + ly;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const float xv = tile[(ly + ky) * (BW + KS - 1) + lx + kx];
+            const float* wr = w + (ky * KS + kx) * COUT;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) acc[c] = __builtin_fmaf(xv, wr[c], acc[c]);
+        }
+    if (x >= Wp || y >= Hp) return;
+    uint16_t o[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        float v = 0.0f;
+        if (c < COUT) {
+            v = acc[c] + bias[c];
+            if (relu) v = v > 0.f ? v : 0.f;
+        }
+        o[c] = d_f2bf(v);
+    }
+    uint4* d = (uint4*)(dst + ((size_t)y * Wp + x) * CS);
+#pragma unroll
+    for (int q = 0; q < CS / 8; ++q)
+        d[q] = make_uint4(o[8 * q] | ((uint32_t)o[8 * q + 1] << 16), o[8 * q + 2] | ((uint32_t)o[8 * q + 3] << 16),
+                          o[8 * q + 4] | ((uint32_t)o[8 * q + 5] << 16), o[8 * q + 6] | ((uint32_t)o[8 * q + 7] << 16));
+}
+
+// generic input staging for graphs whose first conv runs on the MFMA kernel: uint8 -> bf16(x/255)
+__global__ void preprocess_bf16_kernel(const uint8_t* img, int H, int W, int C, const float* lut,
+                                       uint16_t* dst, int Hp, int Wp, int Cs) {
+    const size_t n = (size_t)Hp * Wp;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(p % Wp), y = (int)(p / Wp);
+        for (int c = 0; c < Cs; ++c) {
+            float v = 0.0f;
+            if (c < C && y < H && x < W) v = lut[img[((size_t)y * W + x) * C + c]];
+            dst[p * Cs + c] = d_f2bf(v);
+        }
+    }
+}
+
+__global__ void pool_bf16_kernel(const uint16_t* in, int H, int W, int nch, uint16_t* out) {
+    const size_t n = (size_t)(H / 2) * (W / 2) * nch;
+    const int Wo = W / 2;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(t % nch);
+        const size_t p = t / nch;
+        const int x = (int)(p % Wo), y = (int)(p / Wo);
+        const uint4* b = (const uint4*)(in + ((size_t)(2 * y) * W + 2 * x) * nch * 8) + ch;
+        const uint4 m = max_bf16x8(max_bf16x8(b[0], b[nch]), max_bf16x8(b[(size_t)W * nch], b[(size_t)W * nch + nch]));
+        ((uint4*)out)[t] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail: crop + logits 1x1 + softmax + argmax, one pixel per thread (HBM-bound stream)
+// ---------------------------------------------------------------------------------------------
+template <int CMAX>
+__global__ __launch_bounds__(256) void logits_bf16_kernel(const uint16_t* src0, int nch0, const uint16_t* src1,
+                                                          int nch1, int Wp, int H, int W, const float* w,
+                                                          const float* bias, int C, float* logits, float* probs,
+                                                          int64_t* labels, uint8_t* labels_u8) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const size_t q = (size_t)y * Wp + x;
+    float z[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) z[c] = 0.0f;
+    auto accum = [&](const uint16_t* src, int nch, int cbase) {
+        const uint4* s = (const uint4*)(src + q * nch * 8);
+        for (int ch = 0; ch < nch; ++ch) {
+            const uint4 v = s[ch];
+            const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = __uint_as_float((j & 1) ? (ws[j >> 1] & 0xffff0000u) : (ws[j >> 1] << 16));
+                const float* wr = w + (size_t)(cbase + ch * 8 + j) * CMAX;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) z[c] = __builtin_fmaf(xv, wr[c], z[c]);
+            }
+        }
+    };
+    accum(src0, nch0, 0);
+    if (src1) accum(src1, nch1, nch0 * 8);
+    int best = 0;
+    float bv = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        if (c < C) {
+            z[c] += bias[c];
+            if (c == 0 || z[c] > bv) { bv = z[c]; best = c; }
+        }
+    }
+    if (labels) labels[p] = best;
+    if (labels_u8) labels_u8[p] = (uint8_t)best;
+    if (logits)
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) logits[(size_t)p * C + c] = z[c];
+    if (probs) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) s += expf(z[c] - bv);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) probs[(size_t)p * C + c] = expf(z[c] - bv) / s;
+    }
+}
+
+// =============================================================================================
+// host side: plans, packing, launches
+// =============================================================================================
+enum PlanKind { PLAN_GENERIC = 0, PLAN_CONV1 = 1, PLAN_LOGITS = 2 };
+
+struct MfmaPlan {
+    int kind = PLAN_GENERIC;
+    int MT = 4, NT = 2, KS = 1, stride = 1;
+    int nblk = 1, nc_full = 1, nc_last = 1, ks_full = 1, ks_last = 1;
+    int PS2 = 0, row_pitch = 0, THH = 0, TWH = 0, GK = 4, lds_w_off = 0, lds_tab_off = 0, lds_bytes = 0;
+    int NTtot = 0, nblocks_n = 1, CoP = 0;
+    int* d_tab_full = nullptr;
+    int* d_tab_last = nullptr;
+    uint16_t* d_wpk = nullptr;
+    float* d_bias = nullptr;
+    float* d_wf = nullptr;   // conv1 / logits: f32 (bf16-rounded) weights
+    float* d_lut = nullptr;  // conv1: bf16-rounded x/255 table
+    int cmax = 4;
+};
+
+void mfma_free_op(Op& op) {
+    auto* p = (MfmaPlan*)op.plan;
+    if (!p) return;
+    (void)hipFree(p->d_tab_full); (void)hipFree(p->d_tab_last); (void)hipFree(p->d_wpk);
+    (void)hipFree(p->d_bias); (void)hipFree(p->d_wf); (void)hipFree(p->d_lut);
+    delete p;
+    op.plan = nullptr;
+}
+
+static int producer_of(const Engine& e, int tensor) {
+    for (size_t i = 0; i < e.ops.size(); ++i)
+        if (e.ops[i].dst == tensor) return (int)i;
+    return -1;
+}
+
+// Fold every MaxPooling2D into the epilogue of the conv that produces its input.
+int mfma_plan_graph(Engine& e) {
+    for (auto& op : e.ops) {
+        if (op.type != OP_POOL) continue;
+        const int pi = producer_of(e, op.src0);
+        if (pi >= 0 && e.ops[pi].type == OP_CONV && e.ops[pi].pool_dst < 0) {
+            e.ops[pi].pool_dst = op.dst;
+            op.fused_away = true;
+        }
+    }
+    return PSEG_OK;
+}
+
+// sigma: LDS pixel stride in 16-byte slots; sigma = 2 (mod 4) and >= nc
+static int sigma_for(int nc) {
+    int s = std::max(nc, 2);
+    while (s % 4 != 2) ++s;
+    return s;
+}
+
+struct Chunk { int tap, cc; };  // cc < 0: dummy (zero weights)
+
+// Order the k-chunks of a channel block so that the two chunks a lane-group pair reads in one
+// ds_read_b128 ((g0,g1) and (g2,g3)) sit an odd number of 16-byte slots apart: with
+// sigma = 2 (mod 4) and an odd row pitch the slot parity of chunk (ky,kx,cc) is (ky + cc) & 1.
+static std::vector<Chunk> pair_chunks(int KS, int nc) {
+    std::vector<Chunk> ev, od, out;
+    for (int t = 0; t < KS * KS; ++t)
+        for (int c = 0; c < nc; ++c) (((t / KS) + c) & 1 ? od : ev).push_back(Chunk{t, c});
+    size_t i = 0, j = 0;
+    while (i < ev.size() && j < od.size()) { out.push_back(ev[i++]); out.push_back(od[j++]); }
+    while (i < ev.size()) out.push_back(ev[i++]);
+    while (j < od.size()) out.push_back(od[j++]);
+    while (out.size() % 4) out.push_back(Chunk{0, -1});
+    return out;
+}
+
+static bool is_conv1_special(const Engine& e, const Op& op, int* ks, int* cout) {
+    if (op.type != OP_CONV || op.src0 != e.input_tensor || op.src1 >= 0 || e.in_ch != 1) return false;
+    if (op.stride != 1 || op.up0 || op.in_relu || op.add >= 0 || op.pool_dst >= 0) return false;
+    const int combos[][2] = {{5, 20}, {3, 64}, {3, 32}, {1, 32}};
+    for (auto& c : combos)
+        if (op.k == c[0] && op.Cout == c[1]) { *ks = c[0]; *cout = c[1]; return true; }
+    return false;
+}
+
+template <typename T>
+static int upload(T** d, const std::vector<T>& h) {
+    if (*d) (void)hipFree(*d);
+    *d = nullptr;
+    PSEG_HIP(hipMalloc((void**)d, std::max<size_t>(h.size(), 1) * sizeof(T)));
+    if (!h.empty()) PSEG_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PSEG_OK;
+}
+
+int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vector<float>& bias) {
+    mfma_free_op(op);
+    auto* P = new MfmaPlan();
+    op.plan = P;
+    const Tensor& s0 = e.tensors[op.src0];
+    const Tensor* s1 = op.src1 >= 0 ? &e.tensors[op.src1] : nullptr;
+    const int C0 = s0.C, Cs0 = s0.Cs, C1 = s1 ? s1->C : 0, Cs1 = s1 ? s1->Cs : 0;
+    const int Cin = C0 + C1, Cout = op.Cout, k = op.k;
+    auto rb = [](float f) { return bf2f(f2bf(f)); };
+
+    int ks1, co1;
+    if (is_conv1_special(e, op, &ks1, &co1)) {
+        P->kind = PLAN_CONV1;
+        P->KS = ks1;
+        std::vector<float> wf((size_t)k * k * Cout), lut(256);
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = rb(w[i]);  // Cin == 1: [tap][Cout]
+        for (int i = 0; i < 256; ++i) lut[i] = rb((float)i / 255.0f);
+        PSEG_TRY(upload(&P->d_wf, wf));
+        PSEG_TRY(upload(&P->d_lut, lut));
+        PSEG_TRY(upload(&P->d_bias, bias));
+        return PSEG_OK;
+    }
+    if (op.type == OP_LOGITS) {
+        P->kind = PLAN_LOGITS;
+        P->cmax = Cout <= 4 ? 4 : (Cout <= 8 ? 8 : 16);
+        if (Cout > 16) return fail(PSEG_EUNSUPPORTED, "bf16 mode supports at most 16 classes (got %d)", Cout);
+        std::vector<float> wf((size_t)(Cs0 + Cs1) * P->cmax, 0.0f), bb(P->cmax, 0.0f);
+        for (int ci = 0; ci < Cin; ++ci) {
+            const int cs = ci < C0 ? ci : Cs0 + (ci - C0);
+            for (int c = 0; c < Cout; ++c) wf[(size_t)cs * P->cmax + c] = rb(w[(size_t)ci * Cout + c]);
+        }
+        for (int c = 0; c < Cout; ++c) bb[c] = bias[c];
+        PSEG_TRY(upload(&P->d_wf, wf));
+        PSEG_TRY(upload(&P->d_bias, bb));
+        return PSEG_OK;
+    }
+    if (op.type == OP_POOL) return PSEG_OK;
+
+    // ---- generic MFMA conv / deconv2 ------------------------------------------------------------
+    const bool deconv = op.type == OP_DECONV2;
+    const int KS = deconv ? 1 : k;
+    const int Ntrue = deconv ? 4 * round_up(Cout, 4) : Cout;
+    P->CoP = round_up(Cout, 4);
+    int NTall = cdiv(Ntrue, 16);
+    int NT = NTall <= 5 ? NTall : (NTall % 5 == 0 ? 5 : (NTall % 4 == 0 ? 4 : (NTall % 3 == 0 ? 3 : 4)));
+    P->NT = NT;
+    P->nblocks_n = cdiv(NTall, NT);
+    P->NTtot = P->nblocks_n * NT;
+    P->MT = (NT <= 2 && !deconv) ? 8 : 4;
+    P->KS = KS;
+    P->stride = deconv ? 1 : op.stride;
+    const int TH = 2 * P->MT;
+    const int totc = (Cs0 + Cs1) / 8;
+    P->nc_full = totc <= 5 ? totc : 4;
+    P->nblk = cdiv(totc, P->nc_full);
+    P->nc_last = totc - (P->nblk - 1) * P->nc_full;
+    const int sigma = sigma_for(P->nc_full);
+    P->PS2 = sigma * 16;
+    P->THH = (TH - 1) * P->stride + KS;
+    P->TWH = (TW - 1) * P->stride + KS;
+    P->row_pitch = P->TWH * P->PS2 + 16;  // odd number of 16-byte slots
+    const auto ord_full = pair_chunks(KS, P->nc_full);
+    const auto ord_last = pair_chunks(KS, P->nc_last);
+    P->ks_full = (int)ord_full.size() / 4;
+    P->ks_last = (int)ord_last.size() / 4;
+    if ((int)ord_full.size() > MAX_TAB) return fail(PSEG_EUNSUPPORTED, "k-chunk table too large");
+    auto mk_tab = [&](const std::vector<Chunk>& ord) {
+        std::vector<int> t(ord.size());
+        for (size_t i = 0; i < ord.size(); ++i) {
+            const Chunk c = ord[i];
+            // a dummy chunk reads slot 0 or 1 of the tile origin (finite data, zero weights),
+            // whichever keeps the pair's slot parity odd
+            if (c.cc < 0) {
+                const int odd_slot = P->nc_full >= 2 && &ord == &ord_full ? 16 : (KS >= 2 ? P->row_pitch : 0);
+                t[i] = (i & 1) ? odd_slot : 0;
+                continue;
+            }
+            t[i] = (c.tap / KS) * P->row_pitch + (c.tap % KS) * P->PS2 + c.cc * 16;
+        }
+        return t;
+    };
+    PSEG_TRY(upload(&P->d_tab_full, mk_tab(ord_full)));
+    PSEG_TRY(upload(&P->d_tab_last, mk_tab(ord_last)));
+    // LDS budget: input tile + 2 weight buffers of GK k-steps + table; aim at 2 workgroups per CU
+    const int in_bytes = P->THH * P->row_pitch;
+    const int out_bytes = TH * TW * (NT * 16 + 4) * 2;
+    const int tab_bytes = std::max(P->ks_full, P->ks_last) * 16;
+    int GK = 8;
+    auto total = [&](int gk) { return std::max(in_bytes + 2 * gk * NT * 1024, out_bytes) + tab_bytes + 16; };
+    while (GK > 2 && total(GK) > 80 * 1024) GK /= 2;
+    P->GK = GK;
+    P->lds_w_off = round_up(in_bytes, 16);
+    P->lds_tab_off = std::max(P->lds_w_off + 2 * GK * NT * 1024, round_up(out_bytes, 16));
+    P->lds_bytes = P->lds_tab_off + tab_bytes;
+    if (P->lds_bytes > 160 * 1024) return fail(PSEG_EUNSUPPORTED, "layer %s needs %d B of LDS", op.layer.c_str(), P->lds_bytes);
+
+    // ---- pack weights into MFMA A-fragment order -----------------------------------------------
+    // concat-storage channel cs -> true input channel (or -1 for pad)
+    auto true_ci = [&](int cs) {
+        if (cs < Cs0) return cs < C0 ? cs : -1;
+        const int c = cs - Cs0;
+        return c < C1 ? C0 + c : -1;
+    };
+    // weight of (tap, ci, n): conv: w[(tap*Cin+ci)*Cout + n]; deconv: n = ab*CoP + co -> w[(ab*Cin+ci)*Cout+co]
+    auto wval = [&](int tap, int ci, int n) -> float {
+        if (!deconv) return n < Cout ? w[((size_t)tap * Cin + ci) * Cout + n] : 0.0f;
+        const int ab = n / P->CoP, co = n % P->CoP;
+        return (ab < 4 && co < Cout) ? w[((size_t)ab * Cin + ci) * Cout + co] : 0.0f;
+    };
+    const int ks_total = (P->nblk - 1) * P->ks_full + P->ks_last;
+    std::vector<uint16_t> pk((size_t)ks_total * P->NTtot * 512, 0);
+    for (int b = 0; b < P->nblk; ++b) {
+        const bool last = b == P->nblk - 1;
+        const auto& ord = last ? ord_last : ord_full;
+        const int ksb = last ? P->ks_last : P->ks_full;
+        for (int s = 0; s < ksb; ++s)
+            for (int t = 0; t < P->NTtot; ++t)
+                for (int l = 0; l < 64; ++l) {
+                    const Chunk c = ord[(size_t)s * 4 + (l >> 4)];
+                    if (c.cc < 0) continue;
+                    const int n = t * 16 + (l & 15);
+                    uint16_t* o = &pk[(((size_t)(b * P->ks_full + s) * P->NTtot + t) * 64 + l) * 8];
+                    for (int j = 0; j < 8; ++j) {
+                        const int ci = true_ci((b * P->nc_full + c.cc) * 8 + j);
+                        if (ci >= 0) o[j] = f2bf(wval(c.tap, ci, n));
+                    }
+                }
+    }
+    PSEG_TRY(upload(&P->d_wpk, pk));
+    std::vector<float> bb((size_t)P->NTtot * 16, 0.0f);
+    for (int n = 0; n < P->NTtot * 16; ++n) {
+        if (!deconv) { if (n < Cout) bb[n] = bias[n]; }
+        else { const int ab = n / P->CoP, co = n % P->CoP; if (ab < 4 && co < Cout) bb[n] = bias[co]; }
+    }
+    PSEG_TRY(upload(&P->d_bias, bb));
+    return PSEG_OK;
+}
+
+template <int MT, int NT>
+static int launch_generic(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    PSEG_HIP(hipGetDevice(&dev));
+    if (!attr_set[dev & 63]) {
+        PSEG_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[dev & 63] = true;
+    }
+    conv_mfma_kernel<MT, NT><<<grid, 256, P.lds_bytes, st>>>(a);
+    return PSEG_OK;
+}
+
+static int launch_generic_any(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
+    if (P.MT == 8) {
+        if (P.NT == 1) return launch_generic<8, 1>(a, P, grid, st);
+        return launch_generic<8, 2>(a, P, grid, st);
+    }
+    switch (P.NT) {
+        case 1: return launch_generic<4, 1>(a, P, grid, st);
+        case 2: return launch_generic<4, 2>(a, P, grid, st);
+        case 3: return launch_generic<4, 3>(a, P, grid, st);
+        case 4: return launch_generic<4, 4>(a, P, grid, st);
+        case 5: return launch_generic<4, 5>(a, P, grid, st);
+    }
+    return fail(PSEG_EUNSUPPORTED, "no kernel instance for NT=%d", P.NT);
+}
+
+static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv& a) {
+    const Tensor& s0 = e.tensors[op.src0];
+    const Tensor* s1 = op.src1 >= 0 ? &e.tensors[op.src1] : nullptr;
+    a.src0 = (const uint16_t*)s0.d;
+    a.src1 = s1 ? (const uint16_t*)s1->d : nullptr;
+    a.nch0 = s0.Cs / 8;
+    a.nch1 = s1 ? s1->Cs / 8 : 0;
+    a.up0 = op.up0;
+    a.up1 = op.up1;
+    a.Hin = e.tH(s0) << op.up0;
+    a.Win = e.tW(s0) << op.up0;
+    a.in_relu = op.in_relu;
+    a.relu = op.relu;
+    a.nblk = P.nblk; a.nc_full = P.nc_full; a.nc_last = P.nc_last; a.ks_full = P.ks_full; a.ks_last = P.ks_last;
+    a.tab_full = P.d_tab_full; a.tab_last = P.d_tab_last; a.wpk = P.d_wpk; a.NTtot = P.NTtot; a.bias = P.d_bias;
+    a.PS2 = P.PS2; a.row_pitch = P.row_pitch; a.THH = P.THH; a.TWH = P.TWH; a.GK = P.GK;
+    a.lds_w_off = P.lds_w_off; a.lds_tab_off = P.lds_tab_off;
+    const Tensor& d = e.tensors[op.dst];
+    a.dst = (uint16_t*)d.d;
+    a.nch_out = d.Cs / 8;
+    a.CoP = P.CoP;
+}
+
+int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
+    auto* P = (MfmaPlan*)op.plan;
+    if (!P) return fail(PSEG_EINVAL, "layer %s has no bf16 plan", op.layer.c_str());
+    const Tensor& d = e.tensors[op.dst];
+    if (P->kind == PLAN_CONV1) {
+        dim3 grid(cdiv(e.Wp, 32), cdiv(e.Hp, 8));
+        const uint8_t* img = e.cur_img;  // raw uint8 page (x/255 and pad-to-32 are fused)
+        if (P->KS == 5 && op.Cout == 20)
+            conv1_bf16_kernel<5, 20><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
+        else if (P->KS == 3 && op.Cout == 64)
+            conv1_bf16_kernel<3, 64><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
+        else if (P->KS == 3 && op.Cout == 32)
+            conv1_bf16_kernel<3, 32><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
+        else
+            conv1_bf16_kernel<1, 32><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
+        return PSEG_OK;
+    }
+    MConv a{};
+    fill_common(e, op, *P, a);
+    a.Hout = e.tH(d);
+    a.Wout = e.tW(d);
+    a.stride = op.stride;
+    const int tot_h = std::max((a.Hout - 1) * op.stride + op.k - a.Hin, 0);
+    const int tot_w = std::max((a.Wout - 1) * op.stride + op.k - a.Win, 0);
+    a.pt = tot_h / 2;
+    a.pl = tot_w / 2;
+    if (op.transposed) { a.pt = tot_h - a.pt; a.pl = tot_w - a.pl; }
+    a.pool_dst = op.pool_dst >= 0 ? (uint16_t*)e.tensors[op.pool_dst].d : nullptr;
+    a.add = op.add >= 0 ? (const uint16_t*)e.tensors[op.add].d : nullptr;
+    a.deconv = 0;
+    dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n);
+    return launch_generic_any(a, *P, grid, st);
+}
+
+int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
+    auto* P = (MfmaPlan*)op.plan;
+    if (!P) return fail(PSEG_EINVAL, "layer %s has no bf16 plan", op.layer.c_str());
+    MConv a{};
+    fill_common(e, op, *P, a);
+    a.Hout = a.Hin;  // the GEMM pixel grid is the input grid
+    a.Wout = a.Win;
+    a.stride = 1;
+    a.pt = a.pl = 0;
+    a.deconv = 1;
+    dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n);
+    return launch_generic_any(a, *P, grid, st);
+}
+
+int mfma_launch_pool(Engine& e, Op& op, hipStream_t st) {
+    const Tensor& s = e.tensors[op.src0];
+    const size_t n = (size_t)(e.tH(s) / 2) * (e.tW(s) / 2) * (s.Cs / 8);
+    pool_bf16_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(
+        (const uint16_t*)s.d, e.tH(s), e.tW(s), s.Cs / 8, (uint16_t*)e.tensors[op.dst].d);
+    return PSEG_OK;
+}
+
+int mfma_launch_logits(Engine& e, Op& op, float* d_logits, float* d_probs, int64_t* d_labels,
+                       uint8_t* d_labels_u8, hipStream_t st) {
+    auto* P = (MfmaPlan*)op.plan;
+    if (!P) return fail(PSEG_EINVAL, "logits layer has no bf16 plan");
+    const Tensor& s0 = e.tensors[op.src0];
+    const Tensor* s1 = op.src1 >= 0 ? &e.tensors[op.src1] : nullptr;
+    const int grid = cdiv(e.H * e.W, 256);
+    const uint16_t* p0 = (const uint16_t*)s0.d;
+    const uint16_t* p1 = s1 ? (const uint16_t*)s1->d : nullptr;
+    const int n0 = s0.Cs / 8, n1 = s1 ? s1->Cs / 8 : 0;
+#define LG(CM) logits_bf16_kernel<CM><<<grid, 256, 0, st>>>(p0, n0, p1, n1, e.Wp, e.H, e.W, P->d_wf, P->d_bias, \
+                                                              op.Cout, d_logits, d_probs, d_labels, d_labels_u8)
+    if (P->cmax == 4) LG(4);
+    else if (P->cmax == 8) LG(8);
+    else LG(16);
+#undef LG
+    return PSEG_OK;
+}
+
+// The fused first-layer kernels read the uint8 page directly (e.cur_img); graphs whose first
+// conv is not on that path get a bf16 canvas of x/255.
+int mfma_preprocess(Engine& e, const uint8_t* d_img, hipStream_t st) {
+    e.cur_img = d_img;
+    bool all_special = true;
+    for (auto& op : e.ops)
+        if (op.src0 == e.input_tensor || op.src1 == e.input_tensor) {
+            auto* P = (MfmaPlan*)op.plan;
+            if (!P || P->kind != PLAN_CONV1) all_special = false;
+        }
+    if (all_special) return PSEG_OK;
+    Tensor& in = e.tensors[e.input_tensor];
+    const size_t n = (size_t)e.Hp * e.Wp;
+    preprocess_bf16_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(
+        d_img, e.H, e.W, in.C, e.d_lut, (uint16_t*)in.d, e.Hp, e.Wp, in.Cs);
+    return PSEG_OK;
+}
 
 }  // namespace pseg

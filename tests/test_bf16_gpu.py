@@ -1,0 +1,82 @@
+"""bf16 MFMA throughput mode vs the bf16-emulating oracle (same rounding points: bf16 kernels,
+bf16 layer outputs, float32 accumulation).  MFMA sums each 32-wide k-step in hardware order, so
+float32 accumulation differs from the oracle's sequential chain by rounding noise; an output
+that lands within that noise of a bf16 rounding boundary flips by one bf16 ulp (2^-8 relative).
+Tolerances (stated per check): activations / logits within 2 % of the tensor's max magnitude;
+label maps identical except at pixels whose oracle top-2 logit margin is below 0.05."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 0.02
+MARGIN = 0.05
+
+
+def _check_labels(pred, logit_o):
+    pred_o = np.argmax(logit_o, -1)
+    srt = np.sort(logit_o, -1)
+    margin = srt[..., -1] - srt[..., -2]
+    bad = (pred != pred_o) & (margin >= MARGIN)
+    return int(bad.sum()), int((pred != pred_o).sum())
+
+
+@pytest.mark.parametrize("arch,C,shape", [
+    ("fcn_skip", 3, (64, 96)), ("fcn_skip", 3, (70, 50)), ("fcn_skip", 6, (160, 96)), ("fcn_skip", 3, (33, 1)),
+    ("fcn_skip", 3, (256, 320)), ("fcn", 3, (96, 64)), ("unet", 3, (64, 96)), ("res_unet", 3, (70, 50)),
+])
+def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, arch, C, shape):
+    rng = np.random.default_rng(11)
+    H, W = shape
+    img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+    Wt = oracle_mod.init_weights(arch, C, seed=42, gain=1.5, bias_scale=0.05)
+    z_o, acts = oracle_mod.forward(arch, Wt, img, "bf16", return_acts=True)
+    eng = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
+    eng.set_weights(Wt)
+    logit, prob, pred = eng.predict(img)
+    for name, a in acts.items():
+        if name == "logits":
+            continue
+        g = eng.activation(name)
+        assert g.shape == a.shape, name
+        err = np.abs(g - a).max()
+        assert err <= TOL * max(1.0, np.abs(a).max()), "%s: max err %g (max |a| %g)" % (name, err, np.abs(a).max())
+    assert np.abs(logit - z_o).max() <= TOL * max(1.0, np.abs(z_o).max())
+    bad, total = _check_labels(pred, z_o)
+    assert bad == 0, "%d label mismatches outside near-ties (%d total)" % (bad, total)
+    assert np.abs(prob.sum(-1) - 1).max() < 1e-5
+    eng.close()
+
+
+def test_bf16_first_layer_bit_exact(gpu, oracle_mod):
+    """conv1 runs as a sequential fmaf chain over bf16-rounded operands: identical to the oracle."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(70, 50), dtype=np.uint8)
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=3, gain=1.5, bias_scale=0.05)
+    _, acts = oracle_mod.forward("fcn_skip", Wt, img, "bf16", return_acts=True)
+    eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
+    eng.set_weights(Wt)
+    eng.predict(img, want_logits=False, want_probs=False)
+    assert np.array_equal(eng.activation("conv2d"), acts["conv2d"])
+    eng.close()
+
+
+def test_bf16_device_entry_and_canvas_reuse(gpu, oracle_mod):
+    """pseg_predict_device with torch-owned buffers; shrinking then growing pages reuse buffers."""
+    import torch
+    rng = np.random.default_rng(9)
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=42, gain=1.5, bias_scale=0.05)
+    eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
+    eng.set_weights(Wt)
+    for (H, W) in [(128, 96), (64, 64), (128, 96), (96, 160)]:
+        img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+        _, _, pred_host = eng.predict(img, want_logits=False, want_probs=False)
+        t_img = torch.from_numpy(img).cuda()
+        t_lab = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+        t_l64 = torch.empty((H, W), dtype=torch.int64, device="cuda")
+        eng.predict_device(t_img.data_ptr(), H, W, d_labels=t_l64.data_ptr(), d_labels_u8=t_lab.data_ptr(),
+                           stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(t_lab.cpu().numpy(), pred_host.astype(np.uint8))
+        assert np.array_equal(t_l64.cpu().numpy(), pred_host)
+    eng.close()

@@ -31,6 +31,13 @@ def _have_gpu():
 @pytest.fixture(scope="session")
 def gpu():
     """GPU tests fail loudly (never skip silently) when the HIP extension or device is missing."""
+    # torch bundles its own HIP runtime: when both live in one process torch has to initialise
+    # first (bench.py does the same), otherwise torch reports "No HIP GPUs are available".
+    try:
+        import torch
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     import pseg_amd
     n = pseg_amd.device_count()
     assert n > 0, "no HIP device visible: -m gpu tests need the MI355X box"

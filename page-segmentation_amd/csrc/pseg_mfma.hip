@@ -16,6 +16,7 @@
 //   The same kernel runs Conv2DTranspose k2 s2 as a 1x1 GEMM with N = 4*Cout and a scatter
 //   epilogue.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "pseg_common.h"
@@ -56,6 +57,8 @@ struct MConv {
     const uint16_t* src0;
     const uint16_t* src1;
     int nch0, nch1;      // 16-byte chunks per pixel of src0 / src1 (Cs / 8)
+    unsigned bytes0, bytes1;  // sizes of the source tensors (buffer descriptors)
+    int sigma;           // LDS pixel stride in 16-byte slots (PS2 / 16)
     int up0, up1;
     int Hin, Win, Hout, Wout;
     int stride, pt, pl, in_relu, relu;
@@ -67,13 +70,15 @@ struct MConv {
     int NTtot;
     const float* bias;    // [NTtot*16]
     // LDS geometry
-    int PS2, row_pitch, THH, TWH, GK, lds_w_off, lds_tab_off;
+    int PS2, row_pitch, THH, TWH, GK, NB, G, lds_w_off, lds_tab_off;
     // output
     uint16_t* dst;
     int nch_out;
     uint16_t* pool_dst;
     const uint16_t* add;
     int deconv, CoP;
+    unsigned long long* trace;  // PSEG_TRACE: per-workgroup s_memtime stamps (diagnostic builds only)
+    int dbg;   // ablation bits (PSEG_DBG): 1 skip input staging, 2 skip MFMAs, 4 skip epilogue, 8 skip weight DMA
 };
 
 __device__ __forceinline__ uint4 relu_bf16x8(uint4 v) {
@@ -96,6 +101,35 @@ __device__ __forceinline__ uint4 max_bf16x8(uint4 a, uint4 b) {
     return make_uint4(m(a.x, b.x), m(a.y, b.y), m(a.z, b.z), m(a.w, b.w));
 }
 
+// counted wait: at most N vector-memory operations of this wave still outstanding
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// workgroup barrier that does NOT drain the LDS-DMA queue (a plain __syncthreads() emits
+// vmcnt(0)): own LDS writes/reads retired, then s_barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+constexpr int STAGE_SLOTS = 12;  // 16-byte loads a lane keeps in flight while staging a tile
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,7 +138,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     char* w_t = smem + a.lds_w_off;
     int* tab_l = (int*)(smem + a.lds_tab_off);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: SALU address math
     const int p16 = lane & 15, g = lane >> 4;
     const int tiles_x = (a.Wout + TW - 1) / TW;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, nb = blockIdx.y;
@@ -118,95 +153,206 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#define PSEG_STAMP(i) if (a.trace && tid == 0) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+    PSEG_STAMP(0)
+
     int pixbase[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = wave * (MT / 2) + (m >> 1), col = (m & 1) * 16 + p16;
         pixbase[m] = row * a.stride * a.row_pitch + col * a.stride * a.PS2;
     }
-
-    const int npix = a.THH * a.TWH;
     const int W0 = a.Win >> a.up0, W1 = a.Win >> a.up1;
 
-    // weight group -> LDS by LDS-DMA: piece pi = (kstep-in-group, n-tile) is 1 KiB, lane-linear
-    auto stage_w = [&](int buf, int k0, int n) {
-        const int pieces = n * NT;
-        for (int pi = wave; pi < pieces; pi += 4) {
+    // ---- weight ring: group q (GK k-steps x NT tiles, zero-padded to full groups on the host)
+    // goes to ring slot q % NB by LDS-DMA; every wave issues exactly L = GK*NT/4 loads per group,
+    // which is what the counted vmcnt waits below rely on.
+    const int L = a.GK * NT / 4;
+    const int G = a.G;
+    auto stage_w = [&](int q) {
+        if (a.dbg & 8) return;
+        char* dstb = w_t + (q % a.NB) * WBUF;
+        for (int j = 0; j < L; ++j) {
+            const int pi = wave + 4 * j;
             const int ks = pi / NT, t = pi - ks * NT;
-            const uint16_t* src = a.wpk + ((size_t)(k0 + ks) * a.NTtot + nb * NT + t) * 512 + lane * 8;
-            char* dstl = w_t + buf * WBUF + pi * 1024;
+            const uint16_t* src = a.wpk + ((size_t)(q * a.GK + ks) * a.NTtot + nb * NT + t) * 512 + lane * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dstl, 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dstb + pi * 1024), 16, 0, 0);
         }
     };
+    const int D = a.NB - 1;  // prefetch distance in groups
+    for (int q = 0; q < D && q < G; ++q) stage_w(q);
+    PSEG_STAMP(1)
 
+    int gq = 0;  // global group index
     for (int b = 0; b < a.nblk; ++b) {
         const bool last = (b == a.nblk - 1);
         const int nc = last ? a.nc_last : a.nc_full;
         const int ks = last ? a.ks_last : a.ks_full;
         const int c0 = b * a.nc_full;
-        const int kbase = b * a.ks_full;
-        __syncthreads();  // previous block fully consumed
+        if (b > 0) lds_barrier();  // every wave is done reading the previous block's tile / table
+        // k-chunk offset table of this block: fetched now, written to LDS after the tile DMAs
+        // have been issued (the fetch latency hides under the DMA issue)
+        int tabv[4];
         {
             const int* tg = last ? a.tab_last : a.tab_full;
-            for (int i = tid; i < ks * 4; i += 256) tab_l[i] = tg[i];
-        }
-        // ---- stage the input halo tile of this channel block (zero outside the image) -------
-        const int items = npix * nc;
-        for (int it0 = 0; it0 < items; it0 += 256 * 4) {
-            uint4 v[4];
-            int dsto[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = it0 + u * 256 + tid;
-                v[u] = make_uint4(0, 0, 0, 0);
-                dsto[u] = -1;
-                if (it < items) {
-                    const int pix = it / nc, cc = it - pix * nc;
-                    const int py = pix / a.TWH, px = pix - py * a.TWH;
-                    const int iy = iy0 + py, ix = ix0 + px;
-                    dsto[u] = py * a.row_pitch + px * a.PS2 + cc * 16;
-                    if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
-                        const int gc = c0 + cc;
-                        const uint16_t* s = gc < a.nch0
-                            ? a.src0 + ((size_t)(iy >> a.up0) * W0 + (ix >> a.up0)) * (a.nch0 * 8) + gc * 8
-                            : a.src1 + ((size_t)(iy >> a.up1) * W1 + (ix >> a.up1)) * (a.nch1 * 8) + (gc - a.nch0) * 8;
-                        v[u] = *(const uint4*)s;
+            for (int u = 0; u < 4; ++u) { const int i = tid + u * 256; tabv[u] = i < ks * 4 ? tg[i] : 0; }
+        }
+        if (b == 0) { PSEG_STAMP(2) }
+        // ---- stage the input halo tile of this channel block (zero outside the image) -------
+        // A wave owns tile rows wave, wave+4, ...; all of a wave's 16-byte loads (up to
+        // STAGE_SLOTS per lane) are issued before the first LDS write so that one memory
+        // latency is exposed per chunk instead of one per row.
+        if (!(a.dbg & 1) && !a.in_relu) {
+            // LDS-DMA staging (buffer_load_dwordx4 ... lds): lane L of one instruction fills
+            // the 16-byte slot (j*64 + L) of a tile row, slot = pixel*sigma + chunk.  A lane
+            // whose pixel lies outside the image, or whose slot is row padding (chunk >= nc),
+            // uses an out-of-range offset: the hardware writes zeros there without touching
+            // memory (SAME padding for free); lanes past the row end are masked off.  No VGPR
+            // round trip, no ds_write, and every row of the wave is in flight at once.
+            // Everything that depends only on the column is computed once per block.
+            const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.bytes1 : 0u, 0x00020000);
+            constexpr int JMAX = 8;
+            constexpr unsigned OOB = 0xfffffff0u;
+            const int row_slots = a.TWH * a.sigma;
+            const int J = (row_slots + 63) >> 6;
+            const unsigned inv = 65536u / (unsigned)a.sigma + 1u;
+            const bool any0 = (c0 < a.nch0), any1 = (c0 + nc > a.nch0);
+            unsigned col[JMAX];   // column part of the byte offset, or OOB
+            int kind[JMAX];       // 0: source 0 (or zero fill), 1: source 1, -1: lane past the row end
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const int sl = j * 64 + lane;
+                const int px = (int)(((unsigned)sl * inv) >> 16), cc = sl - px * a.sigma;
+                const int ix = ix0 + px, gc = c0 + cc;
+                const bool okc = cc < nc && ix >= 0 && ix < a.Win;
+                const bool is1 = okc && gc >= a.nch0;
+                col[j] = !okc ? OOB
+                              : (is1 ? (unsigned)((ix >> a.up1) * a.nch1 + (gc - a.nch0)) * 16u
+                                     : (unsigned)((ix >> a.up0) * a.nch0 + gc) * 16u);
+                kind[j] = sl >= row_slots ? -1 : (is1 ? 1 : 0);
+            }
+            for (int py = wave; py < a.THH; py += 4) {
+                const int iy = iy0 + py;
+                const bool rowv = (iy >= 0 && iy < a.Hin);
+                const unsigned rb0 = rowv ? (unsigned)(iy >> a.up0) * (unsigned)W0 * (unsigned)(a.nch0 * 16) : OOB;
+                const unsigned rb1 = rowv ? (unsigned)(iy >> a.up1) * (unsigned)W1 * (unsigned)(a.nch1 * 16) : OOB;
+                char* drow = in_t + py * a.row_pitch;
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j) {
+                    if (j < J) {
+                        __attribute__((address_space(3))) void* dl = (__attribute__((address_space(3))) void*)(drow + j * 1024);
+                        // OOB + anything stays far out of range (32-bit wrap cannot reach a valid offset
+                        // because tensors are < 2 GiB): use saturating select instead of an add on OOB
+                        if (any0 || !any1) {
+                            const unsigned o0 = (col[j] == OOB || !rowv) ? OOB : rb0 + col[j];
+                            if (kind[j] == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dl, 16, o0, 0, 0, 0);
+                        }
+                        if (any1) {
+                            const unsigned o1 = (col[j] == OOB || !rowv) ? OOB : rb1 + col[j];
+                            if (kind[j] == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dl, 16, o1, 0, 0, 0);
+                        }
                     }
                 }
             }
+        } else if (!(a.dbg & 1)) {
+            const int row_items = a.TWH * nc;
+            const int J = (row_items + 63) >> 6;          // loads per lane per row
+            const int rows_w = (a.THH - wave + 3) >> 2;   // rows of this wave
+            const int total = rows_w * J;
+            const unsigned inv = 65536u / (unsigned)nc + 1u;
+            for (int e0 = 0; e0 < total; e0 += STAGE_SLOTS) {
+                uint4 v[STAGE_SLOTS];
+                int dsto[STAGE_SLOTS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dsto[u] >= 0) *(uint4*)(in_t + dsto[u]) = a.in_relu ? relu_bf16x8(v[u]) : v[u];
-        }
-        // ---- weight pipeline prologue ----------------------------------------------------------
-        stage_w(0, kbase, min(a.GK, ks));
-        __syncthreads();  // also waits vmcnt(0): tile, table and first weight group are in LDS
-        int cur = 0;
-        for (int g0 = 0; g0 < ks; g0 += a.GK) {
-            const int n = min(a.GK, ks - g0);
-            if (g0 + a.GK < ks) stage_w(cur ^ 1, kbase + g0 + a.GK, min(a.GK, ks - g0 - a.GK));
-            const char* wb = w_t + cur * WBUF + lane * 16;
-            for (int s = 0; s < n; ++s) {
-                const int off = tab_l[(g0 + s) * 4 + g];
-                bf16x8 xf[MT], wf[NT];
+                for (int u = 0; u < STAGE_SLOTS; ++u) {
+                    const int e = e0 + u;              // wave-uniform
+                    v[u] = make_uint4(0, 0, 0, 0);
+                    dsto[u] = -1;
+                    if (e < total) {
+                        const int r = e / J, j = e - r * J;
+                        const int py = wave + 4 * r;
+                        const int iy = iy0 + py;
+                        const int i = j * 64 + lane;
+                        if (i < row_items) {
+                            const int px = (int)(((unsigned)i * inv) >> 16), cc = i - px * nc;
+                            const int ix = ix0 + px;
+                            dsto[u] = py * a.row_pitch + px * a.PS2 + cc * 16;
+                            if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                                const int gc = c0 + cc;
+                                const uint16_t* sp = gc < a.nch0
+                                    ? a.src0 + ((size_t)(iy >> a.up0) * W0 + (ix >> a.up0)) * (a.nch0 * 8) + gc * 8
+                                    : a.src1 + ((size_t)(iy >> a.up1) * W1 + (ix >> a.up1)) * (a.nch1 * 8) + (gc - a.nch0) * 8;
+                                v[u] = *(const uint4*)sp;
+                            }
+                        }
+                    }
+                }
 #pragma unroll
-                for (int m = 0; m < MT; ++m) xf[m] = *(const bf16x8*)(in_t + pixbase[m] + off);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) wf[t] = *(const bf16x8*)(wb + (s * NT + t) * 1024);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[m], acc[m][t], 0, 0, 0);
+                for (int u = 0; u < STAGE_SLOTS; ++u)
+                    if (dsto[u] >= 0) *(uint4*)(in_t + dsto[u]) = a.in_relu ? relu_bf16x8(v[u]) : v[u];
             }
-            __syncthreads();  // next group landed (vmcnt(0)) and this buffer is free
-            cur ^= 1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = tid + u * 256; if (i < ks * 4) tab_l[i] = tabv[u]; }
+        if (b == 0) { PSEG_STAMP(3) }
+
+        const int groups_b = (ks + a.GK - 1) / a.GK;
+        for (int lg = 0; lg < groups_b; ++lg, ++gq) {
+            // group gq has landed once at most the loads of the younger groups are pending
+            const int younger = min(D - 1, G - 1 - gq);
+            wait_vmcnt_le(((a.dbg & 8) || lg == 0) ? 0 : L * (younger > 0 ? younger : 0));
+            lds_barrier();
+            if (b == 0 && lg == 0) { PSEG_STAMP(4) }
+            if (gq + D < G) stage_w(gq + D);  // reuses the slot of group gq-1: free after the barrier
+            const int n = min(a.GK, ks - lg * a.GK);
+            const char* wb = w_t + (gq % a.NB) * WBUF + lane * 16;
+            const int* tb = tab_l + lg * a.GK * 4 + g;
+            // two-stage software pipeline: the fragments of k-step s+1 are in flight while the
+            // MFMAs of k-step s issue (A/B are static register sets; index clamped at the tail).
+            bf16x8 xa[MT], wa[NT], xb[MT], wbq[NT];
+#define PSEG_LOAD(XF, WF, S, OFF)                                                                \
+            {                                                                                    \
+                const int s_ = (S) < n ? (S) : n - 1;                                            \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m)                                   \
+                    XF[m] = *(const bf16x8*)(in_t + pixbase[m] + OFF);                           \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                   \
+                    WF[t] = *(const bf16x8*)(wb + (s_ * NT + t) * 1024);                         \
+            }
+#define PSEG_TAB(S) tb[((S) < n ? (S) : n - 1) * 4]
+#define PSEG_MMA(XF, WF)                                                                         \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                       \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m)                                   \
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[t], XF[m], acc[m][t], 0, 0, 0);
+            int offa = PSEG_TAB(0), offb = PSEG_TAB(1);
+            PSEG_LOAD(xa, wa, 0, offa)
+            int s = 0;
+            for (; s + 2 <= n; s += 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                PSEG_LOAD(xb, wbq, s + 1, offb)
+                offa = PSEG_TAB(s + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                PSEG_MMA(xa, wa)
+                __builtin_amdgcn_sched_barrier(0);
+                PSEG_LOAD(xa, wa, s + 2, offa)
+                offb = PSEG_TAB(s + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                PSEG_MMA(xb, wbq)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (n & 1) { PSEG_MMA(xa, wa) }
+#undef PSEG_TAB
+#undef PSEG_LOAD
+#undef PSEG_MMA
         }
     }
 
+    PSEG_STAMP(5)
     // ---- epilogue -----------------------------------------------------------------------------
     // D layout: lane holds pixel (lane & 15) x couts 4*(lane>>4) .. +3 of each 16x16 tile.
+    if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) a.dst[0] = 1; return; }
     if (a.deconv) {
         // Conv2DTranspose k2 s2: n = ab*CoP + co; scatter to (2y + a, 2x + b).  8-byte stores.
 #pragma unroll
@@ -234,22 +380,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
         return;
     }
 
-    constexpr int OS = NT * 16 + 4;  // out-tile pixel stride (elements): conflict-free b64 writes
-    __syncthreads();                 // everyone is done reading in_t / w_t
-    uint16_t* out_t = (uint16_t*)smem;
+    // Direct stores: lane (p16, g) owns couts 4g..4g+3 of pixel p16 in every 16x16 tile, i.e.
+    // 8 contiguous bytes of the NHWC row; the two cout tiles / four g of a pixel complete its
+    // 64-byte line across consecutive store instructions.  The fused 2x2 max-pool is taken in
+    // registers (rows m / m+2 are vertical neighbours in the same lane, x-neighbours are lanes
+    // p16 ^ 1) on the bf16-rounded values, so it equals pooling the stored tensor.
+    const int CsO = a.nch_out * 8;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int prow = wave * (MT / 2) + (m >> 1), pcol = (m & 1) * 16 + p16;
-        const int y = oy0 + prow, x = ox0 + pcol;
-        const bool inb = (y < a.Hout && x < a.Wout);
+    for (int t = 0; t < NT; ++t) {
+        const int n = (nb * NT + t) * 16 + 4 * g;
+        const float4 bv = *(const float4*)(a.bias + n);
+        const bool nvalid = n < CsO;
+        uint2 pk[MT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = (nb * NT + t) * 16 + 4 * g;
-            const float4 bv = *(const float4*)(a.bias + n);
+        for (int m = 0; m < MT; ++m) {
+            const int y = oy0 + wave * (MT / 2) + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+            const bool inb = (y < a.Hout && x < a.Wout) && nvalid;
             float v0 = acc[m][t][0] + bv.x, v1 = acc[m][t][1] + bv.y;
             float v2 = acc[m][t][2] + bv.z, v3 = acc[m][t][3] + bv.w;
-            if (a.add && inb && n < a.nch_out * 8) {
-                const uint2 ad = *(const uint2*)(a.add + ((size_t)y * a.Wout + x) * (a.nch_out * 8) + n);
+            const size_t o = ((size_t)y * a.Wout + x) * CsO + n;
+            if (a.add && inb) {
+                const uint2 ad = *(const uint2*)(a.add + o);
                 v0 += d_bf2f((uint16_t)(ad.x & 0xffff)); v1 += d_bf2f((uint16_t)(ad.x >> 16));
                 v2 += d_bf2f((uint16_t)(ad.y & 0xffff)); v3 += d_bf2f((uint16_t)(ad.y >> 16));
             }
@@ -257,43 +408,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                 v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
                 v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
             }
-            const uint2 pk = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16),
-                                        (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
-            *(uint2*)(out_t + (prow * TW + pcol) * OS + t * 16 + 4 * g) = pk;
+            pk[m] = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16),
+                               (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
+            if (inb) *(uint2*)(a.dst + o) = pk[m];
         }
-    }
-    __syncthreads();
-    constexpr int NCH = NT * 2;  // 16-byte chunks per pixel in this N block
-    for (int it = tid; it < TH * TW * NCH; it += 256) {
-        const int pix = it / NCH, ch = it - pix * NCH;
-        const int prow = pix / TW, pcol = pix - prow * TW;
-        const int y = oy0 + prow, x = ox0 + pcol, gch = nb * NCH + ch;
-        if (y < a.Hout && x < a.Wout && gch < a.nch_out) {
-            const uint2* s = (const uint2*)(out_t + pix * OS + ch * 8);
-            const uint2 lo = s[0], hi = s[1];
-            *(uint4*)(a.dst + ((size_t)y * a.Wout + x) * (a.nch_out * 8) + gch * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-    }
-    if (a.pool_dst) {
-        const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
-        for (int it = tid; it < (TH / 2) * (TW / 2) * NCH; it += 256) {
-            const int pp = it / NCH, ch = it - pp * NCH;
-            const int qy = pp / (TW / 2), qx = pp - qy * (TW / 2);
-            const int y = (oy0 >> 1) + qy, x = (ox0 >> 1) + qx, gch = nb * NCH + ch;
-            if (y < Ho2 && x < Wo2 && gch < a.nch_out) {
-                uint4 r[4];
+        if (a.pool_dst) {
+            const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int pix = (2 * qy + (q >> 1)) * TW + 2 * qx + (q & 1);
-                    const uint2* s = (const uint2*)(out_t + pix * OS + ch * 8);
-                    const uint2 lo = s[0], hi = s[1];
-                    r[q] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
-                const uint4 mx = max_bf16x8(max_bf16x8(r[0], r[1]), max_bf16x8(r[2], r[3]));
-                *(uint4*)(a.pool_dst + ((size_t)y * Wo2 + x) * (a.nch_out * 8) + gch * 8) = mx;
+            for (int m = 0; m < MT; ++m) {
+                if ((m >> 1) & 1) continue;  // pairs (m, m+2): rows 2r and 2r+1 of this wave
+                auto mx2 = [](uint32_t p, uint32_t q) -> uint32_t {
+                    const float pl = __uint_as_float(p << 16), ql = __uint_as_float(q << 16);
+                    const float ph = __uint_as_float(p & 0xffff0000u), qh = __uint_as_float(q & 0xffff0000u);
+                    return ((ph > qh ? p : q) & 0xffff0000u) | ((pl > ql ? p : q) & 0xffffu);
+                };
+                uint32_t vx = mx2(pk[m].x, pk[m + 2].x), vy = mx2(pk[m].y, pk[m + 2].y);
+                vx = mx2(vx, (uint32_t)__shfl_xor((int)vx, 1));
+                vy = mx2(vy, (uint32_t)__shfl_xor((int)vy, 1));
+                const int y = (oy0 >> 1) + ((wave * (MT / 2) + (m >> 1)) >> 1);
+                const int x = (ox0 >> 1) + (((m & 1) * 16 + p16) >> 1);
+                if (!(p16 & 1) && y < Ho2 && x < Wo2 && nvalid)
+                    *(uint2*)(a.pool_dst + ((size_t)y * Wo2 + x) * CsO + n) = make_uint2(vx, vy);
             }
         }
     }
+    PSEG_STAMP(6)
+    if (a.trace && tid == 0) { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(x)); a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = x; }
+#undef PSEG_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -440,7 +581,7 @@ struct MfmaPlan {
     int kind = PLAN_GENERIC;
     int MT = 4, NT = 2, KS = 1, stride = 1;
     int nblk = 1, nc_full = 1, nc_last = 1, ks_full = 1, ks_last = 1;
-    int PS2 = 0, row_pitch = 0, THH = 0, TWH = 0, GK = 4, lds_w_off = 0, lds_tab_off = 0, lds_bytes = 0;
+    int PS2 = 0, row_pitch = 0, THH = 0, TWH = 0, GK = 4, NB = 3, G = 1, lds_w_off = 0, lds_tab_off = 0, lds_bytes = 0;
     int NTtot = 0, nblocks_n = 1, CoP = 0;
     int* d_tab_full = nullptr;
     int* d_tab_last = nullptr;
@@ -570,11 +711,12 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->nblocks_n = cdiv(NTall, NT);
     P->NTtot = P->nblocks_n * NT;
     P->MT = (NT <= 2 && !deconv) ? 8 : 4;
+    if (getenv("PSEG_MT")) P->MT = atoi(getenv("PSEG_MT")) == 8 && NT <= 2 ? 8 : 4;
     P->KS = KS;
     P->stride = deconv ? 1 : op.stride;
     const int TH = 2 * P->MT;
     const int totc = (Cs0 + Cs1) / 8;
-    P->nc_full = totc <= 5 ? totc : 4;
+    P->nc_full = totc <= 5 ? totc : (KS == 1 && totc <= 16 ? totc : 4);
     P->nblk = cdiv(totc, P->nc_full);
     P->nc_last = totc - (P->nblk - 1) * P->nc_full;
     const int sigma = sigma_for(P->nc_full);
@@ -604,18 +746,38 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     };
     PSEG_TRY(upload(&P->d_tab_full, mk_tab(ord_full)));
     PSEG_TRY(upload(&P->d_tab_last, mk_tab(ord_last)));
-    // LDS budget: input tile + 2 weight buffers of GK k-steps + table; aim at 2 workgroups per CU
+    // LDS budget: input tile + a ring of NB weight groups (GK k-steps each) + table; aim at two
+    // workgroups per CU (<= 80 KiB each).  GK*NT must be a multiple of 4 so that every wave
+    // issues the same number of LDS-DMA loads per group (counted vmcnt).  PSEG_GK / PSEG_NB /
+    // PSEG_LDS_KB override for experiments.
     const int in_bytes = P->THH * P->row_pitch;
-    const int out_bytes = TH * TW * (NT * 16 + 4) * 2;
-    const int tab_bytes = std::max(P->ks_full, P->ks_last) * 16;
-    int GK = 8;
-    auto total = [&](int gk) { return std::max(in_bytes + 2 * gk * NT * 1024, out_bytes) + tab_bytes + 16; };
-    while (GK > 2 && total(GK) > 80 * 1024) GK /= 2;
+    const int ks_max = std::max(P->ks_full, P->ks_last);
+    const int tab_bytes = ks_max * 16;
+    int budget = 80 * 1024;
+    if (const char* ev = getenv("PSEG_LDS_KB")) budget = atoi(ev) * 1024;
+    auto total = [&](int gk, int nbuf) { return round_up(in_bytes, 16) + nbuf * gk * NT * 1024 + tab_bytes + 16; };
+    const int gstep = (NT % 4 == 0) ? 1 : (NT % 2 == 0 ? 2 : 4);
+    auto best_gk = [&](int nbuf) {
+        int gk = 0;
+        for (int c = gstep; c <= 16 && c <= round_up(ks_max, gstep); c += gstep)
+            if (total(c, nbuf) <= budget) gk = c;
+        return gk;
+    };
+    // three ring slots (two groups in flight) when that still leaves >= 4 k-steps per group
+    // inside the budget, otherwise two slots with the largest group that fits
+    int NB = 3, GK = best_gk(3);
+    if (GK < 4 && GK < round_up(ks_max, gstep)) { NB = 2; GK = best_gk(2); }
+    if (GK == 0) { NB = 2; GK = gstep; }
+    if (const char* ev = getenv("PSEG_NB")) { NB = std::max(2, std::min(4, atoi(ev))); GK = std::max(best_gk(NB), gstep); }
+    if (const char* ev = getenv("PSEG_GK")) GK = std::max(gstep, atoi(ev) / gstep * gstep);
+    if (total(GK, NB) > 160 * 1024) return fail(PSEG_EUNSUPPORTED, "layer %s needs %d B of LDS", op.layer.c_str(), total(GK, NB));
     P->GK = GK;
+    P->NB = NB;
+    const int gpb_full = cdiv(P->ks_full, GK), gpb_last = cdiv(P->ks_last, GK);
+    P->G = (P->nblk - 1) * gpb_full + gpb_last;
     P->lds_w_off = round_up(in_bytes, 16);
-    P->lds_tab_off = std::max(P->lds_w_off + 2 * GK * NT * 1024, round_up(out_bytes, 16));
-    P->lds_bytes = P->lds_tab_off + tab_bytes;
-    if (P->lds_bytes > 160 * 1024) return fail(PSEG_EUNSUPPORTED, "layer %s needs %d B of LDS", op.layer.c_str(), P->lds_bytes);
+    P->lds_tab_off = P->lds_w_off + NB * GK * NT * 1024;
+    P->lds_bytes = P->lds_tab_off + tab_bytes + 16;
 
     // ---- pack weights into MFMA A-fragment order -----------------------------------------------
     // concat-storage channel cs -> true input channel (or -1 for pad)
@@ -630,19 +792,20 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         const int ab = n / P->CoP, co = n % P->CoP;
         return (ab < 4 && co < Cout) ? w[((size_t)ab * Cin + ci) * Cout + co] : 0.0f;
     };
-    const int ks_total = (P->nblk - 1) * P->ks_full + P->ks_last;
-    std::vector<uint16_t> pk((size_t)ks_total * P->NTtot * 512, 0);
+    // k-steps are laid out group by group; every channel block is zero-padded to whole groups
+    std::vector<uint16_t> pk((size_t)P->G * GK * P->NTtot * 512, 0);
     for (int b = 0; b < P->nblk; ++b) {
         const bool last = b == P->nblk - 1;
         const auto& ord = last ? ord_last : ord_full;
         const int ksb = last ? P->ks_last : P->ks_full;
+        const int kstep0 = b * gpb_full * GK;
         for (int s = 0; s < ksb; ++s)
             for (int t = 0; t < P->NTtot; ++t)
                 for (int l = 0; l < 64; ++l) {
                     const Chunk c = ord[(size_t)s * 4 + (l >> 4)];
                     if (c.cc < 0) continue;
                     const int n = t * 16 + (l & 15);
-                    uint16_t* o = &pk[(((size_t)(b * P->ks_full + s) * P->NTtot + t) * 64 + l) * 8];
+                    uint16_t* o = &pk[(((size_t)(kstep0 + s) * P->NTtot + t) * 64 + l) * 8];
                     for (int j = 0; j < 8; ++j) {
                         const int ci = true_ci((b * P->nc_full + c.cc) * 8 + j);
                         if (ci >= 0) o[j] = f2bf(wval(c.tap, ci, n));
@@ -673,7 +836,24 @@ static int launch_generic(const MConv& a, const MfmaPlan& P, dim3 grid, hipStrea
     return PSEG_OK;
 }
 
-static int launch_generic_any(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
+static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st);
+static int launch_generic_any(const MConv& a0, const MfmaPlan& P, dim3 grid, hipStream_t st, const char* layer) {
+    const char* tr = getenv("PSEG_TRACE");
+    if (!tr || strcmp(tr, layer) != 0) return launch_generic_any2(a0, P, grid, st);
+    MConv a = a0;
+    const size_t n = (size_t)grid.x * grid.y * 8;
+    PSEG_HIP(hipMalloc((void**)&a.trace, n * 8));
+    PSEG_HIP(hipMemset(a.trace, 0, n * 8));
+    int rc = launch_generic_any2(a, P, grid, st);
+    PSEG_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h(n);
+    PSEG_HIP(hipMemcpy(h.data(), a.trace, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(a.trace);
+    std::string fn = std::string("gpurun_out/trace_") + layer + ".bin";
+    if (FILE* f = fopen(fn.c_str(), "wb")) { fwrite(h.data(), 8, n, f); fclose(f); }
+    return rc;
+}
+static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
     if (P.MT == 8) {
         if (P.NT == 1) return launch_generic<8, 1>(a, P, grid, st);
         return launch_generic<8, 2>(a, P, grid, st);
@@ -695,6 +875,9 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.src1 = s1 ? (const uint16_t*)s1->d : nullptr;
     a.nch0 = s0.Cs / 8;
     a.nch1 = s1 ? s1->Cs / 8 : 0;
+    a.bytes0 = (unsigned)((size_t)e.tH(s0) * e.tW(s0) * s0.Cs * 2);
+    a.bytes1 = s1 ? (unsigned)((size_t)e.tH(*s1) * e.tW(*s1) * s1->Cs * 2) : 0u;
+    a.sigma = P.PS2 / 16;
     a.up0 = op.up0;
     a.up1 = op.up1;
     a.Hin = e.tH(s0) << op.up0;
@@ -703,12 +886,13 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.relu = op.relu;
     a.nblk = P.nblk; a.nc_full = P.nc_full; a.nc_last = P.nc_last; a.ks_full = P.ks_full; a.ks_last = P.ks_last;
     a.tab_full = P.d_tab_full; a.tab_last = P.d_tab_last; a.wpk = P.d_wpk; a.NTtot = P.NTtot; a.bias = P.d_bias;
-    a.PS2 = P.PS2; a.row_pitch = P.row_pitch; a.THH = P.THH; a.TWH = P.TWH; a.GK = P.GK;
+    a.PS2 = P.PS2; a.row_pitch = P.row_pitch; a.THH = P.THH; a.TWH = P.TWH; a.GK = P.GK; a.NB = P.NB; a.G = P.G;
     a.lds_w_off = P.lds_w_off; a.lds_tab_off = P.lds_tab_off;
     const Tensor& d = e.tensors[op.dst];
     a.dst = (uint16_t*)d.d;
     a.nch_out = d.Cs / 8;
     a.CoP = P.CoP;
+    a.dbg = getenv("PSEG_DBG") ? atoi(getenv("PSEG_DBG")) : 0;
 }
 
 int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
@@ -742,7 +926,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     a.add = op.add >= 0 ? (const uint16_t*)e.tensors[op.add].d : nullptr;
     a.deconv = 0;
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n);
-    return launch_generic_any(a, *P, grid, st);
+    return launch_generic_any(a, *P, grid, st, op.layer.c_str());
 }
 
 int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
@@ -756,7 +940,7 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
     a.pt = a.pl = 0;
     a.deconv = 1;
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n);
-    return launch_generic_any(a, *P, grid, st);
+    return launch_generic_any(a, *P, grid, st, op.layer.c_str());
 }
 
 int mfma_launch_pool(Engine& e, Op& op, hipStream_t st) {

@@ -44,6 +44,7 @@ struct Tensor {
     int Cs = 0;         // storage channels: C (f32 mode) or round_up(C, 8) (bf16 mode)
     void* d = nullptr;  // device buffer, NHWC, (Hp>>s) x (Wp>>s) x Cs
     size_t bytes = 0;
+    bool fused = false; // bf16 mode: never written to HBM (lives only inside a fused kernel)
 };
 
 struct Param {
@@ -71,7 +72,8 @@ struct Op {
     float* d_w = nullptr;     // f32 correlation form [KH][KW][Cin][Cout] (+slack) / [2][2][Cin][Cout]
     float* d_b = nullptr;     // f32 bias
     void* plan = nullptr;     // bf16 mode: MfmaPlan (pseg_mfma.hip), owned by the op
-    bool fused_away = false;  // bf16 mode: OP_POOL folded into the producing conv's epilogue
+    bool fused_away = false;  // bf16 mode: op folded into a neighbour (pool -> conv epilogue, logits -> deconv tail)
+    int tail_logits = -1;     // bf16 mode: OP_DECONV2 that also runs this OP_LOGITS (fused tail)
     double flops_per_canvas_px = 0;  // algorithmic, true channels
     int timing_slot = -1;
 };
@@ -109,6 +111,10 @@ struct Engine {
     bool weights_dirty = true;
     float* d_lut = nullptr;        // 256-entry u/255 table (f32)
     const uint8_t* cur_img = nullptr;  // bf16 mode: the uint8 page of the running predict call
+    float* cur_logits = nullptr;       // bf16 mode: output pointers of the running predict call
+    float* cur_probs = nullptr;
+    int64_t* cur_labels = nullptr;
+    uint8_t* cur_labels_u8 = nullptr;
     float* d_logits_tmp = nullptr; // H*W*C f32 when the caller does not want logits
     size_t logits_tmp_bytes = 0;
     uint8_t* d_img_stage = nullptr;

@@ -438,6 +438,10 @@ static int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_
 static int run_bf16(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
                     int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st) {
     PSEG_TRY(mfma_preprocess(e, d_img, st));
+    e.cur_logits = d_logits;
+    e.cur_probs = d_probs;
+    e.cur_labels = d_labels;
+    e.cur_labels_u8 = d_labels_u8;
     for (auto& op : e.ops) {
         if (op.fused_away) continue;
         hipEvent_t ev0;
@@ -644,6 +648,7 @@ int pseg_get_activation(pseg_engine* h, const char* layer, float* out, int64_t c
     for (auto& t : e.tensors) {
         if (t.name != layer) continue;
         if (!t.d || e.Hp == 0) return fail(PSEG_EINVAL, "no predict call has run yet");
+        if (t.fused) return fail(PSEG_EUNSUPPORTED, "layer '%s' is fused into its consumer and never materialised", layer);
         const int H = e.tH(t), W = e.tW(t);
         if (dims) { dims[0] = H; dims[1] = W; dims[2] = t.C; }
         const int64_t n = (int64_t)H * W * t.C;

@@ -77,6 +77,13 @@ struct MConv {
     uint16_t* pool_dst;
     const uint16_t* add;
     int deconv, CoP;
+    // fused tail (deconv5 -> crop -> logits 1x1 -> softmax/argmax), see tail_epilogue()
+    int tail, tail_C, H0, W0, nch_skip;
+    const uint16_t* skip;      // full-resolution skip tensor (conv2), or null
+    const uint16_t* tail_wa;   // [64][8] bf16: logits weights for the deconv channels, fragment order
+    const uint16_t* tail_wb;   // [64][8] bf16: logits weights for the skip channels
+    const float* tail_bias;    // [16] logits bias (zero padded)
+    float* out_logits; float* out_probs; int64_t* out_labels; uint8_t* out_labels_u8;
     unsigned long long* trace;  // PSEG_TRACE: per-workgroup s_memtime stamps (diagnostic builds only)
     int dbg;   // ablation bits (PSEG_DBG): 1 skip input staging, 2 skip MFMAs, 4 skip epilogue, 8 skip weight DMA
 };
@@ -130,10 +137,35 @@ __device__ __forceinline__ void lds_barrier() {
 
 constexpr int STAGE_SLOTS = 12;  // 16-byte loads a lane keeps in flight while staging a tile
 
-template <int MT, int NT>
+// Specialisation: KS_ / ST_ / SG_ / MODE_ / FL_ >= 0 are compile-time constants of the hot layer
+// shapes (kernel size, stride, LDS pixel stride in slots, epilogue mode, feature flags); -1 means
+// "read it from the argument block" (generic fallback).  With ~50 runtime geometry fields the
+// compiler hoists and spills scalars by the hundred; with constants the prologue collapses.
+enum { MODE_CONV = 0, MODE_DECONV = 1, MODE_TAIL = 2 };
+enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16 };
+#ifndef PSEG_DIAG
+#define PSEG_DIAG 0   // 1: compile the in-kernel trace stamps / ablation switches (diagnostic builds)
+#endif
+
+template <int MT, int NT, int KS_, int ST_, int SG_, int MODE_, int FL_>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TH = 2 * MT;  // 4 waves x (MT/2) rows
+    constexpr bool FIXED = KS_ > 0;
+    const int c_stride = FIXED ? ST_ : a.stride;
+    const int c_sigma = FIXED ? SG_ : a.sigma;
+    const int c_PS2 = c_sigma * 16;
+    const int c_THH = FIXED ? (TH - 1) * ST_ + KS_ : a.THH;
+    const int c_TWH = FIXED ? (TW - 1) * ST_ + KS_ : a.TWH;
+    const int c_up0 = FIXED ? ((FL_ & FL_UP0) ? 1 : 0) : a.up0;
+    const int c_up1 = FIXED ? ((FL_ & FL_UP1) ? 1 : 0) : a.up1;
+    const bool c_inrelu = FIXED ? (FL_ & FL_INRELU) != 0 : a.in_relu != 0;
+    const bool c_pool = FIXED ? (FL_ & FL_POOL) != 0 : a.pool_dst != nullptr;
+    const bool c_add = FIXED ? (FL_ & FL_ADD) != 0 : a.add != nullptr;
+    const bool c_deconv = FIXED ? MODE_ != MODE_CONV : a.deconv != 0;
+    const bool c_tail = FIXED ? MODE_ == MODE_TAIL : a.tail != 0;
+    const int c_dbg = PSEG_DIAG ? a.dbg : 0;
+    unsigned long long* const c_trace = PSEG_DIAG ? a.trace : nullptr;
     char* in_t = smem;
     char* w_t = smem + a.lds_w_off;
     int* tab_l = (int*)(smem + a.lds_tab_off);
@@ -144,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     const int tiles_x = (a.Wout + TW - 1) / TW;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, nb = blockIdx.y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * a.stride - a.pt, ix0 = ox0 * a.stride - a.pl;
+    const int iy0 = oy0 * c_stride - a.pt, ix0 = ox0 * c_stride - a.pl;
     const int WBUF = a.GK * NT * 1024;
 
     f32x4 acc[MT][NT];
@@ -153,16 +185,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define PSEG_STAMP(i) if (a.trace && tid == 0) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#define PSEG_STAMP(i) if (c_trace && tid == 0) c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
     PSEG_STAMP(0)
 
     int pixbase[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = wave * (MT / 2) + (m >> 1), col = (m & 1) * 16 + p16;
-        pixbase[m] = row * a.stride * a.row_pitch + col * a.stride * a.PS2;
+        pixbase[m] = row * c_stride * a.row_pitch + col * c_stride * c_PS2;
     }
-    const int W0 = a.Win >> a.up0, W1 = a.Win >> a.up1;
+    const int W0 = a.Win >> c_up0, W1 = a.Win >> c_up1;
 
     // ---- weight ring: group q (GK k-steps x NT tiles, zero-padded to full groups on the host)
     // goes to ring slot q % NB by LDS-DMA; every wave issues exactly L = GK*NT/4 loads per group,
@@ -170,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     const int L = a.GK * NT / 4;
     const int G = a.G;
     auto stage_w = [&](int q) {
-        if (a.dbg & 8) return;
+        if (c_dbg & 8) return;
         char* dstb = w_t + (q % a.NB) * WBUF;
         for (int j = 0; j < L; ++j) {
             const int pi = wave + 4 * j;
@@ -180,7 +212,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                                              (__attribute__((address_space(3))) void*)(dstb + pi * 1024), 16, 0, 0);
         }
     };
-    const int D = a.NB - 1;  // prefetch distance in groups
+    // fused tail: the skip-tensor fragments of this lane are requested now, before stage 1; the
+    // barriers of the k-loop keep them above it, so their latency hides under the deconv GEMM.
+    constexpr int NABT = (NT == 4 || NT == 8) ? NT / 2 : 1;
+    uint4 skf[MT][NABT];
+    if constexpr (NT == 4 || NT == 8) {
+        if (c_tail) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int hy = oy0 + wave * (MT / 2) + (m >> 1), hx = ox0 + (m & 1) * 16 + p16;
+#pragma unroll
+                for (int abl = 0; abl < NABT; ++abl) {
+                    const int ab = nb * NABT + abl;
+                    skf[m][abl] = make_uint4(0, 0, 0, 0);
+                    // canvas coordinates are always inside the skip tensor (Hp x Wp); chunk g < nch_skip
+                    if (a.skip && g < a.nch_skip && hy < a.Hout && hx < a.Wout)
+                        skf[m][abl] = *(const uint4*)(a.skip + ((size_t)(2 * hy + (ab >> 1)) * (2 * a.Wout) + 2 * hx + (ab & 1)) * (a.nch_skip * 8) + g * 8);
+                }
+            }
+        }
+    }
+    const int D = a.NB > 1 ? a.NB - 1 : 1;  // prefetch distance in groups (NB == 1: single resident group)
     for (int q = 0; q < D && q < G; ++q) stage_w(q);
     PSEG_STAMP(1)
 
@@ -204,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
         // A wave owns tile rows wave, wave+4, ...; all of a wave's 16-byte loads (up to
         // STAGE_SLOTS per lane) are issued before the first LDS write so that one memory
         // latency is exposed per chunk instead of one per row.
-        if (!(a.dbg & 1) && !a.in_relu) {
+        if (!(c_dbg & 1) && !c_inrelu) {
             // LDS-DMA staging (buffer_load_dwordx4 ... lds): lane L of one instruction fills
             // the 16-byte slot (j*64 + L) of a tile row, slot = pixel*sigma + chunk.  A lane
             // whose pixel lies outside the image, or whose slot is row padding (chunk >= nc),
@@ -216,29 +268,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
             const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.bytes1 : 0u, 0x00020000);
             constexpr int JMAX = 8;
             constexpr unsigned OOB = 0xfffffff0u;
-            const int row_slots = a.TWH * a.sigma;
+            const int row_slots = c_TWH * c_sigma;
             const int J = (row_slots + 63) >> 6;
-            const unsigned inv = 65536u / (unsigned)a.sigma + 1u;
+            const unsigned inv = 65536u / (unsigned)c_sigma + 1u;
             const bool any0 = (c0 < a.nch0), any1 = (c0 + nc > a.nch0);
             unsigned col[JMAX];   // column part of the byte offset, or OOB
             int kind[JMAX];       // 0: source 0 (or zero fill), 1: source 1, -1: lane past the row end
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
                 const int sl = j * 64 + lane;
-                const int px = (int)(((unsigned)sl * inv) >> 16), cc = sl - px * a.sigma;
+                const int px = (int)(((unsigned)sl * inv) >> 16), cc = sl - px * c_sigma;
                 const int ix = ix0 + px, gc = c0 + cc;
                 const bool okc = cc < nc && ix >= 0 && ix < a.Win;
                 const bool is1 = okc && gc >= a.nch0;
                 col[j] = !okc ? OOB
-                              : (is1 ? (unsigned)((ix >> a.up1) * a.nch1 + (gc - a.nch0)) * 16u
-                                     : (unsigned)((ix >> a.up0) * a.nch0 + gc) * 16u);
+                              : (is1 ? (unsigned)((ix >> c_up1) * a.nch1 + (gc - a.nch0)) * 16u
+                                     : (unsigned)((ix >> c_up0) * a.nch0 + gc) * 16u);
                 kind[j] = sl >= row_slots ? -1 : (is1 ? 1 : 0);
             }
-            for (int py = wave; py < a.THH; py += 4) {
+            for (int py = wave; py < c_THH; py += 4) {
                 const int iy = iy0 + py;
                 const bool rowv = (iy >= 0 && iy < a.Hin);
-                const unsigned rb0 = rowv ? (unsigned)(iy >> a.up0) * (unsigned)W0 * (unsigned)(a.nch0 * 16) : OOB;
-                const unsigned rb1 = rowv ? (unsigned)(iy >> a.up1) * (unsigned)W1 * (unsigned)(a.nch1 * 16) : OOB;
+                const unsigned rb0 = rowv ? (unsigned)(iy >> c_up0) * (unsigned)W0 * (unsigned)(a.nch0 * 16) : OOB;
+                const unsigned rb1 = rowv ? (unsigned)(iy >> c_up1) * (unsigned)W1 * (unsigned)(a.nch1 * 16) : OOB;
                 char* drow = in_t + py * a.row_pitch;
 #pragma unroll
                 for (int j = 0; j < JMAX; ++j) {
@@ -257,10 +309,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                     }
                 }
             }
-        } else if (!(a.dbg & 1)) {
-            const int row_items = a.TWH * nc;
+        } else if (!(c_dbg & 1)) {
+            const int row_items = c_TWH * nc;
             const int J = (row_items + 63) >> 6;          // loads per lane per row
-            const int rows_w = (a.THH - wave + 3) >> 2;   // rows of this wave
+            const int rows_w = (c_THH - wave + 3) >> 2;   // rows of this wave
             const int total = rows_w * J;
             const unsigned inv = 65536u / (unsigned)nc + 1u;
             for (int e0 = 0; e0 < total; e0 += STAGE_SLOTS) {
@@ -279,12 +331,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                         if (i < row_items) {
                             const int px = (int)(((unsigned)i * inv) >> 16), cc = i - px * nc;
                             const int ix = ix0 + px;
-                            dsto[u] = py * a.row_pitch + px * a.PS2 + cc * 16;
+                            dsto[u] = py * a.row_pitch + px * c_PS2 + cc * 16;
                             if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
                                 const int gc = c0 + cc;
                                 const uint16_t* sp = gc < a.nch0
-                                    ? a.src0 + ((size_t)(iy >> a.up0) * W0 + (ix >> a.up0)) * (a.nch0 * 8) + gc * 8
-                                    : a.src1 + ((size_t)(iy >> a.up1) * W1 + (ix >> a.up1)) * (a.nch1 * 8) + (gc - a.nch0) * 8;
+                                    ? a.src0 + ((size_t)(iy >> c_up0) * W0 + (ix >> c_up0)) * (a.nch0 * 8) + gc * 8
+                                    : a.src1 + ((size_t)(iy >> c_up1) * W1 + (ix >> c_up1)) * (a.nch1 * 8) + (gc - a.nch0) * 8;
                                 v[u] = *(const uint4*)sp;
                             }
                         }
@@ -292,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                 }
 #pragma unroll
                 for (int u = 0; u < STAGE_SLOTS; ++u)
-                    if (dsto[u] >= 0) *(uint4*)(in_t + dsto[u]) = a.in_relu ? relu_bf16x8(v[u]) : v[u];
+                    if (dsto[u] >= 0) *(uint4*)(in_t + dsto[u]) = c_inrelu ? relu_bf16x8(v[u]) : v[u];
             }
         }
 #pragma unroll
@@ -303,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
         for (int lg = 0; lg < groups_b; ++lg, ++gq) {
             // group gq has landed once at most the loads of the younger groups are pending
             const int younger = min(D - 1, G - 1 - gq);
-            wait_vmcnt_le(((a.dbg & 8) || lg == 0) ? 0 : L * (younger > 0 ? younger : 0));
+            wait_vmcnt_le(((c_dbg & 8) || lg == 0) ? 0 : L * (younger > 0 ? younger : 0));
             lds_barrier();
             if (b == 0 && lg == 0) { PSEG_STAMP(4) }
             if (gq + D < G) stage_w(gq + D);  // reuses the slot of group gq-1: free after the barrier
@@ -352,8 +404,93 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     PSEG_STAMP(5)
     // ---- epilogue -----------------------------------------------------------------------------
     // D layout: lane holds pixel (lane & 15) x couts 4*(lane>>4) .. +3 of each 16x16 tile.
-    if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) a.dst[0] = 1; return; }
-    if (a.deconv) {
+    if (c_dbg & 4) { if (acc[0][0][0] == 123.456f) a.dst[0] = 1; return; }
+    if constexpr (NT == 4 || NT == 8) {
+        if (c_tail) {
+            // Fused tail.  Stage 1 above produced, per half-resolution pixel, the four output
+            // pixels' deconv channels: tiles (2ab, 2ab+1) hold co 0..31 of sub-pixel ab (CoP = 32).
+            // A 16x16 accumulator tile has the pixel on the lane and four channels in registers,
+            // i.e. it already is a B operand (k x pixel) of the next MFMA: two tiles give the 8
+            // k-values a lane needs (k = 8g+j <-> co = 4g+j for j<4, 16+4g+(j-4) otherwise; the
+            // host packs the logits weights in that k order).  The skip channels come straight
+            // from global memory as a second B fragment.  D2[class][pixel] -> argmax / softmax.
+            const bf16x8 wa = *(const bf16x8*)(a.tail_wa + lane * 8);
+            const bf16x8 wbk = *(const bf16x8*)(a.tail_wb + lane * 8);
+            const float4 lb = *(const float4*)(a.tail_bias + 4 * g);
+            const int C = a.tail_C;
+            constexpr int NAB = NT / 2;      // sub-pixels handled by this N block
+            const int ab0 = nb * NAB;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int hy = oy0 + wave * (MT / 2) + (m >> 1), hx = ox0 + (m & 1) * 16 + p16;
+#pragma unroll
+                for (int abl = 0; abl < NAB; ++abl) {
+                    const int ab = ab0 + abl;
+                    const int y = 2 * hy + (ab >> 1), x = 2 * hx + (ab & 1);
+                    const bool inb = (y < a.H0 && x < a.W0);
+                    const float4 b0 = *(const float4*)(a.bias + (2 * ab) * 16 + 4 * g);
+                    const float4 b1 = *(const float4*)(a.bias + (2 * ab + 1) * 16 + 4 * g);
+                    const f32x4 t0 = acc[m][2 * abl], t1 = acc[m][2 * abl + 1];
+                    uint4 dq;
+                    dq.x = (uint32_t)d_f2bf(t0[0] + b0.x) | ((uint32_t)d_f2bf(t0[1] + b0.y) << 16);
+                    dq.y = (uint32_t)d_f2bf(t0[2] + b0.z) | ((uint32_t)d_f2bf(t0[3] + b0.w) << 16);
+                    dq.z = (uint32_t)d_f2bf(t1[0] + b1.x) | ((uint32_t)d_f2bf(t1[1] + b1.y) << 16);
+                    dq.w = (uint32_t)d_f2bf(t1[2] + b1.z) | ((uint32_t)d_f2bf(t1[3] + b1.w) << 16);
+                    f32x4 z = f32x4{lb.x, lb.y, lb.z, lb.w};
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, dq), z, 0, 0, 0);
+                    if (a.skip)
+                        z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbk, __builtin_bit_cast(bf16x8, skf[m][abl]), z, 0, 0, 0);
+                    // argmax over classes 4g+r (first maximum wins), combined across the four g
+                    float bv = -3.4e38f;
+                    int bi = 0x7fffffff;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 4 * g + r;
+                        const bool take = (c < C) & (z[r] > bv);
+                        bv = take ? z[r] : bv;
+                        bi = take ? c : bi;
+                    }
+                    if (C > 4) {   // classes beyond the g = 0 lanes: combine across the four lane groups
+#pragma unroll
+                        for (int sh = 16; sh <= 32; sh <<= 1) {
+                            const float ov = __shfl_xor(bv, sh);
+                            const int oi = __shfl_xor(bi, sh);
+                            const bool take = (ov > bv) | ((ov == bv) & (oi < bi));
+                            bv = take ? ov : bv;
+                            bi = take ? oi : bi;
+                        }
+                    }
+                    const size_t p = (size_t)y * a.W0 + x;
+                    if (inb) {
+                        if (g == 0) {
+                            if (a.out_labels_u8) a.out_labels_u8[p] = (uint8_t)bi;
+                            if (a.out_labels) a.out_labels[p] = bi;
+                        }
+                        if (a.out_logits)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (4 * g + r < C) a.out_logits[p * C + 4 * g + r] = z[r];
+                    }
+                    if (a.out_probs) {
+                        float ex[4], sum = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ex[r] = (4 * g + r < C) ? expf(z[r] - bv) : 0.f; sum += ex[r]; }
+                        if (C > 4) {
+                            sum += __shfl_xor(sum, 16);
+                            sum += __shfl_xor(sum, 32);
+                        }
+                        if (inb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (4 * g + r < C) a.out_probs[p * C + 4 * g + r] = ex[r] / sum;
+                    }
+                }
+            }
+            PSEG_STAMP(6)
+            return;
+        }
+    }
+    if (c_deconv) {
         // Conv2DTranspose k2 s2: n = ab*CoP + co; scatter to (2y + a, 2x + b).  8-byte stores.
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -399,7 +536,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
             float v0 = acc[m][t][0] + bv.x, v1 = acc[m][t][1] + bv.y;
             float v2 = acc[m][t][2] + bv.z, v3 = acc[m][t][3] + bv.w;
             const size_t o = ((size_t)y * a.Wout + x) * CsO + n;
-            if (a.add && inb) {
+            if (c_add && inb) {
                 const uint2 ad = *(const uint2*)(a.add + o);
                 v0 += d_bf2f((uint16_t)(ad.x & 0xffff)); v1 += d_bf2f((uint16_t)(ad.x >> 16));
                 v2 += d_bf2f((uint16_t)(ad.y & 0xffff)); v3 += d_bf2f((uint16_t)(ad.y >> 16));
@@ -412,7 +549,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                                (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
             if (inb) *(uint2*)(a.dst + o) = pk[m];
         }
-        if (a.pool_dst) {
+        if (c_pool) {
             const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -433,7 +570,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
         }
     }
     PSEG_STAMP(6)
-    if (a.trace && tid == 0) { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(x)); a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = x; }
+    if (c_trace && tid == 0) { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(x)); c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = x; }
 #undef PSEG_STAMP
 }
 
@@ -589,6 +726,9 @@ struct MfmaPlan {
     float* d_bias = nullptr;
     float* d_wf = nullptr;   // conv1 / logits: f32 (bf16-rounded) weights
     float* d_lut = nullptr;  // conv1: bf16-rounded x/255 table
+    uint16_t* d_tail_wa = nullptr;
+    uint16_t* d_tail_wb = nullptr;
+    float* d_tail_bias = nullptr;
     int cmax = 4;
 };
 
@@ -597,6 +737,7 @@ void mfma_free_op(Op& op) {
     if (!p) return;
     (void)hipFree(p->d_tab_full); (void)hipFree(p->d_tab_last); (void)hipFree(p->d_wpk);
     (void)hipFree(p->d_bias); (void)hipFree(p->d_wf); (void)hipFree(p->d_lut);
+    (void)hipFree(p->d_tail_wa); (void)hipFree(p->d_tail_wb); (void)hipFree(p->d_tail_bias);
     delete p;
     op.plan = nullptr;
 }
@@ -609,6 +750,21 @@ static int producer_of(const Engine& e, int tensor) {
 
 // Fold every MaxPooling2D into the epilogue of the conv that produces its input.
 int mfma_plan_graph(Engine& e) {
+    // deconv (k2 s2) feeding only the logits layer -> one fused tail kernel
+    if (!getenv("PSEG_NO_TAIL_FUSION"))
+        for (size_t li = 0; li < e.ops.size(); ++li) {
+            Op& lg = e.ops[li];
+            if (lg.type != OP_LOGITS || e.n_classes > 16) continue;
+            const int pi = producer_of(e, lg.src0);
+            if (pi < 0 || e.ops[pi].type != OP_DECONV2 || e.ops[pi].Cout > 32) continue;
+            int users = 0;
+            for (auto& o : e.ops) users += (o.src0 == lg.src0) + (o.src1 == lg.src0) + (o.add == lg.src0);
+            if (users != 1) continue;
+            if (lg.src1 >= 0 && e.tensors[lg.src1].Cs > 32) continue;
+            e.ops[pi].tail_logits = (int)li;
+            e.tensors[e.ops[pi].dst].fused = true;
+            lg.fused_away = true;
+        }
     for (auto& op : e.ops) {
         if (op.type != OP_POOL) continue;
         const int pi = producer_of(e, op.src0);
@@ -629,18 +785,55 @@ static int sigma_for(int nc) {
 
 struct Chunk { int tap, cc; };  // cc < 0: dummy (zero weights)
 
-// Order the k-chunks of a channel block so that the two chunks a lane-group pair reads in one
-// ds_read_b128 ((g0,g1) and (g2,g3)) sit an odd number of 16-byte slots apart: with
-// sigma = 2 (mod 4) and an odd row pitch the slot parity of chunk (ky,kx,cc) is (ky + cc) & 1.
-static std::vector<Chunk> pair_chunks(int KS, int nc) {
-    std::vector<Chunk> ev, od, out;
+// ---- LDS bank model of the im2col fragment read (MI355X_MICROARCH.md, LDS) ---------------------
+// One ds_read_b128 is served in four 16-lane groups; groups {rows 0-3,12-15 of g0 + rows 4-11 of
+// g1} and {rows 4-11 of g0 + rows 0-3,12-15 of g1} involve the k-chunks of lane groups g0/g1 only
+// (same for g2/g3), so the cost of a k-step is the sum over its two chunk pairs.  A pair costs 2
+// LDS cycles when conflict-free, up to 4 otherwise.  Offsets are in 16-byte slots; the pixel
+// stride is sigma slots.
+static int pair_cost(int o0, int o1, int sigma) {
+    static const int RA[8] = {0, 1, 2, 3, 12, 13, 14, 15}, RB[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+    int cost = 0;
+    for (int grp = 0; grp < 2; ++grp) {
+        int cnt[16] = {0};
+        const int* r0 = grp == 0 ? RA : RB;
+        const int* r1 = grp == 0 ? RB : RA;
+        for (int i = 0; i < 8; ++i) cnt[((sigma * r0[i] + o0) % 16 + 16) % 16]++;
+        for (int i = 0; i < 8; ++i) cnt[((sigma * r1[i] + o1) % 16 + 16) % 16]++;
+        int mx = 0;
+        for (int i = 0; i < 16; ++i) mx = std::max(mx, cnt[i]);
+        cost += mx;
+    }
+    return cost;
+}
+
+// Order the k-chunks of a channel block into (g0,g1),(g2,g3) pairs that read conflict-free:
+// greedy matching on the bank model.  pitch_slots = row pitch in 16-byte slots.  Returns the
+// ordered chunks (padded with dummies to a multiple of 4) and the total modelled LDS cycles.
+static std::vector<Chunk> pair_chunks(int KS, int nc, int sigma, int pitch_slots, int* cycles_out = nullptr) {
+    std::vector<Chunk> all;
     for (int t = 0; t < KS * KS; ++t)
-        for (int c = 0; c < nc; ++c) (((t / KS) + c) & 1 ? od : ev).push_back(Chunk{t, c});
-    size_t i = 0, j = 0;
-    while (i < ev.size() && j < od.size()) { out.push_back(ev[i++]); out.push_back(od[j++]); }
-    while (i < ev.size()) out.push_back(ev[i++]);
-    while (j < od.size()) out.push_back(od[j++]);
-    while (out.size() % 4) out.push_back(Chunk{0, -1});
+        for (int c = 0; c < nc; ++c) all.push_back(Chunk{t, c});
+    auto slot = [&](const Chunk& c) { return (c.tap / KS) * pitch_slots + (c.tap % KS) * sigma + c.cc; };
+    std::vector<char> used(all.size(), 0);
+    std::vector<Chunk> out;
+    int cycles = 0;
+    for (size_t i = 0; i < all.size(); ++i) {
+        if (used[i]) continue;
+        used[i] = 1;
+        int best = -1, bc = 99;
+        // nearest partner first keeps taps of a k-step close (weights order is arbitrary anyway)
+        for (size_t j = i + 1; j < all.size() && bc > 2; ++j)
+            if (!used[j]) {
+                const int c = pair_cost(slot(all[i]), slot(all[j]), sigma);
+                if (c < bc) { bc = c; best = (int)j; }
+            }
+        out.push_back(all[i]);
+        if (best >= 0) { used[best] = 1; out.push_back(all[best]); cycles += bc; }
+        else { out.push_back(Chunk{0, -1}); cycles += 2; }
+    }
+    while (out.size() % 4) { out.push_back(Chunk{0, -1}); }
+    if (cycles_out) *cycles_out = cycles;
     return out;
 }
 
@@ -703,10 +896,12 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     // ---- generic MFMA conv / deconv2 ------------------------------------------------------------
     const bool deconv = op.type == OP_DECONV2;
     const int KS = deconv ? 1 : k;
-    const int Ntrue = deconv ? 4 * round_up(Cout, 4) : Cout;
-    P->CoP = round_up(Cout, 4);
+    const bool tail = deconv && op.tail_logits >= 0;
+    P->CoP = tail ? 32 : round_up(Cout, 4);
+    const int Ntrue = deconv ? 4 * P->CoP : Cout;
     int NTall = cdiv(Ntrue, 16);
     int NT = NTall <= 5 ? NTall : (NTall % 5 == 0 ? 5 : (NTall % 4 == 0 ? 4 : (NTall % 3 == 0 ? 3 : 4)));
+    if (tail) NT = 4;   // two sub-pixels (four cout tiles) per N block: 64 accumulators per lane
     P->NT = NT;
     P->nblocks_n = cdiv(NTall, NT);
     P->NTtot = P->nblocks_n * NT;
@@ -719,13 +914,35 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->nc_full = totc <= 5 ? totc : (KS == 1 && totc <= 16 ? totc : 4);
     P->nblk = cdiv(totc, P->nc_full);
     P->nc_last = totc - (P->nblk - 1) * P->nc_full;
-    const int sigma = sigma_for(P->nc_full);
-    P->PS2 = sigma * 16;
+    // Layout choice.  Default: sigma = 2 (mod 4) slots per pixel and an odd row pitch (every pair
+    // of consecutive chunks reads conflict-free).  If the whole layer's weights then do not fit
+    // beside the tile in half a CU's LDS but would with the unpadded stride sigma = nc, take the
+    // dense layout and let the bank model pick the row pitch / chunk pairing (a few 2-way
+    // conflicts are far cheaper than streaming the weights group by group).
+    int sigma = sigma_for(P->nc_full);
+    int pitch_pad = 1;   // extra 16-byte slots per tile row
     P->THH = (TH - 1) * P->stride + KS;
     P->TWH = (TW - 1) * P->stride + KS;
-    P->row_pitch = P->TWH * P->PS2 + 16;  // odd number of 16-byte slots
-    const auto ord_full = pair_chunks(KS, P->nc_full);
-    const auto ord_last = pair_chunks(KS, P->nc_last);
+    {
+        const int ksf = cdiv(KS * KS * P->nc_full, 4);
+        auto fits = [&](int sg, int pad) {
+            const int in_b = P->THH * ((P->TWH * sg + pad) * 16);
+            return P->nblk == 1 && in_b + round_up(ksf, 4) * NT * 1024 + ksf * 16 + 64 <= 80 * 1024;
+        };
+        if (!getenv("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16)) {
+            sigma = P->nc_full;
+            int best_cyc = 1 << 30;
+            for (int pad = 0; pad < 16; ++pad) {
+                int cyc = 0;
+                (void)pair_chunks(KS, P->nc_full, sigma, P->TWH * sigma + pad, &cyc);
+                if (cyc < best_cyc) { best_cyc = cyc; pitch_pad = pad; }
+            }
+        }
+    }
+    P->PS2 = sigma * 16;
+    P->row_pitch = (P->TWH * sigma + pitch_pad) * 16;
+    const auto ord_full = pair_chunks(KS, P->nc_full, sigma, P->row_pitch / 16);
+    const auto ord_last = pair_chunks(KS, P->nc_last, sigma, P->row_pitch / 16);
     P->ks_full = (int)ord_full.size() / 4;
     P->ks_last = (int)ord_last.size() / 4;
     if ((int)ord_full.size() > MAX_TAB) return fail(PSEG_EUNSUPPORTED, "k-chunk table too large");
@@ -733,13 +950,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         std::vector<int> t(ord.size());
         for (size_t i = 0; i < ord.size(); ++i) {
             const Chunk c = ord[i];
-            // a dummy chunk reads slot 0 or 1 of the tile origin (finite data, zero weights),
-            // whichever keeps the pair's slot parity odd
-            if (c.cc < 0) {
-                const int odd_slot = P->nc_full >= 2 && &ord == &ord_full ? 16 : (KS >= 2 ? P->row_pitch : 0);
-                t[i] = (i & 1) ? odd_slot : 0;
-                continue;
-            }
+            if (c.cc < 0) { t[i] = 0; continue; }  // dummy: finite data, zero weights
             t[i] = (c.tap / KS) * P->row_pitch + (c.tap % KS) * P->PS2 + c.cc * 16;
         }
         return t;
@@ -759,7 +970,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     const int gstep = (NT % 4 == 0) ? 1 : (NT % 2 == 0 ? 2 : 4);
     auto best_gk = [&](int nbuf) {
         int gk = 0;
-        for (int c = gstep; c <= 16 && c <= round_up(ks_max, gstep); c += gstep)
+        for (int c = gstep; c <= 32 && c <= round_up(ks_max, gstep); c += gstep)
             if (total(c, nbuf) <= budget) gk = c;
         return gk;
     };
@@ -768,6 +979,11 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     int NB = 3, GK = best_gk(3);
     if (GK < 4 && GK < round_up(ks_max, gstep)) { NB = 2; GK = best_gk(2); }
     if (GK == 0) { NB = 2; GK = gstep; }
+    // all weights of a single-block layer resident in one slot: no ring, no group barriers
+    if (P->nblk == 1 && total(round_up(ks_max, gstep), 1) <= budget && round_up(ks_max, gstep) <= 32) {
+        NB = 1;
+        GK = round_up(ks_max, gstep);
+    }
     if (const char* ev = getenv("PSEG_NB")) { NB = std::max(2, std::min(4, atoi(ev))); GK = std::max(best_gk(NB), gstep); }
     if (const char* ev = getenv("PSEG_GK")) GK = std::max(gstep, atoi(ev) / gstep * gstep);
     if (total(GK, NB) > 160 * 1024) return fail(PSEG_EUNSUPPORTED, "layer %s needs %d B of LDS", op.layer.c_str(), total(GK, NB));
@@ -819,53 +1035,106 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         else { const int ab = n / P->CoP, co = n % P->CoP; if (ab < 4 && co < Cout) bb[n] = bias[co]; }
     }
     PSEG_TRY(upload(&P->d_bias, bb));
+    if (tail) {
+        // logits weights (Keras (1,1,Cin,C): w[ci*C + c]) in the fragment order of the fused
+        // tail: lane l = (class = l & 15, g = l >> 4), element j <-> deconv channel
+        // co = j < 4 ? 4g + j : 16 + 4g + (j - 4); skip channel 8g + j.
+        const Op& lg = e.ops[op.tail_logits];
+        const std::vector<float>& lw = e.params[lg.kparam].host;
+        const std::vector<float>& lbias = e.params[lg.bparam].host;
+        const int C = lg.Cout, Cd = Cout;
+        const int Cskip = lg.src1 >= 0 ? e.tensors[lg.src1].C : 0;
+        std::vector<uint16_t> wa(64 * 8, 0), wbk(64 * 8, 0);
+        for (int l = 0; l < 64; ++l) {
+            const int cls = l & 15, gg = l >> 4;
+            if (cls >= C) continue;
+            for (int j = 0; j < 8; ++j) {
+                const int co = j < 4 ? 4 * gg + j : 16 + 4 * gg + (j - 4);
+                if (co < Cd) wa[l * 8 + j] = f2bf(lw[(size_t)co * C + cls]);
+                const int ch = 8 * gg + j;
+                if (ch < Cskip) wbk[l * 8 + j] = f2bf(lw[(size_t)(Cd + ch) * C + cls]);
+            }
+        }
+        std::vector<float> tb(16, 0.0f);
+        for (int c = 0; c < C; ++c) tb[c] = lbias[c];
+        PSEG_TRY(upload(&P->d_tail_wa, wa));
+        PSEG_TRY(upload(&P->d_tail_wb, wbk));
+        PSEG_TRY(upload(&P->d_tail_bias, tb));
+    }
     return PSEG_OK;
 }
 
-template <int MT, int NT>
-static int launch_generic(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
+template <int MT, int NT, int KS, int ST, int SG, int MODE, int FL>
+static int launch_inst(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     PSEG_HIP(hipGetDevice(&dev));
     if (!attr_set[dev & 63]) {
-        PSEG_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT>,
+        PSEG_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT, KS, ST, SG, MODE, FL>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev & 63] = true;
     }
-    conv_mfma_kernel<MT, NT><<<grid, 256, P.lds_bytes, st>>>(a);
+    conv_mfma_kernel<MT, NT, KS, ST, SG, MODE, FL><<<grid, 256, P.lds_bytes, st>>>(a);
     return PSEG_OK;
 }
 
-static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st);
-static int launch_generic_any(const MConv& a0, const MfmaPlan& P, dim3 grid, hipStream_t st, const char* layer) {
-    const char* tr = getenv("PSEG_TRACE");
-    if (!tr || strcmp(tr, layer) != 0) return launch_generic_any2(a0, P, grid, st);
-    MConv a = a0;
-    const size_t n = (size_t)grid.x * grid.y * 8;
-    PSEG_HIP(hipMalloc((void**)&a.trace, n * 8));
-    PSEG_HIP(hipMemset(a.trace, 0, n * 8));
-    int rc = launch_generic_any2(a, P, grid, st);
-    PSEG_HIP(hipStreamSynchronize(st));
-    std::vector<unsigned long long> h(n);
-    PSEG_HIP(hipMemcpy(h.data(), a.trace, n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(a.trace);
-    std::string fn = std::string("gpurun_out/trace_") + layer + ".bin";
-    if (FILE* f = fopen(fn.c_str(), "wb")) { fwrite(h.data(), 8, n, f); fclose(f); }
-    return rc;
-}
+// Specialised instances of the hot fcn / fcn_skip layer shapes, then the runtime-generic fallback.
 static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
+    const int mode = a.tail ? MODE_TAIL : (a.deconv ? MODE_DECONV : MODE_CONV);
+    const int fl = (a.pool_dst ? FL_POOL : 0) | (a.add ? FL_ADD : 0) | (a.in_relu ? FL_INRELU : 0) |
+                   (a.up0 ? FL_UP0 : 0) | (a.up1 ? FL_UP1 : 0);
+    const int sg = a.sigma, st_ = a.stride, ks = P.KS;
+#define PSEG_TRY_INST(MT_, NT_, KS_, ST_, SG_, MODE_, FL_)                                          \
+    if (!getenv("PSEG_GENERIC") && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == FL_) \
+        return launch_inst<MT_, NT_, KS_, ST_, SG_, MODE_, FL_>(a, P, grid, st);
+    PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL)      // conv2 (dense tile, resident weights)
+    PSEG_TRY_INST(8, 2, 5, 1, 6, MODE_CONV, FL_POOL)      // conv2 (padded tile)
+    PSEG_TRY_INST(4, 3, 5, 1, 6, MODE_CONV, 0)            // conv3, deconv3
+    PSEG_TRY_INST(4, 3, 5, 1, 6, MODE_CONV, FL_POOL)      // conv4
+    PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, 0)            // conv5
+    PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, FL_POOL)      // conv6
+    PSEG_TRY_INST(4, 5, 5, 1, 6, MODE_CONV, 0)            // conv7, deconv1
+    PSEG_TRY_INST(4, 5, 1, 1, 10, MODE_DECONV, 0)         // deconv2
+    PSEG_TRY_INST(4, 4, 1, 1, 14, MODE_DECONV, 0)         // deconv4 (fcn_skip)
+    PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_DECONV, 0)          // deconv4 (fcn)
+    PSEG_TRY_INST(4, 4, 1, 1, 10, MODE_TAIL, 0)           // deconv5 + logits (fcn_skip)
+    PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_TAIL, 0)            // deconv5 + logits (fcn)
+#undef PSEG_TRY_INST
     if (P.MT == 8) {
-        if (P.NT == 1) return launch_generic<8, 1>(a, P, grid, st);
-        return launch_generic<8, 2>(a, P, grid, st);
+        if (P.NT == 1) return launch_inst<8, 1, -1, -1, -1, -1, -1>(a, P, grid, st);
+        return launch_inst<8, 2, -1, -1, -1, -1, -1>(a, P, grid, st);
     }
     switch (P.NT) {
-        case 1: return launch_generic<4, 1>(a, P, grid, st);
-        case 2: return launch_generic<4, 2>(a, P, grid, st);
-        case 3: return launch_generic<4, 3>(a, P, grid, st);
-        case 4: return launch_generic<4, 4>(a, P, grid, st);
-        case 5: return launch_generic<4, 5>(a, P, grid, st);
+        case 1: return launch_inst<4, 1, -1, -1, -1, -1, -1>(a, P, grid, st);
+        case 2: return launch_inst<4, 2, -1, -1, -1, -1, -1>(a, P, grid, st);
+        case 3: return launch_inst<4, 3, -1, -1, -1, -1, -1>(a, P, grid, st);
+        case 4: return launch_inst<4, 4, -1, -1, -1, -1, -1>(a, P, grid, st);
+        case 5: return launch_inst<4, 5, -1, -1, -1, -1, -1>(a, P, grid, st);
     }
     return fail(PSEG_EUNSUPPORTED, "no kernel instance for NT=%d", P.NT);
+}
+
+static int launch_generic_any(const MConv& a0, const MfmaPlan& P, dim3 grid, hipStream_t st, const char* layer) {
+#if PSEG_DIAG
+    const char* tr = getenv("PSEG_TRACE");
+    if (tr && strcmp(tr, layer) == 0) {
+        MConv a = a0;
+        const size_t n = (size_t)grid.x * grid.y * 8;
+        PSEG_HIP(hipMalloc((void**)&a.trace, n * 8));
+        PSEG_HIP(hipMemset(a.trace, 0, n * 8));
+        int rc = launch_generic_any2(a, P, grid, st);
+        PSEG_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(n);
+        PSEG_HIP(hipMemcpy(h.data(), a.trace, n * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(a.trace);
+        std::string fn = std::string("gpurun_out/trace_") + layer + ".bin";
+        if (FILE* f = fopen(fn.c_str(), "wb")) { fwrite(h.data(), 8, n, f); fclose(f); }
+        return rc;
+    }
+#else
+    (void)layer;
+#endif
+    return launch_generic_any2(a0, P, grid, st);
 }
 
 static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv& a) {
@@ -892,7 +1161,7 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.dst = (uint16_t*)d.d;
     a.nch_out = d.Cs / 8;
     a.CoP = P.CoP;
-    a.dbg = getenv("PSEG_DBG") ? atoi(getenv("PSEG_DBG")) : 0;
+    a.dbg = (PSEG_DIAG && getenv("PSEG_DBG")) ? atoi(getenv("PSEG_DBG")) : 0;
 }
 
 int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
@@ -939,6 +1208,22 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
     a.stride = 1;
     a.pt = a.pl = 0;
     a.deconv = 1;
+    if (op.tail_logits >= 0) {
+        const Op& lg = e.ops[op.tail_logits];
+        a.tail = 1;
+        a.tail_C = lg.Cout;
+        a.H0 = e.H;
+        a.W0 = e.W;
+        a.skip = lg.src1 >= 0 ? (const uint16_t*)e.tensors[lg.src1].d : nullptr;
+        a.nch_skip = lg.src1 >= 0 ? e.tensors[lg.src1].Cs / 8 : 0;
+        a.tail_wa = P->d_tail_wa;
+        a.tail_wb = P->d_tail_wb;
+        a.tail_bias = P->d_tail_bias;
+        a.out_logits = e.cur_logits;
+        a.out_probs = e.cur_probs;
+        a.out_labels = e.cur_labels;
+        a.out_labels_u8 = e.cur_labels_u8;
+    }
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n);
     return launch_generic_any(a, *P, grid, st, op.layer.c_str());
 }

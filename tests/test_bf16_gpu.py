@@ -35,13 +35,20 @@ def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, arch, C, shape):
     eng = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
     eng.set_weights(Wt)
     logit, prob, pred = eng.predict(img)
+    checked = 0
     for name, a in acts.items():
         if name == "logits":
             continue
-        g = eng.activation(name)
+        try:
+            g = eng.activation(name)
+        except gpu.PsegError as ex:      # tensors that live only inside a fused kernel
+            assert "fused" in str(ex), ex
+            continue
+        checked += 1
         assert g.shape == a.shape, name
         err = np.abs(g - a).max()
         assert err <= TOL * max(1.0, np.abs(a).max()), "%s: max err %g (max |a| %g)" % (name, err, np.abs(a).max())
+    assert checked >= len(acts) - 3
     assert np.abs(logit - z_o).max() <= TOL * max(1.0, np.abs(z_o).max())
     bad, total = _check_labels(pred, logit, z_o)
     assert np.array_equal(pred, np.argmax(logit, -1))
@@ -82,3 +89,26 @@ def test_bf16_device_entry_and_canvas_reuse(gpu, oracle_mod):
         assert np.array_equal(t_lab.cpu().numpy(), pred_host.astype(np.uint8))
         assert np.array_equal(t_l64.cpu().numpy(), pred_host)
     eng.close()
+
+
+def test_bf16_unfused_tail_matches_fused(gpu, oracle_mod, monkeypatch):
+    """The fused deconv5+logits tail and the separate deconv / logits kernels agree (same bf16
+    rounding points; MFMA vs sequential logits accumulation differ by float32 rounding only)."""
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, size=(96, 130), dtype=np.uint8)
+    Wt = oracle_mod.init_weights("fcn_skip", 6, seed=4, gain=1.5, bias_scale=0.05)
+    eng = gpu.Engine("fcn_skip", 6, mode=gpu.MODE_BF16)
+    eng.set_weights(Wt)
+    z_f, p_f, l_f = eng.predict(img)
+    eng.close()
+    monkeypatch.setenv("PSEG_NO_TAIL_FUSION", "1")
+    eng = gpu.Engine("fcn_skip", 6, mode=gpu.MODE_BF16)
+    eng.set_weights(Wt)
+    z_u, p_u, l_u = eng.predict(img)
+    d5 = eng.activation("conv2d_transpose_4")
+    eng.close()
+    assert d5.shape[2] == 20 and np.abs(d5).max() > 0
+    assert np.abs(z_f - z_u).max() <= 1e-4 * max(1.0, np.abs(z_u).max())
+    assert np.abs(p_f - p_u).max() <= 1e-4
+    bad, total = _check_labels(l_f, z_f, z_u)
+    assert bad == 0

@@ -625,6 +625,87 @@ __global__ __launch_bounds__(256) void conv1_bf16_kernel(const uint8_t* img, int
                           o[8 * q + 4] | ((uint32_t)o[8 * q + 5] << 16), o[8 * q + 6] | ((uint32_t)o[8 * q + 7] << 16));
 }
 
+// ---------------------------------------------------------------------------------------------
+// first layer on MFMA (Cin = 1).  K = KS rows x 8 columns (columns >= KS carry zero weights):
+// k-step s, lane group g <-> kernel row ky = 4s + g, element j <-> kernel column kx = j.  The B
+// fragment of pixel (y, x) for row ky is therefore 8 consecutive input pixels
+// t[y+ky][x .. x+7]: the uint8 tile is converted once (bf16(u * 1/255) == bf16(u / 255) for all
+// 256 byte values, checked in tests/test_host_logic.py) and stored as 8 copies shifted by 0..7
+// pixels, so that every fragment is one 16-byte-aligned ds_read_b128.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int COUT>
+__global__ __launch_bounds__(256) void conv1_mfma_kernel(const uint8_t* img, int H, int W, int Wp,
+                                                         const uint16_t* wpk, const float* bias,
+                                                         uint16_t* dst, int relu) {
+    constexpr int CS = (COUT + 7) / 8 * 8, NT = (COUT + 15) / 16, NKS = (KS + 3) / 4, P = KS / 2;
+    constexpr int TH1 = 16, TR = TH1 + KS - 1, TC = 48;      // tile rows, logical tile columns
+    constexpr int RS = 80, CSTR = (TR * RS / 16 + ((2 - (TR * RS / 16) % 16) + 16) % 16) * 16;  // slots/copy = 2 (mod 16)
+    __shared__ __attribute__((aligned(16))) uint16_t t[TR * TC];
+    __shared__ __attribute__((aligned(16))) char cp[8 * CSTR];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, g = lane >> 4;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TH1;
+    // A fragments (weights) and biases of this lane
+    bf16x8 wf[NKS][NT];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) wf[s][q] = *(const bf16x8*)(wpk + ((size_t)(s * NT + q) * 64 + lane) * 8);
+    float4 bv[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) bv[q] = *(const float4*)(bias + q * 16 + 4 * g);
+    // uint8 tile -> bf16(x/255), zero outside the image (pad-to-32 and SAME padding)
+    for (int i = tid; i < TR * TC; i += 256) {
+        const int r = i / TC, c = i - r * TC;
+        const int y = oy0 + r - P, x = ox0 + c - P;
+        float v = 0.0f;
+        if (c < 32 + KS - 1 && y >= 0 && y < H && x >= 0 && x < W) v = (float)img[(size_t)y * W + x] * 0.00392156886f;
+        t[i] = d_f2bf(v);
+    }
+    __syncthreads();
+    // 8 shifted copies: copy c, row r, slot q holds t[r][8q + c .. 8q + c + 7]
+    for (int i = tid; i < 8 * TR * 5; i += 256) {
+        const int c = i / (TR * 5), rem = i - c * (TR * 5), r = rem / 5, q = rem - r * 5;
+        const uint16_t* sp = t + r * TC + 8 * q + c;
+        uint4 v;
+        v.x = sp[0] | ((uint32_t)sp[1] << 16);
+        v.y = sp[2] | ((uint32_t)sp[3] << 16);
+        v.z = sp[4] | ((uint32_t)sp[5] << 16);
+        v.w = sp[6] | ((uint32_t)sp[7] << 16);
+        *(uint4*)(cp + c * CSTR + r * RS + q * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int row = wave * 4 + (m >> 1), xl = (m & 1) * 16 + p16;
+        const char* base = cp + (xl & 7) * CSTR + (xl >> 3) * 16;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const int ky = min(4 * s + g, KS - 1);   // rows past the kernel carry zero weights
+            const bf16x8 xf = *(const bf16x8*)(base + (row + ky) * RS);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][q], xf, acc[q], 0, 0, 0);
+        }
+        const size_t o = ((size_t)(oy0 + row) * Wp + ox0 + xl) * CS;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int n = q * 16 + 4 * g;
+            float v0 = acc[q][0] + bv[q].x, v1 = acc[q][1] + bv[q].y, v2 = acc[q][2] + bv[q].z, v3 = acc[q][3] + bv[q].w;
+            if (relu) {
+                v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+                v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+            }
+            if (n < CS)
+                *(uint2*)(dst + o + n) = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16),
+                                                    (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
+        }
+    }
+}
+
 // generic input staging for graphs whose first conv runs on the MFMA kernel: uint8 -> bf16(x/255)
 __global__ void preprocess_bf16_kernel(const uint8_t* img, int H, int W, int C, const float* lut,
                                        uint16_t* dst, int Hp, int Wp, int Cs) {
@@ -874,7 +955,22 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         for (int i = 0; i < 256; ++i) lut[i] = rb((float)i / 255.0f);
         PSEG_TRY(upload(&P->d_wf, wf));
         PSEG_TRY(upload(&P->d_lut, lut));
-        PSEG_TRY(upload(&P->d_bias, bias));
+        // MFMA form: A fragments [k-step][cout tile][lane][8]; lane = (cout & 15, g), k-step s:
+        // kernel row ky = 4s + g, element j = kernel column kx
+        const int nks = (k + 3) / 4, nt = cdiv(Cout, 16);
+        std::vector<uint16_t> apk((size_t)nks * nt * 64 * 8, 0);
+        for (int sidx = 0; sidx < nks; ++sidx)
+            for (int q = 0; q < nt; ++q)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = q * 16 + (l & 15), ky = 4 * sidx + (l >> 4);
+                    if (co >= Cout || ky >= k) continue;
+                    for (int j = 0; j < k; ++j)
+                        apk[(((size_t)sidx * nt + q) * 64 + l) * 8 + j] = f2bf(w[((size_t)ky * k + j) * Cout + co]);
+                }
+        PSEG_TRY(upload(&P->d_wpk, apk));
+        std::vector<float> bb((size_t)nt * 16, 0.0f);
+        for (int c = 0; c < Cout; ++c) bb[c] = bias[c];
+        PSEG_TRY(upload(&P->d_bias, bb));
         return PSEG_OK;
     }
     if (op.type == OP_LOGITS) {
@@ -1169,8 +1265,17 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     if (!P) return fail(PSEG_EINVAL, "layer %s has no bf16 plan", op.layer.c_str());
     const Tensor& d = e.tensors[op.dst];
     if (P->kind == PLAN_CONV1) {
-        dim3 grid(cdiv(e.Wp, 32), cdiv(e.Hp, 8));
         const uint8_t* img = e.cur_img;  // raw uint8 page (x/255 and pad-to-32 are fused)
+        if (!getenv("PSEG_CONV1_VALU")) {
+            dim3 g1(e.Wp / 32, cdiv(e.Hp, 16));
+            uint16_t* o = (uint16_t*)d.d;
+            if (P->KS == 5 && op.Cout == 20) conv1_mfma_kernel<5, 20><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
+            else if (P->KS == 3 && op.Cout == 64) conv1_mfma_kernel<3, 64><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
+            else if (P->KS == 3 && op.Cout == 32) conv1_mfma_kernel<3, 32><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
+            else conv1_mfma_kernel<1, 32><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
+            return PSEG_OK;
+        }
+        dim3 grid(cdiv(e.Wp, 32), cdiv(e.Hp, 8));
         if (P->KS == 5 && op.Cout == 20)
             conv1_bf16_kernel<5, 20><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
         else if (P->KS == 3 && op.Cout == 64)

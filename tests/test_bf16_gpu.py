@@ -57,8 +57,10 @@ def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, arch, C, shape):
     eng.close()
 
 
-def test_bf16_first_layer_bit_exact(gpu, oracle_mod):
-    """conv1 runs as a sequential fmaf chain over bf16-rounded operands: identical to the oracle."""
+def test_bf16_first_layer(gpu, oracle_mod):
+    """conv1 (MFMA, K = 25 taps): float32 sums of exact bf16 products; only the summation order
+    differs from the oracle's sequential chain, so after bf16 rounding almost every value is
+    identical and none is off by more than one bf16 ulp (2^-7 relative)."""
     rng = np.random.default_rng(5)
     img = rng.integers(0, 256, size=(70, 50), dtype=np.uint8)
     Wt = oracle_mod.init_weights("fcn_skip", 3, seed=3, gain=1.5, bias_scale=0.05)
@@ -66,7 +68,9 @@ def test_bf16_first_layer_bit_exact(gpu, oracle_mod):
     eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
     eng.set_weights(Wt)
     eng.predict(img, want_logits=False, want_probs=False)
-    assert np.array_equal(eng.activation("conv2d"), acts["conv2d"])
+    g, a = eng.activation("conv2d"), acts["conv2d"]
+    assert (g == a).mean() > 0.99
+    assert np.all(np.abs(g - a) <= np.abs(a) * 2.0 ** -7 + 1e-30)
     eng.close()
 
 

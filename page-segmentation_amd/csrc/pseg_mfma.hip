@@ -25,6 +25,7 @@ namespace pseg {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2;
 
 constexpr int TW = 32;          // output tile width (two 16-pixel MFMA column tiles)
 constexpr int MAX_TAB = 1024;   // k-chunks per channel block (KS*KS*nc + padding)
@@ -76,6 +77,7 @@ struct MConv {
     int nch_out;
     uint16_t* pool_dst;
     const uint16_t* add;
+    unsigned dst_bytes, pool_bytes;
     int deconv, CoP;
     // fused tail (deconv5 -> crop -> logits 1x1 -> softmax/argmax), see tail_epilogue()
     int tail, tail_C, H0, W0, nch_skip;
@@ -201,16 +203,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     // which is what the counted vmcnt waits below rely on.
     const int L = a.GK * NT / 4;
     const int G = a.G;
-    auto stage_w = [&](int q) {
+    // packed weights are laid out [group][N block][piece][lane][8]: one group of one N block is
+    // a contiguous run of GK*NT KiB in exactly the order of its LDS ring slot, so the DMA source
+    // and destination of piece (wave + 4j) are base + j * 4 KiB.
+    const uint16_t* wsrc = a.wpk + ((size_t)nb * a.GK * NT + wave) * 512 + lane * 8;
+    const size_t wgstride = (size_t)gridDim.y * a.GK * NT * 512;   // elements per group
+    auto stage_w = [&](int q, int slot) {
         if (c_dbg & 8) return;
-        char* dstb = w_t + (q % a.NB) * WBUF;
-        for (int j = 0; j < L; ++j) {
-            const int pi = wave + 4 * j;
-            const int ks = pi / NT, t = pi - ks * NT;
-            const uint16_t* src = a.wpk + ((size_t)(q * a.GK + ks) * a.NTtot + nb * NT + t) * 512 + lane * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dstb + pi * 1024), 16, 0, 0);
-        }
+        const uint16_t* src = wsrc + (size_t)q * wgstride;
+        char* dstb = w_t + slot * WBUF + wave * 1024;
+        for (int j = 0; j < L; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * 2048),
+                                             (__attribute__((address_space(3))) void*)(dstb + j * 4096), 16, 0, 0);
     };
     // fused tail: the skip-tensor fragments of this lane are requested now, before stage 1; the
     // barriers of the k-loop keep them above it, so their latency hides under the deconv GEMM.
@@ -232,8 +236,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
             }
         }
     }
+    // biases of this lane's couts: requested now, consumed in the epilogue
+    float4 biasr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) biasr[t] = *(const float4*)(a.bias + (nb * NT + t) * 16 + 4 * g);
     const int D = a.NB > 1 ? a.NB - 1 : 1;  // prefetch distance in groups (NB == 1: single resident group)
-    for (int q = 0; q < D && q < G; ++q) stage_w(q);
+    for (int q = 0; q < D && q < G; ++q) stage_w(q, q);
+    int slot_c = 0;             // ring slot of the group being computed
+    int slot_n = D % a.NB;      // ring slot the next prefetch goes to
     PSEG_STAMP(1)
 
     int gq = 0;  // global group index
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
             // Everything that depends only on the column is computed once per block.
             const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, a.src1 ? a.bytes1 : 0u, 0x00020000);
-            constexpr int JMAX = 8;
+            constexpr int JMAX = FIXED ? ((((TW - 1) * (ST_ > 0 ? ST_ : 1) + (KS_ > 0 ? KS_ : 1)) * (SG_ > 0 ? SG_ : 1) + 63) >> 6) : 8;
             constexpr unsigned OOB = 0xfffffff0u;
             const int row_slots = c_TWH * c_sigma;
             const int J = (row_slots + 63) >> 6;
@@ -358,9 +368,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
             wait_vmcnt_le(((c_dbg & 8) || lg == 0) ? 0 : L * (younger > 0 ? younger : 0));
             lds_barrier();
             if (b == 0 && lg == 0) { PSEG_STAMP(4) }
-            if (gq + D < G) stage_w(gq + D);  // reuses the slot of group gq-1: free after the barrier
+            if (gq + D < G) stage_w(gq + D, slot_n);  // reuses the slot of group gq-1: free after the barrier
+            slot_n = slot_n + 1 == a.NB ? 0 : slot_n + 1;
             const int n = min(a.GK, ks - lg * a.GK);
-            const char* wb = w_t + (gq % a.NB) * WBUF + lane * 16;
+            const char* wb = w_t + slot_c * WBUF + lane * 16;
+            slot_c = slot_c + 1 == a.NB ? 0 : slot_c + 1;
             const int* tb = tab_l + lg * a.GK * 4 + g;
             // two-stage software pipeline: the fragments of k-step s+1 are in flight while the
             // MFMAs of k-step s issue (A/B are static register sets; index clamped at the tail).
@@ -428,8 +440,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                     const int ab = ab0 + abl;
                     const int y = 2 * hy + (ab >> 1), x = 2 * hx + (ab & 1);
                     const bool inb = (y < a.H0 && x < a.W0);
-                    const float4 b0 = *(const float4*)(a.bias + (2 * ab) * 16 + 4 * g);
-                    const float4 b1 = *(const float4*)(a.bias + (2 * ab + 1) * 16 + 4 * g);
+                    const float4 b0 = biasr[2 * abl], b1 = biasr[2 * abl + 1];
                     const f32x4 t0 = acc[m][2 * abl], t1 = acc[m][2 * abl + 1];
                     uint4 dq;
                     dq.x = (uint32_t)d_f2bf(t0[0] + b0.x) | ((uint32_t)d_f2bf(t0[1] + b0.y) << 16);
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                 const int n = (nb * NT + t) * 16 + 4 * g;
                 const int ab = n / a.CoP, co = n - ab * a.CoP;
                 if (ab >= 4) continue;
-                const float4 bv = *(const float4*)(a.bias + n);
+                const float4 bv = biasr[t];
                 float v0 = acc[m][t][0] + bv.x, v1 = acc[m][t][1] + bv.y;
                 float v2 = acc[m][t][2] + bv.z, v3 = acc[m][t][3] + bv.w;
                 if (a.relu) {
@@ -518,54 +529,64 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     }
 
     // Direct stores: lane (p16, g) owns couts 4g..4g+3 of pixel p16 in every 16x16 tile, i.e.
-    // 8 contiguous bytes of the NHWC row; the two cout tiles / four g of a pixel complete its
-    // 64-byte line across consecutive store instructions.  The fused 2x2 max-pool is taken in
-    // registers (rows m / m+2 are vertical neighbours in the same lane, x-neighbours are lanes
-    // p16 ^ 1) on the bf16-rounded values, so it equals pooling the stored tensor.
+    // 8 contiguous bytes of the NHWC row; the cout tiles / four g of a pixel complete its line
+    // across consecutive store instructions.  Bounds are enforced by the buffer descriptors (an
+    // out-of-range offset drops the store), so the epilogue is branch-free.  The fused 2x2
+    // max-pool is taken on the float32 values in registers (rows m / m+2 are vertical
+    // neighbours in the same lane, x-neighbours are lanes p16 ^ 1); rounding is monotone, so it
+    // equals pooling the stored bf16 tensor.
     const int CsO = a.nch_out * 8;
+    constexpr unsigned OOBS = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, a.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(c_pool ? a.pool_dst : a.dst), 0, c_pool ? a.pool_bytes : 0u, 0x00020000);
+    unsigned pixoff[MT];   // byte offset of this lane's pixel in dst, or OOBS
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int y = oy0 + wave * (MT / 2) + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+        pixoff[m] = (y < a.Hout && x < a.Wout) ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) : OOBS;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = (nb * NT + t) * 16 + 4 * g;
-        const float4 bv = *(const float4*)(a.bias + n);
-        const bool nvalid = n < CsO;
-        uint2 pk[MT];
+        const unsigned noff = n < CsO ? (unsigned)n * 2u : OOBS;
+        float v[MT][4];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int y = oy0 + wave * (MT / 2) + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
-            const bool inb = (y < a.Hout && x < a.Wout) && nvalid;
-            float v0 = acc[m][t][0] + bv.x, v1 = acc[m][t][1] + bv.y;
-            float v2 = acc[m][t][2] + bv.z, v3 = acc[m][t][3] + bv.w;
-            const size_t o = ((size_t)y * a.Wout + x) * CsO + n;
-            if (c_add && inb) {
-                const uint2 ad = *(const uint2*)(a.add + o);
-                v0 += d_bf2f((uint16_t)(ad.x & 0xffff)); v1 += d_bf2f((uint16_t)(ad.x >> 16));
-                v2 += d_bf2f((uint16_t)(ad.y & 0xffff)); v3 += d_bf2f((uint16_t)(ad.y >> 16));
+            v[m][0] = acc[m][t][0] + biasr[t].x; v[m][1] = acc[m][t][1] + biasr[t].y;
+            v[m][2] = acc[m][t][2] + biasr[t].z; v[m][3] = acc[m][t][3] + biasr[t].w;
+            const unsigned o = (pixoff[m] == OOBS || noff == OOBS) ? OOBS : pixoff[m] + noff;
+            if (c_add) {
+                const uint2 ad = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(
+                    __builtin_amdgcn_make_buffer_rsrc((void*)a.add, 0, a.dst_bytes, 0x00020000), o, 0, 0));
+                v[m][0] += d_bf2f((uint16_t)(ad.x & 0xffff)); v[m][1] += d_bf2f((uint16_t)(ad.x >> 16));
+                v[m][2] += d_bf2f((uint16_t)(ad.y & 0xffff)); v[m][3] += d_bf2f((uint16_t)(ad.y >> 16));
             }
             if (a.relu) {
-                v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
-                v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[m][r] = fmaxf(v[m][r], 0.0f);
             }
-            pk[m] = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16),
-                               (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
-            if (inb) *(uint2*)(a.dst + o) = pk[m];
+            const uint2 pk = make_uint2((uint32_t)d_f2bf(v[m][0]) | ((uint32_t)d_f2bf(v[m][1]) << 16),
+                                        (uint32_t)d_f2bf(v[m][2]) | ((uint32_t)d_f2bf(v[m][3]) << 16));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
         }
         if (c_pool) {
             const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 if ((m >> 1) & 1) continue;  // pairs (m, m+2): rows 2r and 2r+1 of this wave
-                auto mx2 = [](uint32_t p, uint32_t q) -> uint32_t {
-                    const float pl = __uint_as_float(p << 16), ql = __uint_as_float(q << 16);
-                    const float ph = __uint_as_float(p & 0xffff0000u), qh = __uint_as_float(q & 0xffff0000u);
-                    return ((ph > qh ? p : q) & 0xffff0000u) | ((pl > ql ? p : q) & 0xffffu);
-                };
-                uint32_t vx = mx2(pk[m].x, pk[m + 2].x), vy = mx2(pk[m].y, pk[m + 2].y);
-                vx = mx2(vx, (uint32_t)__shfl_xor((int)vx, 1));
-                vy = mx2(vy, (uint32_t)__shfl_xor((int)vy, 1));
+                float q[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    q[r] = fmaxf(v[m][r], v[m + 2][r]);
+                    q[r] = fmaxf(q[r], __shfl_xor(q[r], 1));
+                }
                 const int y = (oy0 >> 1) + ((wave * (MT / 2) + (m >> 1)) >> 1);
                 const int x = (ox0 >> 1) + (((m & 1) * 16 + p16) >> 1);
-                if (!(p16 & 1) && y < Ho2 && x < Wo2 && nvalid)
-                    *(uint2*)(a.pool_dst + ((size_t)y * Wo2 + x) * CsO + n) = make_uint2(vx, vy);
+                const bool ok = !(p16 & 1) && y < Ho2 && x < Wo2 && noff != OOBS;
+                const unsigned o = ok ? (unsigned)(y * Wo2 + x) * (unsigned)(CsO * 2) + noff : OOBS;
+                const uint2 pk = make_uint2((uint32_t)d_f2bf(q[0]) | ((uint32_t)d_f2bf(q[1]) << 16),
+                                            (uint32_t)d_f2bf(q[2]) | ((uint32_t)d_f2bf(q[3]) << 16));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rp, o, 0, 0);
             }
         }
     }
@@ -1104,7 +1125,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         const int ab = n / P->CoP, co = n % P->CoP;
         return (ab < 4 && co < Cout) ? w[((size_t)ab * Cin + ci) * Cout + co] : 0.0f;
     };
-    // k-steps are laid out group by group; every channel block is zero-padded to whole groups
+    // layout [group][N block][k-step in group][cout tile][lane][8]; every channel block is
+    // zero-padded to whole groups
     std::vector<uint16_t> pk((size_t)P->G * GK * P->NTtot * 512, 0);
     for (int b = 0; b < P->nblk; ++b) {
         const bool last = b == P->nblk - 1;
@@ -1117,7 +1139,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
                     const Chunk c = ord[(size_t)s * 4 + (l >> 4)];
                     if (c.cc < 0) continue;
                     const int n = t * 16 + (l & 15);
-                    uint16_t* o = &pk[(((size_t)(kstep0 + s) * P->NTtot + t) * 64 + l) * 8];
+                    const int kq = (kstep0 + s) / GK, ksg = (kstep0 + s) % GK, nbk = t / NT, tl = t % NT;
+                    uint16_t* o = &pk[(((((size_t)kq * P->nblocks_n + nbk) * GK + ksg) * NT + tl) * 64 + l) * 8];
                     for (int j = 0; j < 8; ++j) {
                         const int ci = true_ci((b * P->nc_full + c.cc) * 8 + j);
                         if (ci >= 0) o[j] = f2bf(wval(c.tap, ci, n));
@@ -1256,6 +1279,7 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     const Tensor& d = e.tensors[op.dst];
     a.dst = (uint16_t*)d.d;
     a.nch_out = d.Cs / 8;
+    a.dst_bytes = (unsigned)((size_t)e.tH(d) * e.tW(d) * d.Cs * 2);
     a.CoP = P.CoP;
     a.dbg = (PSEG_DIAG && getenv("PSEG_DBG")) ? atoi(getenv("PSEG_DBG")) : 0;
 }
@@ -1297,6 +1321,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     a.pl = tot_w / 2;
     if (op.transposed) { a.pt = tot_h - a.pt; a.pl = tot_w - a.pl; }
     a.pool_dst = op.pool_dst >= 0 ? (uint16_t*)e.tensors[op.pool_dst].d : nullptr;
+    if (op.pool_dst >= 0) { const Tensor& pt = e.tensors[op.pool_dst]; a.pool_bytes = (unsigned)((size_t)e.tH(pt) * e.tW(pt) * pt.Cs * 2); }
     a.add = op.add >= 0 ? (const uint16_t*)e.tensors[op.add].d : nullptr;
     a.deconv = 0;
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n);

@@ -30,7 +30,8 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(_CSRC, "libpseg.so")
+    # PSEG_LIB selects another build of the same ABI (e.g. csrc/libpseg_diag.so with trace stamps)
+    return os.environ.get("PSEG_LIB") or os.path.join(_CSRC, "libpseg.so")
 
 
 def lib():

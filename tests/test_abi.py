@@ -1,0 +1,59 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/pseg.h declares, and fails
+loudly (no CPU fallback) when no HIP device is visible.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "pseg.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pseg_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import pseg_amd
+    L = pseg_amd.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for sym in declared:
+        assert hasattr(L, sym), "libpseg.so does not export %s" % sym
+    assert sorted(pseg_amd.EXPORTED_SYMBOLS) == declared
+    assert L.pseg_abi_version() == 1
+
+
+def test_oracle_library_is_separate_from_the_product():
+    """Nothing of the oracle is linked into or imported by the product package."""
+    import subprocess
+    import pseg_amd
+    out = subprocess.run(["nm", "-D", pseg_amd.lib_path()], capture_output=True, text=True).stdout
+    assert "orc_" not in out
+    pkg = os.path.join(ROOT, "page-segmentation_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dp, fn)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, fn
+
+
+def test_fails_loudly_without_a_gpu():
+    import pseg_amd
+    if pseg_amd.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(pseg_amd.PsegError) as ei:
+        pseg_amd.Engine("fcn_skip", 3)
+    assert "no CPU fallback" in str(ei.value) or "HIP" in str(ei.value)
+    import numpy as np
+    with pytest.raises(pseg_amd.PsegError):
+        pseg_amd.cc_vote(np.zeros((4, 4), np.int64), np.ones((4, 4), np.uint8), 3)
+    with pytest.raises(pseg_amd.PsegError):
+        pseg_amd.masks(np.zeros((4, 4), np.int64), np.ones((4, 4), np.uint8), np.zeros((3, 3), np.uint8))
+    L = pseg_amd.lib()
+    h = ctypes.c_void_p()
+    assert L.pseg_create(0, 3, 1, 0, 1, ctypes.byref(h)) != 0
+    assert L.pseg_create(99, 3, 1, 0, 1, ctypes.byref(h)) != 0
+    assert len(L.pseg_last_error()) > 0

@@ -1,0 +1,115 @@
+"""The drop-in Python API (ocr4all_pixel_classifier.lib.*) end to end on the GPU, plus full-size
+(BASELINE.json sizes) property checks where the oracle is too slow to run."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(gpu, oracle_mod, exact, n_classes=3, shape=(96, 80), page=0):
+    from pseg_amd import synth
+    from ocr4all_pixel_classifier.lib.network import Network
+    from ocr4all_pixel_classifier.lib.dataset import SingleData
+    img, binary, mask = synth.synth_page(page, shape[0], shape[1], n_classes)
+    net = Network("Predict", n_classes=n_classes, exact=exact)
+    Wt = oracle_mod.init_weights("fcn_skip", n_classes, seed=42, gain=1.5, bias_scale=0.05)
+    net.model.set_weights(Wt)
+    data = SingleData(image=img, binary=binary, original_shape=img.shape, image_path="page.png")
+    return net, Wt, data
+
+
+def test_predictor_roundtrip_exact_mode(gpu, oracle_mod, tmp_path):
+    from ocr4all_pixel_classifier.lib.predictor import Predictor
+    from ocr4all_pixel_classifier.lib.predictor_data import PredictSettings
+    from ocr4all_pixel_classifier.lib.postprocess import find_postprocessor
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    from ocr4all_pixel_classifier.lib.dataset import Dataset
+    net, Wt, data = _setup(gpu, oracle_mod, exact=True)
+    cm = ColorMap({"(255, 255, 255)": [0, "bg"], "(255, 0, 0)": [1, "text"], "(0, 255, 0)": [2, "image"]})
+    settings = PredictSettings(n_classes=3, color_map=cm, post_process=[find_postprocessor("cc_majority")],
+                               output=str(tmp_path))
+    pred = Predictor(settings, net)
+    p = pred.predict_single(data)
+    logit_o, prob_o, lab_o = oracle_mod.predict_single_data("fcn_skip", Wt, data.image, "f32")
+    want = oracle_mod.vote_connected_component_class(lab_o, data.binary)
+    assert p.labels.dtype == np.int64 and np.array_equal(p.labels, want)
+    assert np.abs(p.probabilities - prob_o).max() <= 2e-6
+    assert [q.labels.shape for q in pred.predict(Dataset([data], cm))] == [data.image.shape]
+    m = pred.predict_masks(data)
+    wc, wo, wi, wf = oracle_mod.generate_output_masks(want, data.binary, cm.lut())
+    assert np.array_equal(m.color, wc) and np.array_equal(m.overlay, wo)
+    assert np.array_equal(m.inverted_overlay, wi) and np.array_equal(m.fg_color_mask, wf)
+    for sub in ("color", "overlay", "inverted"):
+        assert (tmp_path / sub).is_dir()
+    from ocr4all_pixel_classifier.lib.output import output_data
+    output_data(str(tmp_path), want, data, cm)
+    assert (tmp_path / "color" / "page.png").exists()
+    # weights round-trip through the engine and the .npz file
+    path = net.save_weights(str(tmp_path / "model.h5"))
+    assert path.endswith(".npz")
+    from ocr4all_pixel_classifier.lib.network import Network
+    net2 = Network("Predict", n_classes=3, model=str(tmp_path / "model"), exact=True)
+    got = net2.model.get_weights()
+    assert all(np.array_equal(got[k], Wt[k]) for k in Wt)
+    _, _, lab2 = net2.predict_single_data(data)
+    assert np.array_equal(lab2, lab_o)
+
+
+def test_char_height_via_api(gpu, oracle_mod, tmp_path):
+    from PIL import Image
+    from pseg_amd import synth
+    from ocr4all_pixel_classifier.lib.image_ops import compute_char_height
+    img, _, _ = synth.synth_page(1, 384, 512)
+    gray = 255 - img
+    Image.fromarray(gray).save(tmp_path / "scan.png")
+    assert compute_char_height(str(tmp_path / "scan.png"), False) == oracle_mod.compute_char_height_from_gray(gray, False)
+    with pytest.raises(Exception):
+        compute_char_height(str(tmp_path / "missing.png"), False)
+
+
+def test_full_size_page_properties(gpu, oracle_mod):
+    """BASELINE configs[1] size (2048x1536): the oracle would take too long for every check, so
+    use size-independent properties: determinism, exact-vs-bf16 agreement outside near-ties,
+    tiling invariance (an interior crop far from the borders sees the same receptive field),
+    CC vote idempotence and label-set preservation, masks consistency."""
+    from pseg_amd import synth
+    H, W, C = 2048, 1536, 3
+    img, binary, _ = synth.synth_page(0, H, W, C)
+    Wt = oracle_mod.init_weights("fcn_skip", C, seed=42, gain=1.5, bias_scale=0.05)
+    e32 = gpu.Engine("fcn_skip", C, mode=gpu.MODE_F32_EXACT)
+    e32.set_weights(Wt)
+    eb = gpu.Engine("fcn_skip", C, mode=gpu.MODE_BF16)
+    eb.set_weights(Wt)
+    z32, _, l32 = e32.predict(img, want_probs=False)
+    zb, _, lb = eb.predict(img, want_probs=False)
+    zb2, _, lb2 = eb.predict(img, want_probs=False)
+    assert np.array_equal(zb, zb2) and np.array_equal(lb, lb2)            # deterministic
+    err = np.abs(zb - z32).max()
+    assert err <= 0.03 * max(1.0, np.abs(z32).max())                      # bf16 vs f32, whole net
+    srt = np.sort(z32, -1)
+    margin = srt[..., -1] - srt[..., -2]
+    assert not ((lb != l32) & (margin > 2 * err)).any()                   # flips only at near-ties
+    assert (lb != l32).mean() < 0.02
+    # the oracle agrees with the exact engine on a crop-sized page (bit-identical), and an
+    # interior window of the full page equals the same window of a 512x512 sub-page whose borders
+    # are > 80 px (receptive-field radius 72) away
+    y0, x0 = 768, 512
+    sub = np.ascontiguousarray(img[y0:y0 + 512, x0:x0 + 512])
+    zs, _, _ = e32.predict(sub, want_probs=False)
+    assert np.array_equal(zs[96:416, 96:416], z32[y0 + 96:y0 + 416, x0 + 96:x0 + 416])
+    zo = oracle_mod.forward("fcn_skip", Wt, sub[:160, :192])
+    zg, _, _ = e32.predict(np.ascontiguousarray(sub[:160, :192]), want_probs=False)
+    assert np.array_equal(zo, zg)
+    # post-process properties at full size
+    v1 = gpu.cc_vote(lb.copy(), binary, C)
+    v2 = gpu.cc_vote(v1.copy(), binary, C)
+    assert np.array_equal(v1, v2)                                          # idempotent
+    assert np.array_equal(v1[binary == 0], lb[binary == 0])                # paper pixels untouched
+    assert set(np.unique(v1)) <= set(np.unique(lb))
+    lut = np.array([[255, 255, 255], [255, 0, 0], [0, 255, 0]], np.uint8)
+    color, overlay, inverted, fg = gpu.masks(v1, binary, lut)
+    assert np.array_equal(color, lut[v1])
+    assert (overlay[binary == 1] == 0).all() and np.array_equal(inverted, fg)
+    assert int(overlay.astype(np.int64).sum() + inverted.astype(np.int64).sum()) == int(color.astype(np.int64).sum())
+    e32.close()
+    eb.close()

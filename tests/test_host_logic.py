@@ -1,0 +1,142 @@
+"""Host-side mirror of the reference API (no GPU): names, defaults, enum values, record fields,
+dataset JSON format, post-processor registry, sharding helper."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
+
+
+def test_enums_match_reference_values():
+    from ocr4all_pixel_classifier.lib.architecture import Architecture, Optimizers, default_preprocess
+    assert {m.name: m.value for m in Architecture} == GOLD["architecture_values"]
+    assert {m.name: m.value for m in Optimizers} == GOLD["optimizer_values"]
+    want = np.array(GOLD["preprocess_f32_bits"], np.uint32).view(np.float32)
+    assert np.array_equal(default_preprocess(np.arange(256, dtype=np.uint8)).astype(np.float32), want)
+    assert Architecture.FCN_SKIP.model() == "fcn_skip" and Architecture.UNET.preprocess()[1] is False
+    with pytest.raises(Exception):
+        Architecture.RES_NET.model()            # pretrained backbones are out of scope
+
+
+def test_util_matches_reference_vectors():
+    from ocr4all_pixel_classifier.lib.util import gray_to_rgb, image_to_batch, preserving_resize
+    img = np.array(GOLD["util_img"], np.uint8)
+    assert list(image_to_batch(img).shape) == GOLD["image_to_batch_shape_2d"]
+    assert list(image_to_batch(np.zeros((3, 4, 3))).shape) == GOLD["image_to_batch_shape_3d"]
+    assert gray_to_rgb(img).tolist() == GOLD["gray_to_rgb"]
+    assert list(gray_to_rgb(np.zeros((3, 4, 3), np.uint8)).shape) == GOLD["gray_to_rgb_passthrough_shape"]
+    a = np.arange(12).reshape(3, 4)
+    assert np.array_equal(preserving_resize(a, (6, 8)), np.repeat(np.repeat(a, 2, 0), 2, 1))
+    assert np.array_equal(preserving_resize(np.repeat(np.repeat(a, 2, 0), 2, 1), (3, 4)), a)
+
+
+def test_records_and_settings_keep_the_reference_fields():
+    from ocr4all_pixel_classifier.lib.dataset import SingleData, Dataset
+    from ocr4all_pixel_classifier.lib.trainer import TrainSettings, AugmentationSettings
+    from ocr4all_pixel_classifier.lib.predictor_data import PredictSettings, Prediction
+    from ocr4all_pixel_classifier.lib.metrics import Loss, Monitor
+    from ocr4all_pixel_classifier.lib.architecture import Architecture, Optimizers
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    import dataclasses
+    # lib/dataset.py:18-29
+    assert [f.name for f in dataclasses.fields(SingleData)] == [
+        "image", "binary", "orig_binary", "mask", "image_path", "binary_path", "mask_path",
+        "line_height_px", "original_shape", "output_path", "user_data"]
+    assert SingleData().line_height_px == 1
+    ds = Dataset([SingleData(), SingleData()], ColorMap({}))
+    assert len(ds) == 2 and len(list(ds)) == 2
+    # lib/trainer.py:59-106: positional head + defaults
+    assert TrainSettings._fields[:8] == ("n_epoch", "n_classes", "l_rate", "train_data", "validation_data",
+                                         "display", "output_dir", "threads")
+    d = TrainSettings._field_defaults
+    assert d["architecture"] is Architecture.FCN_SKIP and d["loss"] is Loss.CATEGORICAL_CROSSENTROPY
+    assert d["monitor"] is Monitor.VAL_LOSS and d["optimizer"] is Optimizers.ADAM
+    assert d["optimizer_norm_clipping"] is True and d["optimizer_norm_clip_value"] == 1.0
+    assert d["early_stopping_max_performance_drops"] == 10 and d["model_suffix"] == ".h5"
+    assert d["data_augmentation"] is False and d["image_dimension"] == 1
+    a = AugmentationSettings()
+    assert a.rotation_range == 2.5 and a.zoom_range == [0.95, 1.05]
+    assert a.to_image_params()["interpolation_order"] == 3 and "brightness_range" in a.to_image_params()
+    assert a.to_mask_params()["interpolation_order"] == 0 and "brightness_range" not in a.to_mask_params()
+    # lib/predictor_data.py:18-26
+    ps = PredictSettings()
+    assert ps.n_classes == -1 and ps.high_res_output is False and ps.post_process is None
+    assert Prediction._fields == ("labels", "probabilities", "data")
+    assert Monitor.JACRAD_COEF.value == "jacard_coef" and Loss.CATEGORCAL_FOCAL.value == "categorical_focal"
+
+
+def test_postprocessor_registry_key_normalisation():
+    from ocr4all_pixel_classifier.lib import postprocess as pp
+    assert pp.find_postprocessor("cc_majority") is pp.vote_connected_component_class
+    assert pp.find_postprocessor("CC-Vote") is pp.vote_connected_component_class
+    assert pp.find_postprocessor("bounding_boxes") is pp.add_bounding_boxes
+    assert pp.find_postprocessor("BBox") is pp.add_bounding_boxes
+    with pytest.raises(KeyError):
+        pp.find_postprocessor("nope")
+    assert "cc_majority" in pp.postprocess_help()
+
+
+def test_dataset_json_and_prepare_images(tmp_path):
+    from PIL import Image
+    from ocr4all_pixel_classifier.lib.dataset import DatasetLoader, prepare_images
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    rng = np.random.default_rng(0)
+    gray = rng.integers(0, 256, (40, 30), dtype=np.uint8)
+    mask_rgb = np.zeros((40, 30, 3), np.uint8)
+    mask_rgb[5:20, 3:12] = (255, 0, 0)
+    Image.fromarray(gray).save(tmp_path / "p.png")
+    Image.fromarray(mask_rgb).save(tmp_path / "m.png")
+    cm = ColorMap({"(0, 0, 0)": [0, "bg"], "(255, 0, 0)": [1, "text"]})
+    js = {"train": [{"binary_path": str(tmp_path / "p.png"), "image_path": str(tmp_path / "p.png"),
+                     "mask_path": str(tmp_path / "m.png"), "line_height_px": 6}], "test": [], "eval": []}
+    (tmp_path / "d.json").write_text(json.dumps(js))            # README.md:46-70 format
+    ds = DatasetLoader(6, cm).load_data_from_json([str(tmp_path / "d.json")], "train")
+    assert len(ds) == 1
+    d = ds.data[0]
+    assert d.image.dtype == np.uint8 and d.image.shape == (40, 30) and d.original_shape == (40, 30)
+    assert np.array_equal(d.image, ((1.0 - gray / 255) * 255).astype(np.uint8))     # lib/dataset.py:137,145
+    assert set(np.unique(d.binary)) <= {0, 1} and d.mask[10, 5] == 1 and d.mask[0, 0] == 0
+    assert np.array_equal(d.binary, (np.where(gray > 127, 255, 0) == 0).astype(np.uint8))   # ink = 1
+    # a scale != 1 needs the bicubic kernels that are not built yet: explicit error, no CPU fallback
+    with pytest.raises(Exception):
+        prepare_images(gray, np.where(gray > 127, 255, 0).astype(np.uint8), 12, 6)
+    assert len(DatasetLoader(6, cm).load_data_from_json([str(tmp_path / "d.json")], "all")) == 1
+
+
+def test_network_needs_the_gpu_engine():
+    import pseg_amd
+    from ocr4all_pixel_classifier.lib.network import Network
+    if pseg_amd.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(Exception):
+        Network("Predict", n_classes=3)
+
+
+def test_shard_pages():
+    from pseg_amd.parallel import shard_pages
+    assert shard_pages(10, 0, 4) == [0, 4, 8] and shard_pages(10, 3, 4) == [3, 7]
+    assert shard_pages(2, 3, 4) == [] and shard_pages(0, 0, 1) == []
+    allp = sorted(sum((shard_pages(257, r, 8) for r in range(8)), []))
+    assert allp == list(range(257))
+    with pytest.raises(ValueError):
+        shard_pages(4, 4, 4)
+
+
+def test_synthetic_weights_agree_with_oracle_init(oracle_mod):
+    """pseg_amd.synth.glorot_weights (product side, used by bench / Network) draws the same
+    numbers as the oracle's init given the same spec order."""
+    from pseg_amd import synth
+    for arch in ("fcn_skip", "res_unet"):
+        specs = []
+        for name, kind, shp, cout in oracle_mod.weight_specs(arch, 3):
+            specs += [(name + "/kernel", tuple(shp)), (name + "/bias", (cout,))]
+        a = synth.glorot_weights(specs, seed=42, gain=1.5, bias_scale=0.05)
+        b = oracle_mod.init_weights(arch, 3, seed=42, gain=1.5, bias_scale=0.05)
+        assert list(a.keys()) == list(b.keys())
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    img, binary, mask = synth.synth_page(3, 128, 96, 6)
+    assert img.shape == (128, 96) and img.dtype == np.uint8 and set(np.unique(binary)) <= {0, 1}
+    assert mask.max() <= 5 and np.array_equal(synth.synth_page(3, 128, 96, 6)[0], img)

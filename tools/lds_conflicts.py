@@ -51,3 +51,54 @@ if __name__ == "__main__":
             for TWH in (36, 20):
                 res.append((sim(KS, nc, PS, TWH), PS, TWH))
         print("KS=%d nc=%d:" % (KS, nc), "  ".join("PS=%d/TWH=%d: avg %.2f worst %d" % (ps, t, a, w) for (a, w), ps, t in res))
+
+
+# ---- pairing model (mirror of pair_cost / pair_chunks in csrc/pseg_mfma.hip) ---------------------
+RA = [0, 1, 2, 3, 12, 13, 14, 15]
+RB = [4, 5, 6, 7, 8, 9, 10, 11]
+
+
+def pair_cost(o0, o1, sigma):
+    cost = 0
+    for r0, r1 in ((RA, RB), (RB, RA)):
+        cnt = [0] * 16
+        for r in r0:
+            cnt[(sigma * r + o0) % 16] += 1
+        for r in r1:
+            cnt[(sigma * r + o1) % 16] += 1
+        cost += max(cnt)
+    return cost
+
+
+def pair_chunks_cycles(KS, nc, sigma, pitch):
+    allc = [(t, c) for t in range(KS * KS) for c in range(nc)]
+    slot = lambda tc: (tc[0] // KS) * pitch + (tc[0] % KS) * sigma + tc[1]
+    used = [False] * len(allc)
+    cycles = 0
+    npairs = 0
+    for i in range(len(allc)):
+        if used[i]:
+            continue
+        used[i] = True
+        best, bc = -1, 99
+        for j in range(i + 1, len(allc)):
+            if not used[j]:
+                c = pair_cost(slot(allc[i]), slot(allc[j]), sigma)
+                if c < bc:
+                    bc, best = c, j
+                    if bc == 2:
+                        break
+        if best >= 0:
+            used[best] = True
+            cycles += bc
+        else:
+            cycles += 2
+        npairs += 1
+    return cycles / npairs * 2   # LDS cycles per fragment read (ideal 4)
+
+
+def sweep():
+    for KS, nc in ((5, 3), (5, 4), (5, 5), (3, 4), (1, 9)):
+        for sigma in range(nc, nc + 4):
+            best = min((pair_chunks_cycles(KS, nc, sigma, 36 * sigma + pad), pad) for pad in range(16))
+            print("KS=%d nc=%d sigma=%d: best %.2f cycles/read at pitch pad %d" % (KS, nc, sigma, best[0], best[1]))

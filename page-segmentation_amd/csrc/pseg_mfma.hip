@@ -90,6 +90,18 @@ struct MConv {
     int dbg;   // ablation bits (PSEG_DBG): 1 skip input staging, 2 skip MFMAs, 4 skip epilogue, 8 skip weight DMA
 };
 
+// single v_max_f32: fmaxf() makes hipcc canonicalise both operands first (3 instructions per max
+// on MFMA outputs); NaNs are not a concern for the ReLU / max-pool epilogue.
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// value of the neighbouring lane (lane ^ 1) by DPP quad_perm [1,0,3,2]: one VALU op, no LDS crossbar
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+
 __device__ __forceinline__ uint4 relu_bf16x8(uint4 v) {
     auto f = [](uint32_t w) -> uint32_t {
         if (w & 0x8000u) w &= 0xffff0000u;
@@ -563,7 +575,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
             }
             if (a.relu) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[m][r] = fmaxf(v[m][r], 0.0f);
+                for (int r = 0; r < 4; ++r) v[m][r] = vmax(v[m][r], 0.0f);
             }
             const uint2 pk = make_uint2((uint32_t)d_f2bf(v[m][0]) | ((uint32_t)d_f2bf(v[m][1]) << 16),
                                         (uint32_t)d_f2bf(v[m][2]) | ((uint32_t)d_f2bf(v[m][3]) << 16));
@@ -577,8 +589,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                 float q[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    q[r] = fmaxf(v[m][r], v[m + 2][r]);
-                    q[r] = fmaxf(q[r], __shfl_xor(q[r], 1));
+                    q[r] = vmax(v[m][r], v[m + 2][r]);
+                    q[r] = vmax(q[r], lane_xor1(q[r]));
                 }
                 const int y = (oy0 >> 1) + ((wave * (MT / 2) + (m >> 1)) >> 1);
                 const int x = (ox0 >> 1) + (((m & 1) * 16 + p16) >> 1);

@@ -79,6 +79,7 @@ struct MConv {
     const uint16_t* add;
     unsigned dst_bytes, pool_bytes;
     int deconv, CoP;
+    int nb_loop, nb_total;   // N blocks walked inside one workgroup / N blocks of the layer
     // fused tail (deconv5 -> crop -> logits 1x1 -> softmax/argmax), see tail_epilogue()
     int tail, tail_C, H0, W0, nch_skip;
     const uint16_t* skip;      // full-resolution skip tensor (conv2), or null
@@ -188,16 +189,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: SALU address math
     const int p16 = lane & 15, g = lane >> 4;
     const int tiles_x = (a.Wout + TW - 1) / TW;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, nb = blockIdx.y;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * c_stride - a.pt, ix0 = ox0 * c_stride - a.pl;
     const int WBUF = a.GK * NT * 1024;
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define PSEG_STAMP(i) if (c_trace && tid == 0) c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
     PSEG_STAMP(0)
@@ -218,8 +213,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     // packed weights are laid out [group][N block][piece][lane][8]: one group of one N block is
     // a contiguous run of GK*NT KiB in exactly the order of its LDS ring slot, so the DMA source
     // and destination of piece (wave + 4j) are base + j * 4 KiB.
+    // N blocks: normally one per workgroup (blockIdx.y); the fused tail walks all of its N blocks in
+    // one workgroup (nb_loop > 1, single channel block) so the input tile is staged once.
+    constexpr int NBL = (FIXED && MODE_ == MODE_TAIL) ? 2 : 1;   // compile-time: other instances keep a flat body
+#pragma unroll 1
+    for (int nbi = 0; nbi < NBL; ++nbi) {
+    const int nb = blockIdx.y * NBL + nbi;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     const uint16_t* wsrc = a.wpk + ((size_t)nb * a.GK * NT + wave) * 512 + lane * 8;
-    const size_t wgstride = (size_t)gridDim.y * a.GK * NT * 512;   // elements per group
+    const size_t wgstride = (size_t)a.nb_total * a.GK * NT * 512;   // elements per group
     auto stage_w = [&](int q, int slot) {
         if (c_dbg & 8) return;
         const uint16_t* src = wsrc + (size_t)q * wgstride;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
         // A wave owns tile rows wave, wave+4, ...; all of a wave's 16-byte loads (up to
         // STAGE_SLOTS per lane) are issued before the first LDS write so that one memory
         // latency is exposed per chunk instead of one per row.
-        if (!(c_dbg & 1) && !c_inrelu) {
+        if (!(c_dbg & 1) && !c_inrelu && nbi == 0) {
             // LDS-DMA staging (buffer_load_dwordx4 ... lds): lane L of one instruction fills
             // the 16-byte slot (j*64 + L) of a tile row, slot = pixel*sigma + chunk.  A lane
             // whose pixel lies outside the image, or whose slot is row padding (chunk >= nc),
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                     }
                 }
             }
-        } else if (!(c_dbg & 1)) {
+        } else if (!(c_dbg & 1) && nbi == 0) {
             const int row_items = c_TWH * nc;
             const int J = (row_items + 63) >> 6;          // loads per lane per row
             const int rows_w = (c_THH - wave + 3) >> 2;   // rows of this wave
@@ -426,6 +433,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     }
 
     PSEG_STAMP(5)
+    do {
     // ---- epilogue -----------------------------------------------------------------------------
     // D layout: lane holds pixel (lane & 15) x couts 4*(lane>>4) .. +3 of each 16x16 tile.
     if (c_dbg & 4) { if (acc[0][0][0] == 123.456f) a.dst[0] = 1; return; }
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                 }
             }
             PSEG_STAMP(6)
-            return;
+            break;
         }
     }
     if (c_deconv) {
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
                 *(uint2*)(a.dst + o) = pk;
             }
         }
-        return;
+        break;
     }
 
     // Direct stores: lane (p16, g) owns couts 4g..4g+3 of pixel p16 in every 16x16 tile, i.e.
@@ -602,6 +610,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
             }
         }
     }
+    } while (0);
+    // the next N block reuses the ring and (tail) the staged tile: every wave must be out of the k-loop
+    if (nbi + 1 < NBL) lds_barrier();
+    }   // N-block loop
     PSEG_STAMP(6)
     if (c_trace && tid == 0) { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(x)); c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = x; }
 #undef PSEG_STAMP
@@ -1293,6 +1305,8 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.nch_out = d.Cs / 8;
     a.dst_bytes = (unsigned)((size_t)e.tH(d) * e.tW(d) * d.Cs * 2);
     a.CoP = P.CoP;
+    a.nb_loop = 1;
+    a.nb_total = P.nblocks_n;
     a.dbg = (PSEG_DIAG && getenv("PSEG_DBG")) ? atoi(getenv("PSEG_DBG")) : 0;
 }
 
@@ -1365,8 +1379,10 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
         a.out_probs = e.cur_probs;
         a.out_labels = e.cur_labels;
         a.out_labels_u8 = e.cur_labels_u8;
+        // the specialised tail instances walk both N blocks in one workgroup (NBL = 2 in the kernel)
+        if (P->nblk == 1 && P->nblocks_n == 2 && !getenv("PSEG_GENERIC") && (a.sigma == 10 || a.sigma == 6)) a.nb_loop = 2;
     }
-    dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n);
+    dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n / a.nb_loop);
     return launch_generic_any(a, *P, grid, st, op.layer.c_str());
 }
 

@@ -73,6 +73,7 @@ struct Op {
     float* d_b = nullptr;     // f32 bias
     void* plan = nullptr;     // bf16 mode: MfmaPlan (pseg_mfma.hip), owned by the op
     bool fused_away = false;  // bf16 mode: op folded into a neighbour (pool -> conv epilogue, logits -> deconv tail)
+    int fuse1 = -1;           // bf16 mode: OP_CONV that recomputes this first-layer op on its halo tile
     int tail_logits = -1;     // bf16 mode: OP_DECONV2 that also runs this OP_LOGITS (fused tail)
     double flops_per_canvas_px = 0;  // algorithmic, true channels
     int timing_slot = -1;

@@ -79,7 +79,9 @@ struct MConv {
     const uint16_t* add;
     unsigned dst_bytes, pool_bytes;
     int deconv, CoP;
-    int nb_loop, nb_total;   // N blocks walked inside one workgroup / N blocks of the layer
+    int nb_loop, nb_total;
+    // fused first layer (FL_FUSE1): conv1 is recomputed on the halo tile from the uint8 page
+    const uint8_t* f1_img; int f1_H, f1_W; const uint16_t* f1_wpk; const float* f1_bias; int f1_relu, lds_f1_off;   // N blocks walked inside one workgroup / N blocks of the layer
     // fused tail (deconv5 -> crop -> logits 1x1 -> softmax/argmax), see tail_epilogue()
     int tail, tail_C, H0, W0, nch_skip;
     const uint16_t* skip;      // full-resolution skip tensor (conv2), or null
@@ -157,7 +159,7 @@ constexpr int STAGE_SLOTS = 12;  // 16-byte loads a lane keeps in flight while s
 // "read it from the argument block" (generic fallback).  With ~50 runtime geometry fields the
 // compiler hoists and spills scalars by the hundred; with constants the prologue collapses.
 enum { MODE_CONV = 0, MODE_DECONV = 1, MODE_TAIL = 2 };
-enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16 };
+enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16, FL_FUSE1 = 32 };
 #ifndef PSEG_DIAG
 #define PSEG_DIAG 0   // 1: compile the in-kernel trace stamps / ablation switches (diagnostic builds)
 #endif
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
     const bool c_add = FIXED ? (FL_ & FL_ADD) != 0 : a.add != nullptr;
     const bool c_deconv = FIXED ? MODE_ != MODE_CONV : a.deconv != 0;
     const bool c_tail = FIXED ? MODE_ == MODE_TAIL : a.tail != 0;
+    constexpr bool c_fuse1 = FIXED && (FL_ & FL_FUSE1) != 0;
     const int c_dbg = PSEG_DIAG ? a.dbg : 0;
     unsigned long long* const c_trace = PSEG_DIAG ? a.trace : nullptr;
     char* in_t = smem;
@@ -285,7 +288,83 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MConv a) {
         // A wave owns tile rows wave, wave+4, ...; all of a wave's 16-byte loads (up to
         // STAGE_SLOTS per lane) are issued before the first LDS write so that one memory
         // latency is exposed per chunk instead of one per row.
-        if (!(c_dbg & 1) && !c_inrelu && nbi == 0) {
+        if constexpr (c_fuse1) {
+            // ---- fused first layer: conv1 (Cin = 1, 5x5, 20 couts) recomputed on the halo tile ---
+            // The uint8 page tile (halo + 2) is converted to bf16(x/255) and kept in LDS twice,
+            // once shifted by one pixel, so that the 8 consecutive pixels a lane needs for kernel
+            // row ky start on a 4-byte boundary in one of the two copies.  K = 5 rows x 8 columns
+            // (as conv1_mfma_kernel); the 16x16 result tile has the pixel on the lane and 4 couts
+            // in registers = 8 bytes of the [row][pixel][chunk] tile conv2 reads.  Halo pixels
+            // outside the canvas are conv2's SAME padding: zeros, not conv1(0).
+            constexpr int HR = TH + 4, HC = TW + 4;          // halo tile of conv2 (k5, stride 1)
+            constexpr int UR = HR + 4, UCB = 96;             // uint8 tile rows; bytes per copy row (48 px)
+            char* f1 = smem + a.lds_f1_off;                  // [2 copies][UR][48] bf16
+            constexpr int NU = (UR * 48 + 255) / 256;        // byte loads per thread, all issued before use
+            uint8_t ub[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = tid + u * 256;
+                const int r = i / 48, c = i - r * 48;
+                const int y = oy0 - 4 + r, x = ox0 - 4 + c;
+                ub[u] = 0;
+                if (i < UR * 48 && c < HC + 4 && y >= 0 && y < a.f1_H && x >= 0 && x < a.f1_W) ub[u] = a.f1_img[(size_t)y * a.f1_W + x];
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = tid + u * 256;
+                if (i < UR * 48) {
+                    const int r = i / 48, c = i - r * 48;
+                    const uint16_t hv = d_f2bf((float)ub[u] * 0.00392156886f);
+                    *(uint16_t*)(f1 + r * UCB + c * 2) = hv;
+                    if (c >= 1) *(uint16_t*)(f1 + UR * UCB + r * UCB + (c - 1) * 2) = hv;
+                }
+            }
+            bf16x8 w1[2][2];
+#pragma unroll
+            for (int s1 = 0; s1 < 2; ++s1)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) w1[s1][q] = *(const bf16x8*)(a.f1_wpk + ((size_t)(s1 * 2 + q) * 64 + lane) * 8);
+            const float4 b1a = *(const float4*)(a.f1_bias + 4 * g), b1b = *(const float4*)(a.f1_bias + 16 + 4 * g);
+            lds_barrier();   // copies visible; does not drain the weight DMAs already in flight
+            constexpr int NMT = HR * HC / 16;                // 45 pixel tiles of 16 (HR*HC = 720)
+            // 45 tiles over 4 waves: every wave runs 12 (the surplus ones redo tile 44, same values), three
+            // independent tiles per trip so that the LDS-read -> MFMA -> convert -> LDS-write latencies of
+            // neighbouring tiles overlap
+            constexpr int TPW = (NMT + 3) / 4;
+            static_assert(TPW % 3 == 0, "tiles per wave must be a multiple of the unroll factor");
+            for (int j0 = 0; j0 < TPW; j0 += 3) {
+#pragma unroll
+            for (int uu = 0; uu < 3; ++uu) {
+                const int mt = min(wave + 4 * (j0 + uu), NMT - 1);
+                const int pi = mt * 16 + p16;
+                const int hr = (int)(((unsigned)pi * (65536u / HC + 1u)) >> 16), hx = pi - hr * HC;
+                const char* cb = f1 + (hx & 1) * (UR * UCB) + (hx & ~1) * 2;
+                f32x4 z0 = f32x4{0.f, 0.f, 0.f, 0.f}, z1 = z0;
+#pragma unroll
+                for (int s1 = 0; s1 < 2; ++s1) {
+                    const int ky = s1 == 0 ? g : 4;          // rows past the kernel carry zero weights
+                    const uint32_t* rp = (const uint32_t*)(cb + (hr + ky) * UCB);
+                    const uint4 xv = make_uint4(rp[0], rp[1], rp[2], rp[3]);
+                    z0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s1][0], __builtin_bit_cast(bf16x8, xv), z0, 0, 0, 0);
+                    z1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s1][1], __builtin_bit_cast(bf16x8, xv), z1, 0, 0, 0);
+                }
+                const int gy = oy0 - 2 + hr, gx = ox0 - 2 + hx;
+                const bool inc = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+                float v0 = z0[0] + b1a.x, v1 = z0[1] + b1a.y, v2 = z0[2] + b1a.z, v3 = z0[3] + b1a.w;
+                float u0 = z1[0] + b1b.x, u1 = z1[1] + b1b.y, u2 = z1[2] + b1b.z, u3 = z1[3] + b1b.w;
+                if (a.f1_relu) {
+                    v0 = vmax(v0, 0.f); v1 = vmax(v1, 0.f); v2 = vmax(v2, 0.f); v3 = vmax(v3, 0.f);
+                    u0 = vmax(u0, 0.f); u1 = vmax(u1, 0.f); u2 = vmax(u2, 0.f); u3 = vmax(u3, 0.f);
+                }
+                uint2 pa = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16), (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
+                uint2 pb = make_uint2((uint32_t)d_f2bf(u0) | ((uint32_t)d_f2bf(u1) << 16), (uint32_t)d_f2bf(u2) | ((uint32_t)d_f2bf(u3) << 16));
+                if (!inc) { pa = make_uint2(0, 0); pb = make_uint2(0, 0); }
+                char* dp = in_t + hr * a.row_pitch + hx * c_PS2;
+                *(uint2*)(dp + g * 8) = pa;                  // couts 4g .. 4g+3
+                if (g < 2) *(uint2*)(dp + 32 + g * 8) = pb;  // couts 16..19 (g = 0), zero pad 20..23 (g = 1)
+            }
+            }
+        } else if (!(c_dbg & 1) && !c_inrelu && nbi == 0) {
             // LDS-DMA staging (buffer_load_dwordx4 ... lds): lane L of one instruction fills
             // the 16-byte slot (j*64 + L) of a tile row, slot = pixel*sigma + chunk.  A lane
             // whose pixel lies outside the image, or whose slot is row padding (chunk >= nc),
@@ -845,7 +924,7 @@ struct MfmaPlan {
     int MT = 4, NT = 2, KS = 1, stride = 1;
     int nblk = 1, nc_full = 1, nc_last = 1, ks_full = 1, ks_last = 1;
     int PS2 = 0, row_pitch = 0, THH = 0, TWH = 0, GK = 4, NB = 3, G = 1, lds_w_off = 0, lds_tab_off = 0, lds_bytes = 0;
-    int NTtot = 0, nblocks_n = 1, CoP = 0;
+    int NTtot = 0, nblocks_n = 1, CoP = 0, lds_f1_off = 0;
     int* d_tab_full = nullptr;
     int* d_tab_last = nullptr;
     uint16_t* d_wpk = nullptr;
@@ -890,6 +969,25 @@ int mfma_plan_graph(Engine& e) {
             e.ops[pi].tail_logits = (int)li;
             e.tensors[e.ops[pi].dst].fused = true;
             lg.fused_away = true;
+        }
+    // first layer (Cin = 1, k5, 20 couts) feeding only one k5 conv -> recomputed inside that conv
+    if (!getenv("PSEG_NO_CONV1_FUSION") && e.in_ch == 1)
+        for (size_t ci = 0; ci < e.ops.size(); ++ci) {
+            Op& c1 = e.ops[ci];
+            if (c1.type != OP_CONV || c1.src0 != e.input_tensor || c1.src1 >= 0 || c1.k != 5 || c1.Cout != 20 || c1.stride != 1) continue;
+            int users = 0, user = -1;
+            for (size_t j = 0; j < e.ops.size(); ++j) {
+                const Op& o = e.ops[j];
+                const int u = (o.src0 == c1.dst) + (o.src1 == c1.dst) + (o.add == c1.dst);
+                users += u;
+                if (u) user = (int)j;
+            }
+            if (users != 1) continue;
+            Op& c2 = e.ops[user];
+            if (c2.type != OP_CONV || c2.k != 5 || c2.stride != 1 || c2.src1 >= 0 || c2.up0 || c2.in_relu || c2.add >= 0 || c2.transposed || c2.Cout > 32) continue;
+            c2.fuse1 = (int)ci;
+            c1.fused_away = true;
+            e.tensors[c1.dst].fused = true;
         }
     for (auto& op : e.ops) {
         if (op.type != OP_POOL) continue;
@@ -1135,6 +1233,10 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->lds_w_off = round_up(in_bytes, 16);
     P->lds_tab_off = P->lds_w_off + NB * GK * NT * 1024;
     P->lds_bytes = P->lds_tab_off + tab_bytes + 16;
+    if (op.fuse1 >= 0) {   // two bf16 copies of the (TH+8) x 48 uint8 tile
+        P->lds_f1_off = round_up(P->lds_bytes, 16);
+        P->lds_bytes = P->lds_f1_off + 2 * (TH + 8) * 96;
+    }
 
     // ---- pack weights into MFMA A-fragment order -----------------------------------------------
     // concat-storage channel cs -> true input channel (or -1 for pad)
@@ -1225,11 +1327,14 @@ static int launch_inst(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t
 static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
     const int mode = a.tail ? MODE_TAIL : (a.deconv ? MODE_DECONV : MODE_CONV);
     const int fl = (a.pool_dst ? FL_POOL : 0) | (a.add ? FL_ADD : 0) | (a.in_relu ? FL_INRELU : 0) |
-                   (a.up0 ? FL_UP0 : 0) | (a.up1 ? FL_UP1 : 0);
+                   (a.up0 ? FL_UP0 : 0) | (a.up1 ? FL_UP1 : 0) | (a.f1_img ? FL_FUSE1 : 0);
     const int sg = a.sigma, st_ = a.stride, ks = P.KS;
+    if (a.f1_img && !(P.MT == 8 && P.NT == 2 && ks == 5 && sg == 3 && mode == MODE_CONV && fl == (FL_POOL | FL_FUSE1)))
+        return fail(PSEG_EUNSUPPORTED, "first-layer fusion has no kernel instance for this shape");
 #define PSEG_TRY_INST(MT_, NT_, KS_, ST_, SG_, MODE_, FL_)                                          \
-    if (!getenv("PSEG_GENERIC") && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == FL_) \
-        return launch_inst<MT_, NT_, KS_, ST_, SG_, MODE_, FL_>(a, P, grid, st);
+    if (!getenv("PSEG_GENERIC") && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == (FL_)) \
+        return launch_inst<MT_, NT_, KS_, ST_, SG_, MODE_, (FL_)>(a, P, grid, st);
+    PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL | FL_FUSE1)   // conv1 + conv2 fused
     PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL)      // conv2 (dense tile, resident weights)
     PSEG_TRY_INST(8, 2, 5, 1, 6, MODE_CONV, FL_POOL)      // conv2 (padded tile)
     PSEG_TRY_INST(4, 3, 5, 1, 6, MODE_CONV, 0)            // conv3, deconv3
@@ -1350,6 +1455,18 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     if (op.pool_dst >= 0) { const Tensor& pt = e.tensors[op.pool_dst]; a.pool_bytes = (unsigned)((size_t)e.tH(pt) * e.tW(pt) * pt.Cs * 2); }
     a.add = op.add >= 0 ? (const uint16_t*)e.tensors[op.add].d : nullptr;
     a.deconv = 0;
+    if (op.fuse1 >= 0) {
+        const Op& c1 = e.ops[op.fuse1];
+        auto* P1 = (MfmaPlan*)c1.plan;
+        if (!P1 || P1->kind != PLAN_CONV1) return fail(PSEG_EINVAL, "fused first layer has no plan");
+        a.f1_img = e.cur_img;
+        a.f1_H = e.H;
+        a.f1_W = e.W;
+        a.f1_wpk = P1->d_wpk;
+        a.f1_bias = P1->d_bias;
+        a.f1_relu = c1.relu;
+        a.lds_f1_off = P->lds_f1_off;
+    }
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n);
     return launch_generic_any(a, *P, grid, st, op.layer.c_str());
 }

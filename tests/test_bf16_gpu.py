@@ -57,7 +57,7 @@ def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, arch, C, shape):
     eng.close()
 
 
-def test_bf16_first_layer(gpu, oracle_mod):
+def test_bf16_first_layer(gpu, oracle_mod, monkeypatch):
     """conv1 (MFMA, K = 25 taps): float32 sums of exact bf16 products; only the summation order
     differs from the oracle's sequential chain, so after bf16 rounding almost every value is
     identical and none is off by more than one bf16 ulp (2^-7 relative)."""
@@ -65,6 +65,7 @@ def test_bf16_first_layer(gpu, oracle_mod):
     img = rng.integers(0, 256, size=(70, 50), dtype=np.uint8)
     Wt = oracle_mod.init_weights("fcn_skip", 3, seed=3, gain=1.5, bias_scale=0.05)
     _, acts = oracle_mod.forward("fcn_skip", Wt, img, "bf16", return_acts=True)
+    monkeypatch.setenv("PSEG_NO_CONV1_FUSION", "1")     # materialise conv1 (stand-alone MFMA kernel)
     eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
     eng.set_weights(Wt)
     eng.predict(img, want_logits=False, want_probs=False)
@@ -116,3 +117,28 @@ def test_bf16_unfused_tail_matches_fused(gpu, oracle_mod, monkeypatch):
     assert np.abs(p_f - p_u).max() <= 1e-4
     bad, total = _check_labels(l_f, z_f, z_u)
     assert bad == 0
+
+
+def test_bf16_conv1_fusion_is_bit_identical_to_unfused(gpu, oracle_mod, monkeypatch):
+    """conv1 recomputed inside conv2's workgroup uses the same k order and rounding points as the
+    stand-alone first-layer kernel: logits of the fused and unfused engines are identical."""
+    rng = np.random.default_rng(33)
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=8, gain=1.5, bias_scale=0.05)
+    outs = []
+    for fuse in (True, False):
+        if not fuse:
+            monkeypatch.setenv("PSEG_NO_CONV1_FUSION", "1")
+        eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
+        eng.set_weights(Wt)
+        res = []
+        for (H, W) in [(70, 50), (160, 224), (33, 1)]:
+            img = np.random.default_rng(H).integers(0, 256, size=(H, W), dtype=np.uint8)
+            z, _, lab = eng.predict(img, want_probs=False)
+            res.append((z, lab, eng.activation("conv2d_1")))
+        if fuse:
+            with pytest.raises(gpu.PsegError):
+                eng.activation("conv2d")            # never materialised
+        eng.close()
+        outs.append(res)
+    for (zf, lf, cf), (zu, lu, cu) in zip(*outs):
+        assert np.array_equal(cf, cu) and np.array_equal(zf, zu) and np.array_equal(lf, lu)

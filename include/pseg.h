@@ -101,6 +101,37 @@ int pseg_timing_num_slots(const pseg_engine* e);
 int pseg_timing_get(pseg_engine* e, int slot, char* name, size_t name_cap, double* total_ms,
                     int64_t* launches, double* flops);
 
+/* ---- Train: lib/network.py:90-104,167-246 (compile + fit), lib/metrics.py:8-17,60-85 ------- */
+
+/* Training state of a PSEG_MODE_F32_EXACT engine (fcn / fcn_skip): Keras-formulation Adam
+ * (lib/architecture.py:83; beta1 .9, beta2 .999, eps 1e-7 are Keras' defaults) with per-tensor
+ * clip-by-norm (`clipnorm`, lib/network.py:97; <= 0 disables) and optional clip-by-value. */
+int pseg_train_init(pseg_engine* e, float beta1, float beta2, float eps, float clipnorm,
+                    float clipvalue);
+
+/* One sample (batch of one page, as the reference: lib/network.py:151-153): forward, mean sparse
+ * softmax cross-entropy + metrics, backward.  img uint8 (H,W), mask uint8 class ids (H,W), host
+ * pointers.  metrics = {loss, accuracy, jacard_coef, dice_coef} of this sample.  Gradients stay
+ * in the engine's flat gradient buffer until pseg_train_apply. */
+int pseg_train_forward_backward(pseg_engine* e, const uint8_t* img, const uint8_t* mask, int H,
+                                int W, float metrics[4]);
+
+/* The flat device gradient buffer (all parameters in weight-table order, then the metric
+ * accumulators): data-parallel training all-reduces exactly this buffer (one RCCL call), then
+ * applies with grad_scale = 1/world. */
+int pseg_train_grad_buffer(pseg_engine* e, float** d_grad, int64_t* count);
+int pseg_train_metrics(pseg_engine* e, float metrics[4]);
+
+/* Clip + Adam update of every parameter with the (scaled) gradients; t += 1. */
+int pseg_train_apply(pseg_engine* e, float lr, float grad_scale);
+
+/* Gradient of one parameter in Keras layout (tests). */
+int pseg_train_get_gradient(pseg_engine* e, const char* name, float* out, int64_t count);
+
+/* model.evaluate step (lib/network.py:244-246): forward + loss/metrics only. */
+int pseg_eval_step(pseg_engine* e, const uint8_t* img, const uint8_t* mask, int H, int W,
+                   float metrics[4]);
+
 /* ---- Post-process: lib/postprocess.py, lib/output.py ---------------------------------- */
 
 /* vote_connected_component_class (lib/postprocess.py:9-26): 4-connected components of

@@ -124,6 +124,7 @@ struct Engine {
     float* d_prob_stage = nullptr;
     float* d_logit_stage = nullptr;
     size_t lab_stage_bytes = 0, prob_stage_bytes = 0, logit_stage_bytes = 0;
+    void* train = nullptr;   // TrainState (pseg_train.hip), f32 mode only
     // timing
     bool timing = false;
     std::vector<TimingSlot> slots;
@@ -133,7 +134,36 @@ struct Engine {
     int tW(const Tensor& t) const { return Wp >> t.s; }
 };
 
+// f32-exact conv launcher shared with the training path (pseg_train.hip)
+struct ConvArgs {
+    const float* src0;
+    const float* src1;
+    int C0, C1;
+    int up0, up1;
+    int Hin, Win;  // logical input dims (after the folded upsample)
+    const float* w;
+    const float* bias;
+    const float* add;
+    float* dst;
+    int KH, KW, stride, pt, pl, Hout, Wout, Cout, in_relu, relu;
+    const float* mask;   // training dgrad: input value counts only where mask (same layout as src0) > 0
+    int dst_pitch;       // pixels per output row (0: Wout) -- crop / canvas-pitched outputs
+};
+int launch_conv_exact(const ConvArgs& a, hipStream_t st);
+int upload_weights(Engine& e);
+int set_canvas(Engine& e, int H, int W);
+int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs, int64_t* d_labels,
+              uint8_t* d_labels_u8, hipStream_t st);
+// training state (pseg_train.hip)
+int train_sync_weights_to_host(Engine& e);
+void train_free(Engine& e);
+
 int time_begin(Engine& e, Op& op, hipStream_t st, hipEvent_t* ev0);
 int time_end(Engine& e, Op& op, hipStream_t st, hipEvent_t ev0);
 
 }  // namespace pseg
+
+// the opaque handle of include/pseg.h
+struct pseg_engine {
+    pseg::Engine e;
+};

@@ -34,18 +34,6 @@ int fail(int code, const char* fmt, ...) {
 // =============================================================================================
 constexpr int COT = 16;  // output channels per thread in the exact conv kernels
 
-struct ConvArgs {
-    const float* src0;
-    const float* src1;
-    int C0, C1;
-    int up0, up1;
-    int Hin, Win;  // logical input dims (after the folded upsample)
-    const float* w;
-    const float* bias;
-    const float* add;
-    float* dst;
-    int KH, KW, stride, pt, pl, Hout, Wout, Cout, in_relu, relu;
-};
 
 // One thread = one output pixel x COT consecutive output channels.  Weights are indexed only by
 // loop counters and blockIdx, i.e. wave-uniform: hipcc serves them through the scalar cache.
@@ -71,6 +59,7 @@ __global__ __launch_bounds__(256) void conv_exact_kernel(ConvArgs a) {
                 for (int ci = 0; ci < a.C0; ++ci) {
                     float xv = p[ci];
                     if (a.in_relu) xv = xv > 0.0f ? xv : 0.0f;
+                    if (a.mask) xv = a.mask[(p - a.src0) + ci] > 0.0f ? xv : 0.0f;
                     const float* wr = wt + (size_t)ci * a.Cout;
 #pragma unroll
                     for (int j = 0; j < COT; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
@@ -89,13 +78,14 @@ __global__ __launch_bounds__(256) void conv_exact_kernel(ConvArgs a) {
             }
         }
     }
-    float* o = a.dst + (size_t)pix * a.Cout;
-    const float* ad = a.add ? a.add + (size_t)pix * a.Cout : nullptr;
+    const size_t opix = a.dst_pitch ? (size_t)y * a.dst_pitch + x : (size_t)pix;
+    float* o = a.dst + opix * a.Cout;
+    const float* ad = a.add ? a.add + opix * a.Cout : nullptr;
 #pragma unroll
     for (int j = 0; j < COT; ++j) {
         const int co = co0 + j;
         if (co < a.Cout) {
-            float v = acc[j] + a.bias[co];
+            float v = a.bias ? acc[j] + a.bias[co] : acc[j];
             if (ad) v = v + ad[co];
             if (a.relu) v = v > 0.0f ? v : 0.0f;
             o[co] = v;
@@ -276,7 +266,14 @@ static int ensure(void** p, size_t* cap, size_t bytes) {
 // Upload weights in correlation form.  Conv2D: as is.  Conv2DTranspose s1 (kh,kw,Cout,Cin):
 // Wc[ky][kx][ci][co] = K[KH-1-ky][KW-1-kx][co][ci].  Conv2DTranspose k2 s2: [a][b][ci][co] =
 // K[a][b][co][ci].
-static int upload_weights(Engine& e) {
+int launch_conv_exact(const ConvArgs& a, hipStream_t st) {
+    dim3 grid(cdiv(a.Hout * a.Wout, 256), cdiv(a.Cout, COT));
+    conv_exact_kernel<<<grid, 256, 0, st>>>(a);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+int upload_weights(Engine& e) {
     for (auto& op : e.ops) {
         if (op.kparam < 0) continue;
         const Param& kp = e.params[op.kparam];
@@ -309,7 +306,7 @@ static int upload_weights(Engine& e) {
     return PSEG_OK;
 }
 
-static int set_canvas(Engine& e, int H, int W) {
+int set_canvas(Engine& e, int H, int W) {
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     const int Hp = round_up(H, 32), Wp = round_up(W, 32);
     e.H = H;
@@ -337,7 +334,7 @@ static int set_canvas(Engine& e, int H, int W) {
     return PSEG_OK;
 }
 
-static int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
+int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
                      int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st) {
     Tensor& in = e.tensors[e.input_tensor];
     {
@@ -480,9 +477,6 @@ static int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* 
 // =============================================================================================
 using namespace pseg;
 
-struct pseg_engine {
-    Engine e;
-};
 
 extern "C" {
 
@@ -538,6 +532,7 @@ int pseg_destroy(pseg_engine* h) {
     Engine& e = h->e;
     (void)hipSetDevice(e.device);
     if (e.stream) (void)hipStreamSynchronize(e.stream);
+    train_free(e);
     for (auto& t : e.tensors) free_dev(t.d);
     for (auto& op : e.ops) {
         free_dev((void*&)op.d_w);
@@ -600,6 +595,7 @@ int pseg_get_weights(const pseg_engine* h, const char* name, float* out, int64_t
     Param* p = find_param(const_cast<Engine&>(h->e), name);
     if (!p) return fail(PSEG_ENOTFOUND, "no weight named '%s'", name);
     if (count != (int64_t)p->host.size()) return fail(PSEG_EINVAL, "weight '%s' has %zu elements", name, p->host.size());
+    if (h->e.train) PSEG_TRY(train_sync_weights_to_host(const_cast<Engine&>(h->e)));
     std::copy(p->host.begin(), p->host.end(), out);
     return PSEG_OK;
 }

@@ -1,0 +1,641 @@
+// pseg_train.hip -- train step of the FCN (float32 engine): forward (pseg_engine.hip) -> sparse
+// softmax cross-entropy + metrics -> backward -> per-tensor clip-by-norm -> Keras-formulation Adam.
+//
+// Reference semantics restated:
+//   lib/metrics.py:8-9     loss      = mean over pixels of logsumexp(z) - z[y]
+//   lib/metrics.py:12-17   accuracy  = mean(argmax(z) == y)
+//   lib/metrics.py:60-85   jacard / dice with the +100 smoothing, per class over (H,W), mean over classes
+//   lib/network.py:90-104  optimizer(lr, clipnorm): per-tensor clip_by_norm (TF2.5 `clipnorm`), then Adam
+//   lib/architecture.py:83 Keras Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps), eps=1e-7
+// Round-1 scope: fcn / fcn_skip graphs (stride-1 convs, k2s2 transposed convs, 2x2 max-pool,
+// concat); correctness first -- these are plain float32 VALU kernels, not tuned.
+// All parameter gradients live in ONE flat device buffer (plus the metric accumulators) so that
+// data-parallel training needs a single RCCL all-reduce.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "pseg_common.h"
+
+namespace pseg {
+
+constexpr int COT = 16;
+
+struct TrainState {
+    float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-7f, clipnorm = 1.0f, clipvalue = 0.0f;
+    int64_t step = 0;
+    // flat buffers: [params in e.params order][metrics: loss, correct, I_c (C), S_c (C)]
+    float* d_grad = nullptr;
+    float* d_m = nullptr;
+    float* d_v = nullptr;
+    float* d_norm = nullptr;     // per-parameter sum of squares
+    std::vector<int64_t> off;    // per param offset in the flat buffers
+    int64_t nparam = 0, nflat = 0;
+    std::vector<float*> tgrad;   // per tensor gradient (canvas dims), lazily sized
+    std::vector<size_t> tbytes;
+    float* d_wd = nullptr;       // scratch: transformed weights for dgrad
+    size_t wd_bytes = 0;
+    float* d_logits = nullptr;
+    float* d_dlogits = nullptr;
+    uint8_t* d_mask = nullptr;
+    uint8_t* d_img = nullptr;
+    size_t logits_bytes = 0, mask_bytes = 0, img_bytes = 0;
+    int H = 0, W = 0;
+};
+
+static TrainState* TS(Engine& e) { return (TrainState*)e.train; }
+
+void train_free(Engine& e) {
+    TrainState* t = TS(e);
+    if (!t) return;
+    (void)hipFree(t->d_grad); (void)hipFree(t->d_m); (void)hipFree(t->d_v); (void)hipFree(t->d_norm);
+    for (auto p : t->tgrad) (void)hipFree(p);
+    (void)hipFree(t->d_wd); (void)hipFree(t->d_logits); (void)hipFree(t->d_dlogits);
+    (void)hipFree(t->d_mask); (void)hipFree(t->d_img);
+    delete t;
+    e.train = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// acc layout: [0] sum loss, [1] count correct, [2..2+C) intersection_c, [2+C..2+2C) sum_c
+__global__ void ce_metrics_kernel(const float* logits, const uint8_t* labels, int n, int C, float inv_n,
+                                  float* dlogits, float* acc) {
+    __shared__ float sh[2 + 2 * 16];
+    if (threadIdx.x < 2 + 2 * 16) sh[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) {
+        const float* z = logits + (size_t)p * C;
+        const int y = labels[p];
+        float m = z[0];
+        int am = 0;
+        for (int c = 1; c < C; ++c)
+            if (z[c] > m) { m = z[c]; am = c; }
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s += expf(z[c] - m);
+        const float lse = logf(s) + m;
+        const float zy = (y < C) ? z[y] : 0.0f;
+        atomicAdd(&sh[0], lse - zy);
+        atomicAdd(&sh[1], am == y ? 1.0f : 0.0f);
+        for (int c = 0; c < C; ++c) {
+            const float pr = expf(z[c] - m) / s;
+            const float oh = (c == y) ? 1.0f : 0.0f;
+            dlogits[(size_t)p * C + c] = (pr - oh) * inv_n;
+            atomicAdd(&sh[2 + c], oh * pr);
+            atomicAdd(&sh[2 + C + c], oh + pr);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 + 2 * C) atomicAdd(&acc[threadIdx.x], sh[threadIdx.x]);
+}
+
+// forward conv weights [KH][KW][Cin][Cout] -> dgrad weights of the channel range [c0, c0+nc):
+// Wd[ky'][kx'][co][ci - c0] = W[KH-1-ky'][KW-1-kx'][ci][co]   (+ slack handled by the caller)
+__global__ void wd_conv_kernel(const float* w, int KH, int KW, int Cin, int Cout, int c0, int nc, float* wd) {
+    const int n = KH * KW * Cout * nc;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int ci = i % nc, co = (i / nc) % Cout, t = i / (nc * Cout);
+        const int ky = t / KW, kx = t % KW;
+        wd[i] = w[(((size_t)(KH - 1 - ky) * KW + (KW - 1 - kx)) * Cin + c0 + ci) * Cout + co];
+    }
+}
+
+// deconv weights [ab][Cin][Cout] -> [ab][Cout][nc] for the channel range [c0, c0+nc)
+__global__ void wd_deconv_kernel(const float* w, int Cin, int Cout, int c0, int nc, float* wd) {
+    const int n = 4 * Cout * nc;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int ci = i % nc, co = (i / nc) % Cout, ab = i / (nc * Cout);
+        wd[i] = w[((size_t)ab * Cin + c0 + ci) * Cout + co];
+    }
+}
+
+// dX[i,j,c] += sum_{ab,co} dY'[2i+a, 2j+b, co] * W[ab][c0+c][co]   (dY' = dY masked by Y > 0 for ReLU)
+__global__ __launch_bounds__(256) void deconv2_dgrad_kernel(const float* dY, const float* Y, int relu, int Hin, int Win,
+                                                            int Cout, const float* wd /*[ab][Cout][nc]*/, int nc,
+                                                            float* dX /*[Hin][Win][nc]*/) {
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= Hin * Win) return;
+    const int c0 = blockIdx.y * COT;
+    const int i = pix / Win, j = pix - i * Win;
+    float acc[COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c) acc[c] = 0.0f;
+    for (int ab = 0; ab < 4; ++ab) {
+        const size_t o = ((size_t)(2 * i + (ab >> 1)) * (2 * Win) + 2 * j + (ab & 1)) * Cout;
+        for (int co = 0; co < Cout; ++co) {
+            float g = dY[o + co];
+            if (relu && !(Y[o + co] > 0.0f)) g = 0.0f;
+            const float* wr = wd + ((size_t)ab * Cout + co) * nc + c0;
+#pragma unroll
+            for (int c = 0; c < COT; ++c) acc[c] = __builtin_fmaf(g, wr[c], acc[c]);
+        }
+    }
+    float* o = dX + (size_t)pix * nc;
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+        if (c0 + c < nc) o[c0 + c] += acc[c];
+}
+
+// max-pool backward: the first maximum of the 2x2 window (row-major) receives the gradient
+__global__ void pool_bwd_kernel(const float* X, const float* dY, int H, int W, int C, float* dX) {
+    const size_t n = (size_t)(H / 2) * (W / 2) * C;
+    const int Wo = W / 2;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const size_t p = t / C;
+        const int x = (int)(p % Wo), y = (int)(p / Wo);
+        const size_t b = ((size_t)(2 * y) * W + 2 * x) * C + c;
+        const size_t o[4] = {b, b + C, b + (size_t)W * C, b + (size_t)W * C + C};
+        int best = 0;
+        float bv = X[o[0]];
+        for (int q = 1; q < 4; ++q)
+            if (X[o[q]] > bv) { bv = X[o[q]]; best = q; }
+        dX[o[best]] += dY[t];
+    }
+}
+
+// dW[tap][ci0+ci][co] += sum over the pixel strip of X[src pixel of (p, tap)][ci] * dY'[p][co]
+// mode 0 (conv / logits): p = (y,x) of dY, X pixel = (y + ky - pt, x + kx - pl) (zero outside)
+// mode 1 (deconv k2s2):   p = (i,j) of X,  dY pixel = (2i + a, 2j + b), tap = ab
+struct WgradArgs {
+    const float* X;
+    int XC, ci0, Hx, Wx, xpitch;
+    const float* dY;
+    const float* maskY;
+    int Hy, Wy, ypitch, Cout, Cin;
+    int KW, pt, pl, mode, strip_rows;
+    float* dW;
+    float* dB;   // only written by blocks with tap 0 when non-null
+};
+
+constexpr int WG_PC = 32;  // pixels per LDS chunk
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
+    float* Xs = sm;                    // [WG_PC][XCp]
+    float* Ys = sm + WG_PC * XCp;      // [WG_PC][COp]
+    const int tap = blockIdx.y;
+    const int ky = tap / a.KW, kx = tap % a.KW;
+    const int itW = a.mode == 0 ? a.Wy : a.Wx, itH = a.mode == 0 ? a.Hy : a.Hx;
+    const int r0 = blockIdx.x * a.strip_rows, r1 = min(r0 + a.strip_rows, itH);
+    const int tiles_ci = XCp / 4, tiles_co = COp / 4, ntl = tiles_ci * tiles_co;
+    float acc[3][16];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+    float bsum = 0.0f;
+    const int npx = (r1 - r0) * itW;
+    for (int p0 = 0; p0 < npx; p0 += WG_PC) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < WG_PC * XCp; i += 256) {
+            const int pp = i / XCp, c = i - pp * XCp;
+            const int p = p0 + pp;
+            float v = 0.0f;
+            if (p < npx && c < a.XC) {
+                const int y = r0 + p / itW, x = p % itW;
+                int sy, sx;
+                if (a.mode == 0) { sy = y + ky - a.pt; sx = x + kx - a.pl; } else { sy = y; sx = x; }
+                if (sy >= 0 && sy < a.Hx && sx >= 0 && sx < a.Wx) v = a.X[((size_t)sy * a.xpitch + sx) * a.XC + c];
+            }
+            Xs[i] = v;
+        }
+        for (int i = threadIdx.x; i < WG_PC * COp; i += 256) {
+            const int pp = i / COp, c = i - pp * COp;
+            const int p = p0 + pp;
+            float v = 0.0f;
+            if (p < npx && c < a.Cout) {
+                const int y = r0 + p / itW, x = p % itW;
+                const int dy = a.mode == 0 ? y : 2 * y + (tap >> 1), dx = a.mode == 0 ? x : 2 * x + (tap & 1);
+                const size_t o = ((size_t)dy * a.ypitch + dx) * a.Cout + c;
+                v = a.dY[o];
+                if (a.maskY && !(a.maskY[o] > 0.0f)) v = 0.0f;
+            }
+            Ys[i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int tl = threadIdx.x + q * 256;
+            if (tl < ntl) {
+                const int tci = tl / tiles_co, tco = tl - tci * tiles_co;
+                for (int pp = 0; pp < WG_PC; ++pp) {
+                    const float4 xv = *(const float4*)(Xs + pp * XCp + tci * 4);
+                    const float4 yv = *(const float4*)(Ys + pp * COp + tco * 4);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[q][i * 4 + j] = __builtin_fmaf(xs[i], ys[j], acc[q][i * 4 + j]);
+                }
+            }
+        }
+        if (a.dB && tap == 0 && (int)threadIdx.x < a.Cout)
+            for (int pp = 0; pp < WG_PC; ++pp) bsum += Ys[pp * COp + threadIdx.x];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int tl = threadIdx.x + q * 256;
+        if (tl < ntl) {
+            const int tci = tl / tiles_co, tco = tl - tci * tiles_co;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ci = tci * 4 + i, co = tco * 4 + j;
+                    if (ci < a.XC && co < a.Cout)
+                        atomicAdd(&a.dW[((size_t)tap * a.Cin + a.ci0 + ci) * a.Cout + co], acc[q][i * 4 + j]);
+                }
+        }
+    }
+    if (a.dB && tap == 0 && (int)threadIdx.x < a.Cout) atomicAdd(&a.dB[threadIdx.x], bsum);
+}
+
+// dB[co] += sum over pixels of dY' (dY masked by Y > 0 for ReLU layers)
+__global__ void bias_grad_kernel(const float* dY, const float* maskY, size_t npix, int Cout, float* dB) {
+    __shared__ float sh[128];
+    if (threadIdx.x < 128) sh[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const size_t n = npix * Cout;
+    float s = 0.0f;
+    // each thread keeps one channel: stride is a multiple of Cout
+    const size_t stride = (size_t)gridDim.x * blockDim.x / Cout * Cout;
+    const size_t start = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (start < stride)
+        for (size_t i = start; i < n; i += stride) {
+            float v = dY[i];
+            if (maskY && !(maskY[i] > 0.0f)) v = 0.0f;
+            s += v;
+        }
+    if (start < stride) atomicAdd(&sh[start % Cout], s);
+    __syncthreads();
+    if ((int)threadIdx.x < Cout && sh[threadIdx.x] != 0.0f) atomicAdd(&dB[threadIdx.x], sh[threadIdx.x]);
+}
+
+__global__ void sumsq_kernel(const float* g, int64_t n, float scale, float* out) {
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = g[i] * scale;
+        s += v * v;
+    }
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// g <- g*scale; per-tensor clip_by_norm (t * clip / max(norm, clip)); optional clipvalue; Keras Adam
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float gscale, const float* sumsq,
+                            float clipnorm, float clipvalue, float lr_t, float b1, float b2, float eps) {
+    float cn = 1.0f;
+    if (clipnorm > 0.0f) {
+        const float norm = sqrtf(*sumsq);
+        cn = clipnorm / fmaxf(norm, clipnorm);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale * cn;
+        if (clipvalue > 0.0f) gi = fminf(fmaxf(gi, -clipvalue), clipvalue);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+static int ensure_buf(void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p) return PSEG_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    PSEG_HIP(hipMalloc(p, bytes));
+    *cap = bytes;
+    return PSEG_OK;
+}
+
+static int producer_of(const Engine& e, int tensor) {
+    for (size_t i = 0; i < e.ops.size(); ++i)
+        if (e.ops[i].dst == tensor) return (int)i;
+    return -1;
+}
+
+static int train_init(Engine& e, float b1, float b2, float eps, float clipnorm, float clipvalue) {
+    if (e.mode != PSEG_MODE_F32_EXACT) return fail(PSEG_EUNSUPPORTED, "training runs on the float32 engine (mode F32_EXACT)");
+    if (e.arch != PSEG_ARCH_FCN_SKIP && e.arch != PSEG_ARCH_FCN) return fail(PSEG_EUNSUPPORTED, "training is built for fcn / fcn_skip only so far");
+    if (e.n_classes > 16) return fail(PSEG_EUNSUPPORTED, "training supports at most 16 classes");
+    train_free(e);
+    auto* t = new TrainState();
+    e.train = t;
+    t->beta1 = b1; t->beta2 = b2; t->eps = eps; t->clipnorm = clipnorm; t->clipvalue = clipvalue;
+    int64_t o = 0;
+    for (auto& p : e.params) {
+        t->off.push_back(o);
+        o += (int64_t)p.host.size();
+        o = (o + 3) & ~(int64_t)3;
+    }
+    t->nparam = o;
+    t->nflat = o + 2 + 2 * 16;
+    PSEG_HIP(hipMalloc((void**)&t->d_grad, (size_t)t->nflat * 4));
+    PSEG_HIP(hipMalloc((void**)&t->d_m, (size_t)t->nparam * 4));
+    PSEG_HIP(hipMalloc((void**)&t->d_v, (size_t)t->nparam * 4));
+    PSEG_HIP(hipMalloc((void**)&t->d_norm, e.params.size() * 4));
+    PSEG_HIP(hipMemset(t->d_m, 0, (size_t)t->nparam * 4));
+    PSEG_HIP(hipMemset(t->d_v, 0, (size_t)t->nparam * 4));
+    t->tgrad.assign(e.tensors.size(), nullptr);
+    t->tbytes.assign(e.tensors.size(), 0);
+    return PSEG_OK;
+}
+
+// forward + loss/metrics (+ backward when `backward`); inputs are host pointers
+static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int H, int W, bool backward) {
+    TrainState* t = TS(e);
+    if (!t) return fail(PSEG_EINVAL, "pseg_train_init has not been called");
+    PSEG_HIP(hipSetDevice(e.device));
+    for (auto& p : e.params)
+        if (!p.set) return fail(PSEG_EINVAL, "weight '%s' was never set", p.name.c_str());
+    if (e.weights_dirty) PSEG_TRY(upload_weights(e));
+    PSEG_TRY(set_canvas(e, H, W));
+    hipStream_t st = e.stream;
+    const int C = e.n_classes;
+    const size_t npx = (size_t)H * W;
+    PSEG_TRY(ensure_buf((void**)&t->d_img, &t->img_bytes, npx * e.in_ch));
+    PSEG_TRY(ensure_buf((void**)&t->d_mask, &t->mask_bytes, npx));
+    size_t lb = t->logits_bytes;
+    PSEG_TRY(ensure_buf((void**)&t->d_logits, &lb, npx * C * 4));
+    lb = t->logits_bytes;
+    PSEG_TRY(ensure_buf((void**)&t->d_dlogits, &lb, npx * C * 4));
+    t->logits_bytes = lb;
+    t->H = H; t->W = W;
+    PSEG_HIP(hipMemcpyAsync(t->d_img, img, npx * e.in_ch, hipMemcpyHostToDevice, st));
+    PSEG_HIP(hipMemcpyAsync(t->d_mask, mask, npx, hipMemcpyHostToDevice, st));
+    PSEG_TRY(run_exact(e, t->d_img, t->d_logits, nullptr, nullptr, nullptr, st));
+    float* acc = t->d_grad + t->nparam;
+    // a backward pass starts from zeroed parameter gradients; an evaluation step only resets the metric slots
+    if (backward) PSEG_HIP(hipMemsetAsync(t->d_grad, 0, (size_t)t->nflat * 4, st));
+    else PSEG_HIP(hipMemsetAsync(acc, 0, (size_t)(t->nflat - t->nparam) * 4, st));
+    ce_metrics_kernel<<<cdiv((int)npx, 256), 256, 0, st>>>(t->d_logits, t->d_mask, (int)npx, C, 1.0f / (float)npx, t->d_dlogits, acc);
+    PSEG_HIP(hipGetLastError());
+    if (!backward) return PSEG_OK;
+
+    // tensor gradients (canvas dims), zeroed every step
+    for (size_t i = 0; i < e.tensors.size(); ++i) {
+        if ((int)i == e.input_tensor) continue;
+        const Tensor& tn = e.tensors[i];
+        const size_t bytes = (size_t)e.tH(tn) * e.tW(tn) * tn.C * 4;
+        if (bytes > t->tbytes[i]) {
+            (void)hipFree(t->tgrad[i]);
+            t->tgrad[i] = nullptr;
+            PSEG_HIP(hipMalloc((void**)&t->tgrad[i], bytes));
+            t->tbytes[i] = bytes;
+        }
+        PSEG_HIP(hipMemsetAsync(t->tgrad[i], 0, bytes, st));
+    }
+    auto ensure_wd = [&](size_t floats) -> int {
+        return ensure_buf((void**)&t->d_wd, &t->wd_bytes, (floats + COT) * 4);
+    };
+    const int strips_target = 1536;
+
+    for (int oi = (int)e.ops.size() - 1; oi >= 0; --oi) {
+        Op& op = e.ops[oi];
+        const Tensor& s0 = e.tensors[op.src0];
+        const Tensor* s1 = op.src1 >= 0 ? &e.tensors[op.src1] : nullptr;
+        const int C0 = s0.C, C1 = s1 ? s1->C : 0;
+        float* gw = op.kparam >= 0 ? t->d_grad + t->off[op.kparam] : nullptr;
+        float* gb = op.bparam >= 0 ? t->d_grad + t->off[op.bparam] : nullptr;
+        if (op.type == OP_LOGITS || op.type == OP_CONV) {
+            if (op.stride != 1 || op.up0 || op.up1 || op.in_relu || op.add >= 0)
+                return fail(PSEG_EUNSUPPORTED, "backward of layer %s is not built", op.layer.c_str());
+            const bool lg = op.type == OP_LOGITS;
+            const float* dY = lg ? t->d_dlogits : t->tgrad[op.dst];
+            const float* Y = lg ? nullptr : (const float*)e.tensors[op.dst].d;
+            const int Hy = lg ? H : e.tH(e.tensors[op.dst]), Wy = lg ? W : e.tW(e.tensors[op.dst]);
+            const int Hx = e.tH(s0), Wx = e.tW(s0);
+            const int k = op.k, pt = lg ? 0 : (k - 1) / 2, pl = pt;   // stride-1 SAME, odd kernels (flip-symmetric)
+            // ---- wgrad + bias grad ----
+            for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
+                const Tensor& sx = sidx == 0 ? s0 : *s1;
+                WgradArgs a{};
+                a.X = (const float*)sx.d; a.XC = sx.C; a.ci0 = sidx == 0 ? 0 : C0; a.Hx = Hx; a.Wx = Wx; a.xpitch = Wx;
+                a.dY = dY; a.maskY = (op.relu && Y) ? Y : nullptr;
+                a.Hy = Hy; a.Wy = Wy; a.ypitch = Wy; a.Cout = op.Cout; a.Cin = op.Cin;
+                a.KW = k; a.pt = pt; a.pl = pl; a.mode = 0;
+                a.strip_rows = std::max(1, cdiv(Hy * k * k, strips_target));
+                a.dW = gw; a.dB = sidx == 0 ? gb : nullptr;
+                const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
+                if ((XCp / 4) * (COp / 4) > 768) return fail(PSEG_EUNSUPPORTED, "wgrad tile count too large for %s", op.layer.c_str());
+                dim3 grid(cdiv(Hy, a.strip_rows), k * k);
+                wgrad_kernel<<<grid, 256, (size_t)WG_PC * (XCp + COp) * 4, st>>>(a);
+                PSEG_HIP(hipGetLastError());
+            }
+            // ---- dgrad into the source gradients (skipped for the network input) ----
+            for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
+                const int src = sidx == 0 ? op.src0 : op.src1;
+                if (src == e.input_tensor) continue;
+                const int c0 = sidx == 0 ? 0 : C0, nc = sidx == 0 ? C0 : C1;
+                PSEG_TRY(ensure_wd((size_t)k * k * op.Cout * nc));
+                wd_conv_kernel<<<64, 256, 0, st>>>(op.d_w, k, k, op.Cin, op.Cout, c0, nc, t->d_wd);
+                ConvArgs a{};
+                a.src0 = dY; a.C0 = op.Cout; a.Hin = Hy; a.Win = Wy;
+                a.w = t->d_wd; a.bias = nullptr; a.KH = a.KW = k; a.stride = 1;
+                a.pt = k - 1 - pt; a.pl = k - 1 - pl;
+                a.Hout = lg ? H : Hx; a.Wout = lg ? W : Wx; a.Cout = nc;
+                a.mask = (op.relu && Y) ? Y : nullptr;
+                a.dst = t->tgrad[src]; a.add = t->tgrad[src];
+                a.dst_pitch = Wx;
+                PSEG_TRY(launch_conv_exact(a, st));
+            }
+        } else if (op.type == OP_DECONV2) {
+            const float* dY = t->tgrad[op.dst];
+            const float* Y = (const float*)e.tensors[op.dst].d;
+            const int Hx = e.tH(s0), Wx = e.tW(s0);
+            for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
+                const Tensor& sx = sidx == 0 ? s0 : *s1;
+                WgradArgs a{};
+                a.X = (const float*)sx.d; a.XC = sx.C; a.ci0 = sidx == 0 ? 0 : C0; a.Hx = Hx; a.Wx = Wx; a.xpitch = Wx;
+                a.dY = dY; a.maskY = op.relu ? Y : nullptr;
+                a.Hy = 2 * Hx; a.Wy = 2 * Wx; a.ypitch = 2 * Wx; a.Cout = op.Cout; a.Cin = op.Cin;
+                a.KW = 2; a.mode = 1;
+                a.strip_rows = std::max(1, cdiv(Hx * 4, strips_target));
+                a.dW = gw; a.dB = nullptr;
+                const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
+                dim3 grid(cdiv(Hx, a.strip_rows), 4);
+                wgrad_kernel<<<grid, 256, (size_t)WG_PC * (XCp + COp) * 4, st>>>(a);
+                PSEG_HIP(hipGetLastError());
+            }
+            if (op.Cout > 128) return fail(PSEG_EUNSUPPORTED, "bias gradient supports at most 128 channels");
+            bias_grad_kernel<<<512, 256, 0, st>>>(dY, op.relu ? Y : nullptr, (size_t)4 * Hx * Wx, op.Cout, gb);
+            PSEG_HIP(hipGetLastError());
+            for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
+                const int src = sidx == 0 ? op.src0 : op.src1;
+                const int c0 = sidx == 0 ? 0 : C0, nc = sidx == 0 ? C0 : C1;
+                PSEG_TRY(ensure_wd((size_t)4 * op.Cout * nc));
+                wd_deconv_kernel<<<64, 256, 0, st>>>(op.d_w, op.Cin, op.Cout, c0, nc, t->d_wd);
+                dim3 grid(cdiv(Hx * Wx, 256), cdiv(nc, COT));
+                deconv2_dgrad_kernel<<<grid, 256, 0, st>>>(dY, Y, op.relu, Hx, Wx, op.Cout, t->d_wd, nc, t->tgrad[src]);
+                PSEG_HIP(hipGetLastError());
+            }
+        } else if (op.type == OP_POOL) {
+            const size_t n = (size_t)(e.tH(s0) / 2) * (e.tW(s0) / 2) * s0.C;
+            pool_bwd_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(
+                (const float*)s0.d, t->tgrad[op.dst], e.tH(s0), e.tW(s0), s0.C, t->tgrad[op.src0]);
+            PSEG_HIP(hipGetLastError());
+        }
+    }
+    (void)producer_of;
+    return PSEG_OK;
+}
+
+static int train_metrics(Engine& e, float out[4]) {
+    TrainState* t = TS(e);
+    const int C = e.n_classes;
+    std::vector<float> acc(2 + 2 * 16);
+    PSEG_HIP(hipStreamSynchronize(e.stream));
+    PSEG_HIP(hipMemcpy(acc.data(), t->d_grad + t->nparam, acc.size() * 4, hipMemcpyDeviceToHost));
+    const double n = (double)t->H * t->W;
+    out[0] = (float)(acc[0] / n);
+    out[1] = (float)(acc[1] / n);
+    double jac = 0, dice = 0;
+    for (int c = 0; c < C; ++c) {
+        const double I = acc[2 + c], S = acc[2 + C + c];
+        jac += (I + 100.0) / (S - I + 100.0);
+        dice += (2.0 * I + 100.0) / (S + 100.0);
+    }
+    out[2] = (float)(jac / C);
+    out[3] = (float)(dice / C);
+    return PSEG_OK;
+}
+
+static int train_apply(Engine& e, float lr, float gscale) {
+    TrainState* t = TS(e);
+    if (!t) return fail(PSEG_EINVAL, "pseg_train_init has not been called");
+    PSEG_HIP(hipSetDevice(e.device));
+    hipStream_t st = e.stream;
+    t->step += 1;
+    const double b1t = std::pow((double)t->beta1, (double)t->step), b2t = std::pow((double)t->beta2, (double)t->step);
+    const float lr_t = (float)(lr * std::sqrt(1.0 - b2t) / (1.0 - b1t));
+    PSEG_HIP(hipMemsetAsync(t->d_norm, 0, e.params.size() * 4, st));
+    // parameter -> device buffer (kernels: op.d_w in correlation layout; biases: op.d_b)
+    for (auto& op : e.ops) {
+        if (op.kparam < 0) continue;
+        for (int which = 0; which < 2; ++which) {
+            const int pi = which == 0 ? op.kparam : op.bparam;
+            const int64_t n = (int64_t)e.params[pi].host.size();
+            float* g = t->d_grad + t->off[pi];
+            float* p = which == 0 ? op.d_w : op.d_b;
+            const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
+            if (t->clipnorm > 0.0f) sumsq_kernel<<<grid, 256, 0, st>>>(g, n, gscale, t->d_norm + pi);
+            adam_kernel<<<grid, 256, 0, st>>>(p, g, t->d_m + t->off[pi], t->d_v + t->off[pi], n, gscale, t->d_norm + pi,
+                                             t->clipnorm, t->clipvalue, lr_t, t->beta1, t->beta2, t->eps);
+        }
+    }
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+// device (correlation) layout -> Keras layout, inverse of upload_weights()
+static void to_keras(const Op& op, const std::vector<float>& w, std::vector<float>& out) {
+    const int k = op.k, Cin = op.Cin, Cout = op.Cout;
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int co = 0; co < Cout; ++co) {
+                    const float v = w[(((size_t)ky * k + kx) * Cin + ci) * Cout + co];
+                    size_t o;
+                    if (!op.transposed) o = (((size_t)ky * k + kx) * Cin + ci) * Cout + co;
+                    else if (op.type == OP_DECONV2) o = (((size_t)ky * k + kx) * Cout + co) * Cin + ci;
+                    else o = (((size_t)(k - 1 - ky) * k + (k - 1 - kx)) * Cout + co) * Cin + ci;
+                    out[o] = v;
+                }
+}
+
+int train_sync_weights_to_host(Engine& e) {
+    PSEG_HIP(hipSetDevice(e.device));
+    PSEG_HIP(hipStreamSynchronize(e.stream));
+    for (auto& op : e.ops) {
+        if (op.kparam < 0 || !op.d_w) continue;
+        Param& kp = e.params[op.kparam];
+        Param& bp = e.params[op.bparam];
+        std::vector<float> w(kp.host.size());
+        PSEG_HIP(hipMemcpy(w.data(), op.d_w, w.size() * 4, hipMemcpyDeviceToHost));
+        to_keras(op, w, kp.host);
+        PSEG_HIP(hipMemcpy(bp.host.data(), op.d_b, bp.host.size() * 4, hipMemcpyDeviceToHost));
+    }
+    return PSEG_OK;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+extern "C" {
+
+int pseg_train_init(pseg_engine* h, float beta1, float beta2, float eps, float clipnorm, float clipvalue) {
+    if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    PSEG_HIP(hipSetDevice(h->e.device));
+    return train_init(h->e, beta1, beta2, eps, clipnorm, clipvalue);
+}
+
+int pseg_train_forward_backward(pseg_engine* h, const uint8_t* img, const uint8_t* mask, int H, int W, float metrics[4]) {
+    if (!h || !img || !mask) return fail(PSEG_EINVAL, "NULL argument");
+    if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
+    PSEG_TRY(train_fwd_bwd(h->e, img, mask, H, W, true));
+    if (metrics) PSEG_TRY(train_metrics(h->e, metrics));
+    return PSEG_OK;
+}
+
+int pseg_eval_step(pseg_engine* h, const uint8_t* img, const uint8_t* mask, int H, int W, float metrics[4]) {
+    if (!h || !img || !mask || !metrics) return fail(PSEG_EINVAL, "NULL argument");
+    if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
+    if (!h->e.train) PSEG_TRY(train_init(h->e, 0.9f, 0.999f, 1e-7f, 0.0f, 0.0f));
+    PSEG_TRY(train_fwd_bwd(h->e, img, mask, H, W, false));
+    return train_metrics(h->e, metrics);
+}
+
+int pseg_train_grad_buffer(pseg_engine* h, float** d_grad, int64_t* count) {
+    if (!h || !h->e.train) return fail(PSEG_EINVAL, "pseg_train_init has not been called");
+    TrainState* t = (TrainState*)h->e.train;
+    if (d_grad) *d_grad = t->d_grad;
+    if (count) *count = t->nflat;
+    return PSEG_OK;
+}
+
+int pseg_train_metrics(pseg_engine* h, float metrics[4]) {
+    if (!h || !h->e.train || !metrics) return fail(PSEG_EINVAL, "bad argument");
+    return train_metrics(h->e, metrics);
+}
+
+int pseg_train_apply(pseg_engine* h, float lr, float grad_scale) {
+    if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    return train_apply(h->e, lr, grad_scale);
+}
+
+int pseg_train_get_gradient(pseg_engine* h, const char* name, float* out, int64_t count) {
+    if (!h || !h->e.train || !name || !out) return fail(PSEG_EINVAL, "bad argument");
+    Engine& e = h->e;
+    TrainState* t = (TrainState*)e.train;
+    PSEG_HIP(hipSetDevice(e.device));
+    for (size_t pi = 0; pi < e.params.size(); ++pi) {
+        if (e.params[pi].name != name) continue;
+        const int64_t n = (int64_t)e.params[pi].host.size();
+        if (count != n) return fail(PSEG_EINVAL, "gradient '%s' has %lld elements", name, (long long)n);
+        PSEG_HIP(hipStreamSynchronize(e.stream));
+        std::vector<float> g((size_t)n);
+        PSEG_HIP(hipMemcpy(g.data(), t->d_grad + t->off[pi], (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (auto& op : e.ops)
+            if (op.kparam == (int)pi) {
+                std::vector<float> k((size_t)n);
+                to_keras(op, g, k);
+                std::copy(k.begin(), k.end(), out);
+                return PSEG_OK;
+            }
+        std::copy(g.begin(), g.end(), out);   // bias
+        return PSEG_OK;
+    }
+    return fail(PSEG_ENOTFOUND, "no weight named '%s'", name);
+}
+
+}  // extern "C"

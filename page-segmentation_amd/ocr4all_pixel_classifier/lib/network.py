@@ -118,17 +118,139 @@ class Network:
         logit, prob, pred = self.model.predict(image)
         return logit, prob, pred
 
-    # -- training (lib/network.py:127-246): later SURVEY 8 row ------------------------------------
+    # -- training (lib/network.py:127-246) --------------------------------------------------------
     def create_dataset_inputs(self, train_data: Dataset, data_augmentation=True,
                               data_augmentation_settings=None, shuffle=False):
-        raise Exception("the training path (create_dataset_inputs / train_dataset) is not built yet "
-                        "in the MI355X engine")
+        """Infinite sample stream with the reference's structure (lib/network.py:127-165): in-place
+        shuffle of the data list per pass when training, binary defaulting to ones, in-place
+        foreground masking, batch of one; keys 'input_1' / 'input_2' / 'logits'."""
+        from .architecture import default_preprocess
+        from .util import image_to_batch
+        if self.type == 'train' and data_augmentation:
+            raise Exception("data augmentation (keras-preprocessing affine warps) is not built in the "
+                            "MI355X engine yet; train with data_augmentation=False (the reference default)")
+        data = train_data.data
+        while True:
+            if self.type == 'train' and shuffle:
+                np.random.shuffle(data)
+            for d in data:
+                b, i, m = d.binary, d.image, d.mask
+                if self._rgb:
+                    i = gray_to_rgb(i)
+                if b is None:
+                    b = np.full(i.shape, 1, dtype=np.uint8)
+                    assert i.dtype == np.uint8
+                if self.foreground_masks:
+                    m[b != 1] = 0
+                yield ({'input_1': image_to_batch(default_preprocess(i)), 'input_2': image_to_batch(b)},
+                       {'logits': image_to_batch(m)})
 
-    def train_dataset(self, setting=None, callback: Optional[TrainProgressCallback] = None):
-        raise Exception("the training path (train_dataset) is not built yet in the MI355X engine")
+    def _ensure_train_state(self):
+        if getattr(self, "_train_ready", False):
+            return
+        if self.model.mode != _eng.MODE_F32_EXACT:
+            raise Exception("training needs the float32 engine: construct Network(..., exact=True) "
+                            "(Trainer does this)")
+        if self.optimizer is not Optimizers.ADAM:
+            raise Exception("only the Adam optimizer (the reference default) is built in the MI355X engine")
+        if self.loss_func is not None and getattr(self.loss_func, "value", "categorical_crossentropy") != "categorical_crossentropy":
+            raise Exception("only the categorical cross-entropy loss (the reference default) is built")
+        self.model.train_init(clipnorm=self.optimizer_norm_clip_value if self.optimizer_norm_clipping else 0.0,
+                              clipvalue=self.optimizer_clip_value if self.optimizer_clipping else 0.0)
+        self._train_ready = True
+
+    def _samples(self, dataset):
+        for d in dataset.data:
+            b, i, m = d.binary, d.image, d.mask
+            if self.foreground_masks and b is not None:
+                m[b != 1] = 0
+            yield (gray_to_rgb(i) if self._rgb else i), m
 
     def evaluate_dataset(self, eval_data):
-        raise Exception("the training path (evaluate_dataset) is not built yet in the MI355X engine")
+        """model.evaluate (lib/network.py:244-246): mean loss / accuracy / jacard / dice."""
+        self._ensure_train_state()
+        rows = [self.model.eval_step(i, m) for i, m in self._samples(eval_data)]
+        mean = np.mean(np.asarray(rows, np.float64), axis=0) if rows else np.zeros(4)
+        return dict(zip(("loss", "accuracy", "jacard_coef", "dice_coef"), (float(v) for v in mean)))
+
+    def train_dataset(self, setting=None, callback: Optional[TrainProgressCallback] = None,
+                      rank: int = 0, world: int = 1):
+        """model.fit of lib/network.py:167-242 with the callbacks it configures: ModelCheckpoint
+        (best only on `monitor`), EarlyStopping (patience = early_stopping_max_performance_drops,
+        min_delta, restore best), ReduceLROnPlateau (factor, patience = drops / 2, min_lr) and the
+        progress callback.  Batch of one page; with world > 1 every rank takes its own page per
+        step and the gradients are averaged by one RCCL all-reduce (pseg_amd.parallel)."""
+        from pseg_amd.parallel import allreduce_gradients
+        self._ensure_train_state()
+        s = setting
+        os.makedirs(s.output_dir, exist_ok=True)
+        ckpt = os.path.join(s.output_dir, s.model_name + s.model_suffix)
+        monitor = s.monitor.value
+        maximise = ('acc' in monitor) or monitor.endswith('coef') or monitor.startswith('fmeasure')
+        better = (lambda a, b: a > b + s.early_stopping_min_delta) if maximise else (lambda a, b: a < b - s.early_stopping_min_delta)
+        best, wait, lr_wait = None, 0, 0
+        best_weights = None
+        lr = float(s.l_rate)
+        history = {"loss": [], "accuracy": [], "jacard_coef": [], "dice_coef": [],
+                   "val_loss": [], "val_accuracy": [], "lr": []}
+        train = s.train_data.data
+        n = len(train)
+        it = 0
+        for epoch in range(s.n_epoch):
+            np.random.shuffle(train)                      # lib/network.py:134-135 (in place)
+            rows = []
+            for k in range(rank, n, world):
+                d = train[k]
+                img = gray_to_rgb(d.image) if self._rgb else d.image
+                m = d.mask
+                if self.foreground_masks and d.binary is not None:
+                    m[d.binary != 1] = 0
+                loss, acc, jac, dice = self.model.train_forward_backward(img, m)
+                allreduce_gradients(self.model, world)
+                self.model.train_apply(lr, 1.0 / world)
+                rows.append((loss, acc, jac, dice))
+                if callback:
+                    callback.update_loss(it, loss, acc)
+                it += 1
+            logs = dict(zip(("loss", "accuracy", "jacard_coef", "dice_coef"),
+                            (float(v) for v in np.mean(np.asarray(rows, np.float64), axis=0))))
+            if s.validation_data is not None and len(s.validation_data) > 0:
+                ev = self.evaluate_dataset(s.validation_data)
+                logs.update({"val_" + k: v for k, v in ev.items()})
+            for k in history:
+                if k in logs:
+                    history[k].append(logs[k])
+            history["lr"].append(lr)
+            cur = logs.get(monitor)
+            if cur is None:
+                logger.warning("monitor %s is not available (no validation data?), falling back to loss", monitor)
+                cur, maximise_now = logs["loss"], False
+                improved = best is None or cur < best - s.early_stopping_min_delta
+            else:
+                improved = best is None or better(cur, best)
+            if improved:
+                best, wait, lr_wait = cur, 0, 0
+                if rank == 0 and (s.save_best_model_only or True):
+                    self.save_weights(ckpt)
+                if s.early_stopping_restore_best_weights:
+                    best_weights = self.model.get_weights()
+            else:
+                wait += 1
+                lr_wait += 1
+                if rank == 0 and not s.save_best_model_only:
+                    self.save_weights(ckpt)
+                if s.reduce_lr_on_plateau and lr_wait >= s.early_stopping_max_performance_drops / 2:
+                    lr = max(lr * s.reduce_lr_plateau_factor, s.reduce_lr_min_lr)
+                    lr_wait = 0
+            if callback:
+                callback.next_best(it - 1, best, wait)
+            if s.early_stopping_max_performance_drops != 0 and wait >= s.early_stopping_max_performance_drops:
+                logger.info("early stopping after epoch %d", epoch + 1)
+                break
+        if best_weights is not None and s.early_stopping_restore_best_weights and wait > 0:
+            self.model.set_weights(best_weights)
+        self.history = history
+        return history
 
 
 def tf_backend_allow_growth():

@@ -1,6 +1,6 @@
 """TrainSettings / AugmentationSettings / Trainer (reference: lib/trainer.py).  The settings keep
-the reference's field names, order and defaults (they are the API the frontend fills); the
-train step itself is a later SURVEY 8 row and raises until it is built."""
+the reference's field names, order and defaults (they are the API the frontend fills); training
+runs on the float32 engine (Network(..., exact=True))."""
 import logging
 from typing import List, NamedTuple, Optional
 
@@ -101,7 +101,8 @@ class Trainer:
                                  optimizer_norm_clipping=s.optimizer_norm_clipping,
                                  optimizer_norm_clip_value=s.optimizer_norm_clip_value,
                                  optimizer_clipping=s.optimizer_clipping,
-                                 optimizer_clip_value=s.optimizer_clip_value, loss_func=s.loss)
+                                 optimizer_clip_value=s.optimizer_clip_value, loss_func=s.loss,
+                                 exact=True)
         if len(s.train_data) == 0 and s.n_epoch > 0:
             raise Exception("No training files specified. Maybe set n_iter=0")
         if s.compute_baseline:
@@ -116,13 +117,13 @@ class Trainer:
         if callback:
             callback.init(self.settings.n_epoch * len(self.settings.train_data.data),
                           self.settings.early_stopping_max_performance_drops)
-        self.train_net.train_dataset(setting=self.settings, callback=callback)
+        return self.train_net.train_dataset(setting=self.settings, callback=callback)
 
     def eval(self) -> None:
         if self.settings.evaluation_data is None:
             logger.info('Evaluation Dataset in Trainsetting not set! ')
             return
         if len(self.settings.evaluation_data) > 0:
-            self.train_net.evaluate_dataset(self.settings.evaluation_data)
+            return self.train_net.evaluate_dataset(self.settings.evaluation_data)
         else:
             logger.info('Empty Dataset. Skipping Evaluation')

@@ -17,6 +17,8 @@ EXPORTED_SYMBOLS = (
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
     "pseg_predict", "pseg_predict_device", "pseg_get_activation", "pseg_flops_per_pixel",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
+    "pseg_train_init", "pseg_train_forward_backward", "pseg_train_grad_buffer", "pseg_train_metrics",
+    "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
     "pseg_cc_vote", "pseg_cc_vote_device", "pseg_bbox_fill", "pseg_masks", "pseg_masks_device",
     "pseg_otsu_char_height",
 )
@@ -62,6 +64,14 @@ def lib():
     L.pseg_timing_num_slots.argtypes = [vp]
     L.pseg_timing_get.argtypes = [vp, i, c.c_char_p, c.c_size_t, c.POINTER(c.c_double),
                                   c.POINTER(i64), c.POINTER(c.c_double)]
+    f = c.c_float
+    L.pseg_train_init.argtypes = [vp, f, f, f, f, f]
+    L.pseg_train_forward_backward.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
+    L.pseg_train_grad_buffer.argtypes = [vp, c.POINTER(vp), c.POINTER(i64)]
+    L.pseg_train_metrics.argtypes = [vp, c.POINTER(f)]
+    L.pseg_train_apply.argtypes = [vp, f, f]
+    L.pseg_train_get_gradient.argtypes = [vp, c.c_char_p, vp, i64]
+    L.pseg_eval_step.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
     L.pseg_cc_vote.argtypes = [i, vp, vp, i, i, i]
     L.pseg_cc_vote_device.argtypes = [i, vp, vp, i, i, i, vp]
     L.pseg_bbox_fill.argtypes = [i, vp, vp, i, i, i]
@@ -171,6 +181,49 @@ class Engine:
         _check(lib().pseg_get_activation(self._h, layer.encode(), None, 0, dims))
         out = np.empty((dims[0], dims[1], dims[2]), np.float32)
         _check(lib().pseg_get_activation(self._h, layer.encode(), _ptr(out), out.size, dims))
+        return out
+
+    # -- training (float32 engine) -----------------------------------------------------------------
+    def train_init(self, beta1=0.9, beta2=0.999, eps=1e-7, clipnorm=1.0, clipvalue=0.0):
+        """Keras Adam defaults; clipnorm is per tensor (lib/network.py:97), <= 0 disables."""
+        _check(lib().pseg_train_init(self._h, beta1, beta2, eps, clipnorm, clipvalue))
+
+    def _img_mask(self, image, mask):
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        msk = np.ascontiguousarray(mask, dtype=np.uint8)
+        if img.shape[:2] != msk.shape[:2]:
+            raise PsegError("image %r and mask %r differ in shape" % (img.shape, msk.shape))
+        return img, msk
+
+    def train_forward_backward(self, image, mask):
+        """-> (loss, accuracy, jacard_coef, dice_coef) of this page; gradients stay on the device."""
+        img, msk = self._img_mask(image, mask)
+        m = (ctypes.c_float * 4)()
+        _check(lib().pseg_train_forward_backward(self._h, _ptr(img), _ptr(msk), img.shape[0], img.shape[1], m))
+        return tuple(float(v) for v in m)
+
+    def eval_step(self, image, mask):
+        img, msk = self._img_mask(image, mask)
+        m = (ctypes.c_float * 4)()
+        _check(lib().pseg_eval_step(self._h, _ptr(img), _ptr(msk), img.shape[0], img.shape[1], m))
+        return tuple(float(v) for v in m)
+
+    def train_apply(self, lr, grad_scale=1.0):
+        _check(lib().pseg_train_apply(self._h, float(lr), float(grad_scale)))
+
+    def grad_buffer(self):
+        """(device pointer, float count) of the flat gradient buffer -- what DP all-reduces."""
+        ptr, n = ctypes.c_void_p(), ctypes.c_int64()
+        _check(lib().pseg_train_grad_buffer(self._h, ctypes.byref(ptr), ctypes.byref(n)))
+        return int(ptr.value), int(n.value)
+
+    def gradients(self):
+        L = lib()
+        out = {}
+        for name, shp in self.weight_specs():
+            a = np.empty(shp, np.float32)
+            _check(L.pseg_train_get_gradient(self._h, name.encode(), _ptr(a), a.size))
+            out[name] = a
         return out
 
     def flops_per_pixel(self):

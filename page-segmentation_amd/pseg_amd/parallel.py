@@ -36,3 +36,32 @@ def predict_pages_sharded(predict_fn: Callable[[np.ndarray], np.ndarray], pages:
         for i, lab in part:
             out[i] = lab
     return out  # type: ignore[return-value]
+
+
+class _DevBuf:
+    """__cuda_array_interface__ view of a raw device pointer (float32 vector)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def grad_tensor(engine):
+    """Zero-copy torch view of the engine's flat gradient buffer (all parameters + the metric
+    accumulators).  Data-parallel training = one all-reduce on this tensor, then
+    engine.train_apply(lr, grad_scale=1/world) on every rank."""
+    import torch
+    ptr, n = engine.grad_buffer()
+    return torch.as_tensor(_DevBuf(ptr, n), device="cuda:%d" % engine.device)
+
+
+def allreduce_gradients(engine, world):
+    """the only collective of the build -- one RCCL all-reduce(sum) of the flat fp32
+    gradient (673 013 + metric slots for fcn_skip C=3, 2.7 MB) per train step."""
+    if world <= 1:
+        return
+    import torch
+    import torch.distributed as dist
+    g = grad_tensor(engine)
+    torch.cuda.synchronize(g.device)
+    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize(g.device)

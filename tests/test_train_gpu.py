@@ -1,0 +1,143 @@
+"""Train step (float32 engine) against the torch-CPU autograd reference + NumPy Keras-Adam
+(oracle/train_ref.py).  Floating-point kernel: tolerances are written per check; north_star asks
+for loss within 1e-4 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample(seed, H, W, C):
+    from pseg_amd import synth
+    img, binary, mask = synth.synth_page(seed, H, W, C)
+    return img, mask
+
+
+@pytest.mark.parametrize("arch,C,shape", [("fcn_skip", 3, (64, 96)), ("fcn_skip", 6, (70, 50)), ("fcn", 3, (96, 64))])
+def test_loss_metrics_and_gradients(gpu, oracle_mod, arch, C, shape):
+    from oracle.train_ref import fcn_loss_and_grads
+    Wt = oracle_mod.init_weights(arch, C, seed=11, gain=1.5, bias_scale=0.05)
+    img, mask = _sample(2, shape[0], shape[1], C)
+    loss_o, acc_o, jac_o, dice_o, g_o = fcn_loss_and_grads(arch, Wt, img, mask)
+    eng = gpu.Engine(arch, C, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    eng.train_init(clipnorm=1.0)
+    loss, acc, jac, dice = eng.train_forward_backward(img, mask)
+    assert abs(loss - loss_o) <= 1e-4 * abs(loss_o)              # north_star: 1e-4 relative
+    assert abs(acc - acc_o) <= 2.0 / img.size                    # argmax near-ties may flip a pixel
+    assert abs(jac - jac_o) <= 1e-4 and abs(dice - dice_o) <= 1e-4
+    assert eng.eval_step(img, mask)[0] == pytest.approx(loss, rel=1e-6)
+    g = eng.gradients()
+    assert list(g.keys()) == list(g_o.keys())
+    for k in g_o:
+        scale = np.abs(g_o[k]).max() + 1e-12
+        err = np.abs(g[k] - g_o[k]).max()
+        assert err <= 2e-3 * scale + 1e-9, "%s: max err %g vs scale %g" % (k, err, scale)
+    eng.close()
+
+
+def test_adam_clipnorm_trajectory(gpu, oracle_mod):
+    """Three steps on two pages: weights follow the NumPy restatement of Keras Adam with per-tensor
+    clip_by_norm; the loss trajectory matches within 1e-4 relative."""
+    from oracle.train_ref import fcn_loss_and_grads, KerasAdam
+    arch, C = "fcn_skip", 3
+    Wt = oracle_mod.init_weights(arch, C, seed=5, gain=1.5, bias_scale=0.05)
+    pages = [_sample(s, 64, 64, C) for s in (0, 1)]
+    eng = gpu.Engine(arch, C, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    eng.train_init(clipnorm=1.0)
+    opt = KerasAdam(lr=1e-3, clipnorm=1.0)
+    Wo = Wt
+    for step in range(3):
+        img, mask = pages[step % 2]
+        loss_o, _, _, _, g_o = fcn_loss_and_grads(arch, Wo, img, mask)
+        loss = eng.train_forward_backward(img, mask)[0]
+        assert abs(loss - loss_o) <= 1e-4 * abs(loss_o), (step, loss, loss_o)
+        eng.train_apply(1e-3)
+        Wo = opt.apply(Wo, g_o)
+    Wg = eng.get_weights()
+    for k in Wo:
+        # Adam's first steps move every weight by ~lr regardless of gradient scale, so compare the
+        # *update*; elements whose gradient is ~0 have an ill-conditioned m/sqrt(v) and are excluded
+        d_o, d_g = Wo[k] - Wt[k], Wg[k] - Wt[k]
+        assert np.abs(d_g - d_o).max() <= 0.05 * 3e-3 + 1e-7, k
+        assert np.median(np.abs(d_g - d_o)) <= 2e-5, k
+    # predict after training uses the updated device weights
+    lab = eng.predict(pages[0][0], want_logits=False, want_probs=False)[2]
+    assert lab.shape == pages[0][0].shape
+    eng.close()
+
+
+def test_dp_gradient_buffer_is_torch_visible(gpu, oracle_mod):
+    """The flat gradient buffer can be wrapped zero-copy as a torch tensor (what the RCCL
+    all-reduce operates on) and scaled averaging equals two separate steps."""
+    import torch
+    arch, C = "fcn", 3
+    Wt = oracle_mod.init_weights(arch, C, seed=3, gain=1.5, bias_scale=0.05)
+    (i0, m0), (i1, m1) = _sample(0, 64, 64, C), _sample(1, 64, 64, C)
+    eng = gpu.Engine(arch, C, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    eng.train_init()
+    from pseg_amd.parallel import grad_tensor
+    eng.train_forward_backward(i0, m0)
+    g0 = grad_tensor(eng).clone()
+    eng.train_forward_backward(i1, m1)
+    gt = grad_tensor(eng)
+    assert gt.is_cuda and gt.dtype == torch.float32 and gt.numel() == eng.grad_buffer()[1]
+    gt += g0                                 # "all-reduce(sum)" of two ranks, in place on the engine's buffer
+    torch.cuda.synchronize()
+    eng.train_apply(1e-3, grad_scale=0.5)    # average
+    assert np.isfinite(eng.get_weights()["logits/kernel"]).all()
+    eng.close()
+
+
+def test_trainer_api_end_to_end(gpu, oracle_mod, tmp_path):
+    """Trainer / Network.train_dataset with the reference's settings object: loss goes down on a
+    tiny synthetic set, the progress callback fires, the best checkpoint is written and reloads."""
+    from pseg_amd import synth
+    from ocr4all_pixel_classifier.lib.trainer import Trainer, TrainSettings
+    from ocr4all_pixel_classifier.lib.dataset import Dataset, SingleData
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    from ocr4all_pixel_classifier.lib.callback import TrainProgressCallback
+    from ocr4all_pixel_classifier.lib.network import Network
+    from ocr4all_pixel_classifier.lib.metrics import Monitor
+    np.random.seed(0)
+    cm = ColorMap({})
+
+    def ds(seeds):
+        out = []
+        for s in seeds:
+            img, binary, mask = synth.synth_page(s, 96, 96, 3)
+            out.append(SingleData(image=img, binary=binary, mask=mask, original_shape=img.shape))
+        return Dataset(out, cm)
+
+    class CB(TrainProgressCallback):
+        def __init__(self):
+            self.total = None; self.losses = []; self.best = []
+        def init(self, total_iters, early_stopping_iters):
+            self.total = total_iters
+        def update_loss(self, batch, loss, acc):
+            self.losses.append((batch, loss, acc))
+        def next_best(self, epoch, acc, n_best):
+            self.best.append((epoch, acc, n_best))
+
+    settings = TrainSettings(n_epoch=6, n_classes=3, l_rate=2e-3, train_data=ds([0, 1, 2, 3]),
+                             validation_data=ds([4]), display=1, output_dir=str(tmp_path), threads=1,
+                             monitor=Monitor.VAL_LOSS, evaluation_data=ds([5]))
+    tr = Trainer(settings)
+    cb = CB()
+    hist = tr.train(cb)
+    assert cb.total == 24 and len(cb.losses) == 24 and [b for b, _, _ in cb.losses] == list(range(24))
+    assert len(cb.best) == 6 and len(hist["val_loss"]) == 6
+    assert np.mean(hist["loss"][-2:]) < hist["loss"][0]            # it learns
+    ev = tr.eval()
+    assert set(ev) == {"loss", "accuracy", "jacard_coef", "dice_coef"} and np.isfinite(ev["loss"])
+    assert (tmp_path / "model.npz").exists()
+    net = Network("Predict", n_classes=3, model=str(tmp_path / "model"), exact=True)
+    lab = net.predict_single_data(settings.validation_data.data[0])[2]
+    assert lab.shape == (96, 96)
+    with pytest.raises(Exception):                                   # augmentation is not built
+        next(tr.train_net.create_dataset_inputs(settings.train_data, data_augmentation=True))
+    x, y = next(tr.train_net.create_dataset_inputs(settings.train_data, data_augmentation=False))
+    assert x["input_1"].shape == (1, 96, 96, 1) and x["input_2"].shape == (1, 96, 96, 1) and y["logits"].shape == (1, 96, 96, 1)
+    assert x["input_1"].dtype == np.float64 and x["input_1"].max() <= 1.0

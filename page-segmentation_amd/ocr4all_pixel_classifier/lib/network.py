@@ -180,7 +180,7 @@ class Network:
         min_delta, restore best), ReduceLROnPlateau (factor, patience = drops / 2, min_lr) and the
         progress callback.  Batch of one page; with world > 1 every rank takes its own page per
         step and the gradients are averaged by one RCCL all-reduce (pseg_amd.parallel)."""
-        from pseg_amd.parallel import allreduce_gradients
+        from pseg_amd.parallel import dp_train_epoch, grad_tensor
         self._ensure_train_state()
         s = setting
         os.makedirs(s.output_dir, exist_ok=True)
@@ -198,20 +198,33 @@ class Network:
         it = 0
         for epoch in range(s.n_epoch):
             np.random.shuffle(train)                      # lib/network.py:134-135 (in place)
-            rows = []
-            for k in range(rank, n, world):
+            def fb(k):
                 d = train[k]
                 img = gray_to_rgb(d.image) if self._rgb else d.image
                 m = d.mask
                 if self.foreground_masks and d.binary is not None:
                     m[d.binary != 1] = 0
-                loss, acc, jac, dice = self.model.train_forward_backward(img, m)
-                allreduce_gradients(self.model, world)
-                self.model.train_apply(lr, 1.0 / world)
-                rows.append((loss, acc, jac, dice))
-                if callback:
-                    callback.update_loss(it, loss, acc)
+                return self.model.train_forward_backward(img, m)
+
+            def apply(scale):
+                nonlocal it
+                self.model.train_apply(lr, scale)
                 it += 1
+
+            if world == 1:
+                rows = []
+                for k in range(n):
+                    row = fb(k)
+                    self.model.train_apply(lr, 1.0)
+                    rows.append(row)
+                    if callback:
+                        callback.update_loss(it, row[0], row[1])
+                    it += 1
+            else:                                   # all ranks must share np.random's seed (same shuffle)
+                rows = dp_train_epoch(n, rank, world, fb, lambda: grad_tensor(self.model), apply)
+                if callback:
+                    for j, row in enumerate(rows):
+                        callback.update_loss(it - len(rows) + j, row[0], row[1])
             logs = dict(zip(("loss", "accuracy", "jacard_coef", "dice_coef"),
                             (float(v) for v in np.mean(np.asarray(rows, np.float64), axis=0))))
             if s.validation_data is not None and len(s.validation_data) > 0:

@@ -54,14 +54,45 @@ def grad_tensor(engine):
     return torch.as_tensor(_DevBuf(ptr, n), device="cuda:%d" % engine.device)
 
 
+def allreduce_flat(flat, world):
+    """Sum the flat gradient vector over the ranks in place (RCCL on device tensors, gloo on CPU
+    tensors in the tests).  The 1/world factor is applied by train_apply(grad_scale=1/world)."""
+    if world <= 1:
+        return flat
+    import torch
+    import torch.distributed as dist
+    if flat.is_cuda:                       # the engine writes / reads the buffer on its own stream
+        torch.cuda.synchronize(flat.device)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda:
+        torch.cuda.synchronize(flat.device)
+    return flat
+
+
 def allreduce_gradients(engine, world):
     """the only collective of the build -- one RCCL all-reduce(sum) of the flat fp32
     gradient (673 013 + metric slots for fcn_skip C=3, 2.7 MB) per train step."""
     if world <= 1:
         return
-    import torch
-    import torch.distributed as dist
-    g = grad_tensor(engine)
-    torch.cuda.synchronize(g.device)
-    dist.all_reduce(g, op=dist.ReduceOp.SUM)
-    torch.cuda.synchronize(g.device)
+    allreduce_flat(grad_tensor(engine), world)
+
+
+def dp_train_epoch(n_samples, rank, world, forward_backward, flat_gradient, apply):
+    """One data-parallel pass: rank r takes samples r, r+world, ... (ranks that run out repeat
+    their last sample with zero weight so that every rank enters every all-reduce), the flat
+    gradients are summed over the ranks and applied with scale 1/contributors."""
+    steps = (n_samples + world - 1) // world
+    rows = []
+    for st in range(steps):
+        k = st * world + rank
+        live = k < n_samples
+        m = forward_backward(k if live else n_samples - 1)
+        g = flat_gradient()
+        if not live:
+            g.zero_()
+        allreduce_flat(g, world)
+        contributors = min(world, n_samples - st * world)
+        apply(1.0 / contributors)
+        if live:
+            rows.append(m)
+    return rows

@@ -62,3 +62,80 @@ def test_two_rank_page_sharding_matches_single_process(oracle_mod):
     assert len(got) == len(want)
     for g, w_ in zip(got, want):
         assert np.array_equal(np.array(g), w_)
+
+
+# ---- data-parallel train step: sum of flat gradients over ranks, 1/world at apply -------
+
+def _train_pages():
+    from pseg_amd import synth
+    return [synth.synth_page(s, 32, 32, 3) for s in range(3)]          # 3 samples on 2 ranks: ragged tail
+
+
+def _flat(grads, order):
+    return np.concatenate([np.asarray(grads[k], np.float32).ravel() for k in order])
+
+
+def _dp_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "page-segmentation_amd")]
+    import torch
+    import oracle
+    from oracle import train_ref
+    from pseg_amd.parallel import dp_train_epoch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Wt = oracle.init_weights("fcn", 3, seed=2, gain=1.0, bias_scale=0.05)
+    order = list(Wt)
+    opt = train_ref.KerasAdam(lr=1e-3, clipnorm=1.0)
+    pages = _train_pages()
+    state = {}
+
+    def fb(k):
+        img, _, mask = pages[k]
+        loss, _, _, _, grads = train_ref.fcn_loss_and_grads("fcn", Wt, img, mask)
+        state["g"] = torch.from_numpy(_flat(grads, order).copy())
+        return loss
+
+    def apply(scale):
+        g = state["g"].numpy() * np.float32(scale)
+        off, grads = 0, {}
+        for k in order:
+            n = Wt[k].size
+            grads[k] = g[off:off + n].reshape(Wt[k].shape)
+            off += n
+        opt.apply(Wt, grads)
+
+    dp_train_epoch(len(pages), rank, world, fb, lambda: state["g"], apply)
+    dist.barrier()
+    q.put((rank, {k: v.tolist() for k, v in Wt.items()}))
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_train_matches_gradient_averaging(oracle_mod):
+    import oracle
+    from oracle import train_ref
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process: step 1 averages pages 0 and 1, step 2 takes page 2 alone
+    Wt = oracle.init_weights("fcn", 3, seed=2, gain=1.0, bias_scale=0.05)
+    opt = train_ref.KerasAdam(lr=1e-3, clipnorm=1.0)
+    pages = _train_pages()
+    for group in ([0, 1], [2]):
+        gs = [train_ref.fcn_loss_and_grads("fcn", Wt, pages[k][0], pages[k][2])[4] for k in group]
+        avg = {k: sum(np.asarray(g[k], np.float32) for g in gs) * np.float32(1.0 / len(group)) for k in Wt}
+        opt.apply(Wt, avg)
+    for r in (0, 1):                                   # replicas stay identical and match
+        for k in Wt:
+            np.testing.assert_allclose(np.array(got[r][k], np.float32), Wt[k], rtol=1e-5, atol=1e-7)
+    for k in Wt:
+        assert np.array_equal(np.array(got[0][k], np.float32), np.array(got[1][k], np.float32))

@@ -161,6 +161,43 @@ int pseg_masks_device(int device, const int64_t* d_pred, const uint8_t* d_binary
 int pseg_otsu_char_height(int device, const uint8_t* gray, int H, int W, int inverse,
                           int* height, int* otsu);
 
+/* ---- Line-height normalisation: lib/dataset.py:114-150, lib/util.py:21-29 ------------------ */
+
+/* Output shape of skimage.transform.rescale as scale_binary calls it (lib/dataset.py:115):
+ * np.round(scale * shape), half to even.  Host arithmetic only. */
+int pseg_rescale_shape(int H, int W, double scale, int* Ho, int* Wo);
+
+/* The anti-aliasing kernel scipy.ndimage.gaussian_filter builds for one axis: radius =
+ * int(4 sigma + 0.5), w[i] = exp(-i^2 / 2 sigma^2) / sum, 2*radius+1 entries.  Uses libm's exp; a
+ * caller that needs bit parity with a NumPy-based reference passes NumPy's kernel instead (the
+ * two exp implementations can differ in the last bit).  w may be NULL to query the radius. */
+int pseg_gaussian_kernel(double sigma, double* w, int cap, int* radius);
+
+/* preserving_resize (lib/util.py:21-29) / scale_binary's gather (lib/dataset.py:114-119): order-0
+ * warp of an (H,W) image of elem_bytes-sized pixels (1, 2, 3, 4 or 8) to (Ho,Wo).  Host pointers. */
+int pseg_resize_nearest(int device, const void* src, int H, int W, int elem_bytes, void* dst,
+                        int Ho, int Wo);
+
+/* scale_image (lib/dataset.py:122-128): bicubic resize of a uint8 or float64 (H,W) plane to a
+ * float64 (Ho,Wo) plane, clipped to the input range; Gaussian anti-aliasing (sigma = max(0,
+ * (in/out - 1)/2) per axis) iff the image has more than two distinct values.  wy / wx: the
+ * per-axis kernels with radii ry / rx (NULL: built with pseg_gaussian_kernel). */
+int pseg_scale_image(int device, const void* src, int src_is_f64, int H, int W, double* dst,
+                     int Ho, int Wo, const double* wy, int ry, const double* wx, int rx);
+
+/* prepare_images (lib/dataset.py:131-150), all pixel work on the device in one call.
+ * image, binary: uint8 (H0,W0) scan and binarisation (paper = 1 or 255).  (H1,W1) =
+ * pseg_rescale_shape(H0, W0, target_line_height / line_height_px); (H2,W2) = the max_width stage
+ * (pseg_rescale_shape(H1, W1, max_width / W1) when that factor is < 1), or 0,0 for none.
+ * Outputs: out_img uint8 network input (ink bright), out_bin uint8 ink = 1, both of the final
+ * shape; out_orig_bin (H0,W0) ink map (may be NULL); out_stage1 float64 (H1,W1) bicubic result
+ * before inversion (may be NULL; tests). */
+int pseg_prepare_images(int device, const uint8_t* image, const uint8_t* binary, int H0, int W0,
+                        int H1, int W1, const double* wy1, int ry1, const double* wx1, int rx1,
+                        int H2, int W2, const double* wy2, int ry2, const double* wx2, int rx2,
+                        uint8_t* out_img, uint8_t* out_bin, uint8_t* out_orig_bin,
+                        double* out_stage1);
+
 #ifdef __cplusplus
 }
 #endif

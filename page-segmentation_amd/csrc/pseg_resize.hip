@@ -1,0 +1,421 @@
+// pseg_resize.hip -- line-height normalisation on the GPU: the pixel work of
+// lib/dataset.py:114-150 (scale_binary, scale_image, prepare_images) and lib/util.py:21-29
+// (preserving_resize).  The reference delegates to scikit-image 0.17.2 (resize / rescale ->
+// scipy.ndimage.gaussian_filter -> warp); the kernels below restate that arithmetic in float64
+// with the same operation order (no FMA contraction: -ffp-contract=off), so results equal
+// oracle/resize.py bit for bit:
+//   * anti-aliasing: separable Gaussian, 'mirror' boundary, scipy's symmetric accumulation order
+//     (centre tap, then tap pairs from the outermost inwards); a uint8 image stays uint8 between
+//     the passes (truncating cast), as scipy keeps the input dtype;
+//   * warp: input coordinate = f*o + (f/2 - 0.5), f = in/out; order 0 rounds half away from zero,
+//     order 3 is a 4x4 Catmull-Rom around floor(coord) (columns first, then rows), 'reflect'
+//     index mapping, result clipped to the [min, max] of the (filtered) input.
+// All kernels are HBM-bound streaming / gather kernels: one thread per output pixel, consecutive
+// threads on consecutive x (coalesced rows); algorithmic bytes per pixel are in DESIGN.md.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "pseg_common.h"
+
+namespace pseg {
+
+static int rz_set_dev(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(PSEG_EHIP, "no HIP device available: the MI355X engine needs a GPU (no CPU fallback)");
+    if (device < 0 || device >= n) return fail(PSEG_EINVAL, "device %d out of range (%d visible)", device, n);
+    PSEG_HIP(hipSetDevice(device));
+    return PSEG_OK;
+}
+
+// periodic 'mirror' / skimage 'reflect' extension (no edge repeat): d c b | a b c d | c b a
+__device__ __forceinline__ int mirror_idx(int i, int n) {
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    return i >= n ? p - i : i;
+}
+
+template <typename T>
+__device__ __forceinline__ double ld(const T* p, size_t i) { return (double)p[i]; }
+
+// one pass of scipy.ndimage.correlate1d with a symmetric kernel, mode 'mirror'
+template <typename T, int AXIS>
+__global__ __launch_bounds__(256) void gauss_pass_kernel(const T* src, int H, int W, const double* w, int radius, T* dst) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int i = AXIS == 0 ? y : x, n = AXIS == 0 ? H : W;
+    const size_t row = (size_t)y * W;
+    double acc = ld(src, row + x) * w[radius];
+    for (int j = radius; j >= 1; --j) {
+        const int lo = mirror_idx(i - j, n), hi = mirror_idx(i + j, n);
+        const double a = AXIS == 0 ? ld(src, (size_t)lo * W + x) : ld(src, row + lo);
+        const double b = AXIS == 0 ? ld(src, (size_t)hi * W + x) : ld(src, row + hi);
+        acc = acc + (a + b) * w[radius - j];
+    }
+    dst[row + x] = (T)acc;   // uint8: C truncation, as scipy's line buffer copy
+}
+
+// order-preserving map double -> uint64 (for atomic min / max)
+__device__ __forceinline__ unsigned long long ord_enc(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+static inline double ord_dec(unsigned long long e) {
+    const unsigned long long u = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+}
+
+// stats[0] = min (encoded), stats[1] = max (encoded)
+template <typename T>
+__global__ __launch_bounds__(256) void minmax_kernel(const T* src, size_t n, unsigned long long* stats) {
+    unsigned long long mn = ~0ull, mx = 0ull;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned long long e = ord_enc((double)src[i]);
+        mn = e < mn ? e : mn;
+        mx = e > mx ? e : mx;
+    }
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        const unsigned long long a = __shfl_xor(mn, sh), b = __shfl_xor(mx, sh);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&stats[0], mn);
+        atomicMax(&stats[1], mx);
+    }
+}
+
+// stats[2] != 0  <=>  some value differs from both min and max  <=>  len(np.unique(img)) > 2
+template <typename T>
+__global__ __launch_bounds__(256) void third_value_kernel(const T* src, size_t n, unsigned long long* stats) {
+    const unsigned long long mn = stats[0], mx = stats[1];
+    bool any = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned long long e = ord_enc((double)src[i]);
+        any |= (e != mn) & (e != mx);
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&stats[2], 1ull);
+}
+
+__device__ __forceinline__ double cubic(double x, double f0, double f1, double f2, double f3) {
+    return f1 + 0.5 * x * (f2 - f0 + x * (2.0 * f0 - 5.0 * f1 + 4.0 * f2 - f3 + x * (3.0 * (f1 - f2) + f3 - f0)));
+}
+
+// order-3 warp, output float64 clipped to [lo, hi] (encoded in stats[0..1])
+template <typename T>
+__global__ __launch_bounds__(256) void bicubic_kernel(const T* src, int H, int W, double* dst, int Ho, int Wo,
+                                                      double fy, double ty, double fx, double tx,
+                                                      const unsigned long long* stats) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= Wo) return;
+    const double yr = fy * (double)oy + ty, xc = fx * (double)ox + tx;
+    const double r0f = floor(yr), c0f = floor(xc);
+    const double tr = yr - r0f, tc = xc - c0f;
+    const int r0 = (int)r0f - 1, c0 = (int)c0f - 1;
+    int cols[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cols[k] = mirror_idx(c0 + k, W);
+    double fr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t row = (size_t)mirror_idx(r0 + k, H) * W;
+        fr[k] = cubic(tc, ld(src, row + cols[0]), ld(src, row + cols[1]), ld(src, row + cols[2]), ld(src, row + cols[3]));
+    }
+    double v = cubic(tr, fr[0], fr[1], fr[2], fr[3]);
+    unsigned long long u0 = stats[0], u1 = stats[1];
+    u0 = (u0 >> 63) ? (u0 & 0x7fffffffffffffffull) : ~u0;
+    u1 = (u1 >> 63) ? (u1 & 0x7fffffffffffffffull) : ~u1;
+    const double lo = __longlong_as_double((long long)u0), hi = __longlong_as_double((long long)u1);
+    v = v < lo ? lo : (v > hi ? hi : v);     // np.clip
+    dst[(size_t)oy * Wo + ox] = v;
+}
+
+// order-0 warp = gather of whole pixels (EB bytes each)
+template <int EB>
+__global__ __launch_bounds__(256) void nearest_kernel(const uint8_t* src, int H, int W, uint8_t* dst, int Ho, int Wo,
+                                                      double fy, double ty, double fx, double tx) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+    if (ox >= Wo) return;
+    const double yr = fy * (double)oy + ty, xc = fx * (double)ox + tx;
+    const int r = mirror_idx((int)(yr > 0.0 ? yr + 0.5 : yr - 0.5), H);
+    const int c = mirror_idx((int)(xc > 0.0 ? xc + 0.5 : xc - 0.5), W);
+    const uint8_t* s = src + ((size_t)r * W + c) * EB;
+    uint8_t* d = dst + ((size_t)oy * Wo + ox) * EB;
+    if (EB == 1) *d = *s;
+    else if (EB == 2) *(uint16_t*)d = *(const uint16_t*)s;
+    else if (EB == 4) *(uint32_t*)d = *(const uint32_t*)s;
+    else if (EB == 8) *(uint64_t*)d = *(const uint64_t*)s;
+    else
+        for (int b = 0; b < EB; ++b) d[b] = s[b];
+}
+
+// elementwise steps of prepare_images (lib/dataset.py:135-146)
+//   MODE 0: uint8 binary -> ink map:  out = uint8(1.0 - (gt1 ? b / 255 : b))
+//   MODE 1: float64 v    -> float64:  out = 1.0 - v / 255
+//   MODE 2: float64 v    -> uint8:    out = uint8((1.0 - v / 255) * 255)
+//   MODE 3: float64 v    -> uint8:    out = uint8(v * 255)
+template <int MODE>
+__global__ __launch_bounds__(256) void prep_map_kernel(const void* src, void* dst, size_t n, const unsigned long long* stats) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (MODE == 0) {
+        unsigned long long u1 = stats[1];
+        u1 = (u1 >> 63) ? (u1 & 0x7fffffffffffffffull) : ~u1;
+        const bool gt1 = __longlong_as_double((long long)u1) > 1.0;
+        const double b = (double)((const uint8_t*)src)[i];
+        ((uint8_t*)dst)[i] = (uint8_t)(1.0 - (gt1 ? b / 255.0 : b));
+    } else if (MODE == 1) {
+        ((double*)dst)[i] = 1.0 - ((const double*)src)[i] / 255.0;
+    } else if (MODE == 2) {
+        ((uint8_t*)dst)[i] = (uint8_t)((1.0 - ((const double*)src)[i] / 255.0) * 255.0);
+    } else {
+        ((uint8_t*)dst)[i] = (uint8_t)(((const double*)src)[i] * 255.0);
+    }
+}
+
+static void warp_coeffs(int n_in, int n_out, double* f, double* t) {
+    *f = (double)n_in / (double)n_out;
+    *t = *f * 0.5 - 0.5;
+}
+
+static std::vector<double> host_gauss(double sigma, int* radius) {
+    const int r = (int)(4.0 * sigma + 0.5);
+    std::vector<double> w(2 * r + 1);
+    double s = 0.0;
+    for (int i = -r; i <= r; ++i) s += (w[i + r] = std::exp(-0.5 / (sigma * sigma) * (double)(i * i)));
+    for (auto& v : w) v /= s;
+    *radius = r;
+    return w;   // symmetric: the [::-1] of scipy is the identity
+}
+
+struct DevMem {
+    std::vector<void*> ptrs;
+    ~DevMem() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    int alloc(T** p, size_t count) {
+        *p = nullptr;
+        PSEG_HIP(hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+        ptrs.push_back(*p);
+        return PSEG_OK;
+    }
+};
+
+static int stats_reset(unsigned long long* d_stats, hipStream_t st) {
+    const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+    PSEG_HIP(hipMemcpyAsync(d_stats, init, sizeof(init), hipMemcpyHostToDevice, st));
+    return PSEG_OK;
+}
+
+template <typename T>
+static int compute_stats(const T* d, size_t n, unsigned long long* d_stats, bool third, hipStream_t st) {
+    PSEG_TRY(stats_reset(d_stats, st));
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    minmax_kernel<T><<<grid, 256, 0, st>>>(d, n, d_stats);
+    if (third) third_value_kernel<T><<<grid, 256, 0, st>>>(d, n, d_stats);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+// scale_image on device planes.  d_src: T plane (H, W); d_out: float64 (Ho, Wo).  wy / wx: host
+// kernels (NULL: built here with libm exp); scratch planes are allocated from `mem`.
+template <typename T>
+static int scale_image_dev(DevMem& mem, const T* d_src, int H, int W, double* d_out, int Ho, int Wo,
+                           const double* wy, int ry, const double* wx, int rx, unsigned long long* d_stats,
+                           hipStream_t st) {
+    const size_t n = (size_t)H * W;
+    PSEG_TRY(compute_stats<T>(d_src, n, d_stats, true, st));
+    unsigned long long hs[3];
+    PSEG_HIP(hipMemcpyAsync(hs, d_stats, sizeof(hs), hipMemcpyDeviceToHost, st));
+    PSEG_HIP(hipStreamSynchronize(st));
+    const bool aa = hs[2] != 0;
+    const T* cur = d_src;
+    if (aa) {
+        const double sig[2] = {std::max(0.0, ((double)H / (double)Ho - 1.0) / 2.0),
+                               std::max(0.0, ((double)W / (double)Wo - 1.0) / 2.0)};
+        const double* hw[2] = {wy, wx};
+        int hr[2] = {ry, rx};
+        for (int axis = 0; axis < 2; ++axis) {
+            if (sig[axis] <= 1e-15) continue;
+            std::vector<double> own;
+            if (!hw[axis]) { own = host_gauss(sig[axis], &hr[axis]); hw[axis] = own.data(); }
+            if (hr[axis] != (int)(4.0 * sig[axis] + 0.5))
+                return fail(PSEG_EINVAL, "anti-aliasing kernel radius %d does not match sigma %.17g", hr[axis], sig[axis]);
+            double* d_w = nullptr;
+            T* d_tmp = nullptr;
+            PSEG_TRY(mem.alloc(&d_w, (size_t)2 * hr[axis] + 1));
+            PSEG_TRY(mem.alloc(&d_tmp, n));
+            PSEG_HIP(hipMemcpyAsync(d_w, hw[axis], ((size_t)2 * hr[axis] + 1) * 8, hipMemcpyHostToDevice, st));
+            PSEG_HIP(hipStreamSynchronize(st));   // `own` may go out of scope
+            const dim3 grid(cdiv(W, 256), H);
+            if (axis == 0) gauss_pass_kernel<T, 0><<<grid, 256, 0, st>>>(cur, H, W, d_w, hr[axis], d_tmp);
+            else gauss_pass_kernel<T, 1><<<grid, 256, 0, st>>>(cur, H, W, d_w, hr[axis], d_tmp);
+            PSEG_HIP(hipGetLastError());
+            cur = d_tmp;
+        }
+        if (cur != d_src) PSEG_TRY(compute_stats<T>(cur, n, d_stats, false, st));   // clip range of the filtered image
+    }
+    double fy, ty, fx, tx;
+    warp_coeffs(H, Ho, &fy, &ty);
+    warp_coeffs(W, Wo, &fx, &tx);
+    bicubic_kernel<T><<<dim3(cdiv(Wo, 256), Ho), 256, 0, st>>>(cur, H, W, d_out, Ho, Wo, fy, ty, fx, tx, d_stats);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+static int nearest_dev(const void* d_src, int H, int W, int eb, void* d_dst, int Ho, int Wo, hipStream_t st) {
+    double fy, ty, fx, tx;
+    warp_coeffs(H, Ho, &fy, &ty);
+    warp_coeffs(W, Wo, &fx, &tx);
+    const dim3 grid(cdiv(Wo, 256), Ho);
+    const uint8_t* s = (const uint8_t*)d_src;
+    uint8_t* d = (uint8_t*)d_dst;
+    switch (eb) {
+        case 1: nearest_kernel<1><<<grid, 256, 0, st>>>(s, H, W, d, Ho, Wo, fy, ty, fx, tx); break;
+        case 2: nearest_kernel<2><<<grid, 256, 0, st>>>(s, H, W, d, Ho, Wo, fy, ty, fx, tx); break;
+        case 4: nearest_kernel<4><<<grid, 256, 0, st>>>(s, H, W, d, Ho, Wo, fy, ty, fx, tx); break;
+        case 8: nearest_kernel<8><<<grid, 256, 0, st>>>(s, H, W, d, Ho, Wo, fy, ty, fx, tx); break;
+        case 3: nearest_kernel<3><<<grid, 256, 0, st>>>(s, H, W, d, Ho, Wo, fy, ty, fx, tx); break;
+        default: return fail(PSEG_EUNSUPPORTED, "element size %d (supported: 1, 2, 3, 4, 8 bytes)", eb);
+    }
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+static int check_shape(int H, int W, int Ho, int Wo) {
+    if (H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return fail(PSEG_EINVAL, "empty image or target shape (%d,%d)->(%d,%d)", H, W, Ho, Wo);
+    if ((int64_t)H * W > 0x7fffffffLL || (int64_t)Ho * Wo > 0x7fffffffLL) return fail(PSEG_EUNSUPPORTED, "image too large");
+    return PSEG_OK;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+extern "C" {
+
+int pseg_rescale_shape(int H, int W, double scale, int* Ho, int* Wo) {
+    if (!Ho || !Wo) return fail(PSEG_EINVAL, "NULL argument");
+    // np.round: half to even (nearbyint in the default rounding mode)
+    *Ho = (int)std::nearbyint(scale * (double)H);
+    *Wo = (int)std::nearbyint(scale * (double)W);
+    return PSEG_OK;
+}
+
+int pseg_gaussian_kernel(double sigma, double* w, int cap, int* radius) {
+    if (!radius || !(sigma > 0.0)) return fail(PSEG_EINVAL, "bad argument");
+    int r = 0;
+    const std::vector<double> k = host_gauss(sigma, &r);
+    *radius = r;
+    if (w) {
+        if (cap < 2 * r + 1) return fail(PSEG_EINVAL, "kernel needs %d entries, capacity %d", 2 * r + 1, cap);
+        memcpy(w, k.data(), k.size() * 8);
+    }
+    return PSEG_OK;
+}
+
+int pseg_resize_nearest(int device, const void* src, int H, int W, int elem_bytes, void* dst, int Ho, int Wo) {
+    if (!src || !dst) return fail(PSEG_EINVAL, "NULL argument");
+    PSEG_TRY(check_shape(H, W, Ho, Wo));
+    PSEG_TRY(rz_set_dev(device));
+    DevMem mem;
+    uint8_t *d_s = nullptr, *d_d = nullptr;
+    const size_t ns = (size_t)H * W * elem_bytes, nd = (size_t)Ho * Wo * elem_bytes;
+    PSEG_TRY(mem.alloc(&d_s, ns));
+    PSEG_TRY(mem.alloc(&d_d, nd));
+    PSEG_HIP(hipMemcpy(d_s, src, ns, hipMemcpyHostToDevice));
+    PSEG_TRY(nearest_dev(d_s, H, W, elem_bytes, d_d, Ho, Wo, nullptr));
+    PSEG_HIP(hipMemcpy(dst, d_d, nd, hipMemcpyDeviceToHost));
+    return PSEG_OK;
+}
+
+int pseg_scale_image(int device, const void* src, int src_is_f64, int H, int W, double* dst, int Ho, int Wo,
+                     const double* wy, int ry, const double* wx, int rx) {
+    if (!src || !dst) return fail(PSEG_EINVAL, "NULL argument");
+    PSEG_TRY(check_shape(H, W, Ho, Wo));
+    PSEG_TRY(rz_set_dev(device));
+    DevMem mem;
+    const size_t n = (size_t)H * W, no = (size_t)Ho * Wo;
+    unsigned long long* d_stats = nullptr;
+    double* d_out = nullptr;
+    PSEG_TRY(mem.alloc(&d_stats, 4));
+    PSEG_TRY(mem.alloc(&d_out, no));
+    if (src_is_f64) {
+        double* d_s = nullptr;
+        PSEG_TRY(mem.alloc(&d_s, n));
+        PSEG_HIP(hipMemcpy(d_s, src, n * 8, hipMemcpyHostToDevice));
+        PSEG_TRY(scale_image_dev<double>(mem, d_s, H, W, d_out, Ho, Wo, wy, ry, wx, rx, d_stats, nullptr));
+    } else {
+        uint8_t* d_s = nullptr;
+        PSEG_TRY(mem.alloc(&d_s, n));
+        PSEG_HIP(hipMemcpy(d_s, src, n, hipMemcpyHostToDevice));
+        PSEG_TRY(scale_image_dev<uint8_t>(mem, d_s, H, W, d_out, Ho, Wo, wy, ry, wx, rx, d_stats, nullptr));
+    }
+    PSEG_HIP(hipMemcpy(dst, d_out, no * 8, hipMemcpyDeviceToHost));
+    return PSEG_OK;
+}
+
+int pseg_prepare_images(int device, const uint8_t* image, const uint8_t* binary, int H0, int W0, int H1, int W1,
+                        const double* wy1, int ry1, const double* wx1, int rx1, int H2, int W2,
+                        const double* wy2, int ry2, const double* wx2, int rx2, uint8_t* out_img,
+                        uint8_t* out_bin, uint8_t* out_orig_bin, double* out_stage1) {
+    if (!image || !binary || !out_img || !out_bin) return fail(PSEG_EINVAL, "NULL argument");
+    PSEG_TRY(check_shape(H0, W0, H1, W1));
+    const bool two = H2 > 0 && W2 > 0;
+    if (two) PSEG_TRY(check_shape(H1, W1, H2, W2));
+    PSEG_TRY(rz_set_dev(device));
+    DevMem mem;
+    hipStream_t st = nullptr;
+    const size_t n0 = (size_t)H0 * W0, n1 = (size_t)H1 * W1, n2 = two ? (size_t)H2 * W2 : 0;
+    uint8_t *d_img = nullptr, *d_bin = nullptr, *d_ink0 = nullptr, *d_ink1 = nullptr, *d_o8 = nullptr;
+    double* d_s1 = nullptr;
+    unsigned long long* d_stats = nullptr;
+    PSEG_TRY(mem.alloc(&d_img, n0));
+    PSEG_TRY(mem.alloc(&d_bin, n0));
+    PSEG_TRY(mem.alloc(&d_ink0, n0));
+    PSEG_TRY(mem.alloc(&d_ink1, n1));
+    PSEG_TRY(mem.alloc(&d_s1, n1));
+    PSEG_TRY(mem.alloc(&d_o8, two ? n2 : n1));
+    PSEG_TRY(mem.alloc(&d_stats, 4));
+    PSEG_HIP(hipMemcpyAsync(d_img, image, n0, hipMemcpyHostToDevice, st));
+    PSEG_HIP(hipMemcpyAsync(d_bin, binary, n0, hipMemcpyHostToDevice, st));
+    // binary: orig_bin = b/255 if max > 1 else b; ink = uint8(1 - orig_bin); bin = 1 - nearest(orig_bin)
+    // (the gather commutes with the per-pixel map, so the ink map is gathered)
+    PSEG_TRY(compute_stats<uint8_t>(d_bin, n0, d_stats, false, st));
+    prep_map_kernel<0><<<(unsigned)((n0 + 255) / 256), 256, 0, st>>>(d_bin, d_ink0, n0, d_stats);
+    PSEG_HIP(hipGetLastError());
+    PSEG_TRY(nearest_dev(d_ink0, H0, W0, 1, d_ink1, H1, W1, st));
+    // image: stage 1 on the uint8 scan
+    PSEG_TRY(scale_image_dev<uint8_t>(mem, d_img, H0, W0, d_s1, H1, W1, wy1, ry1, wx1, rx1, d_stats, st));
+    if (out_stage1) PSEG_HIP(hipMemcpyAsync(out_stage1, d_s1, n1 * 8, hipMemcpyDeviceToHost, st));
+    if (!two) {
+        prep_map_kernel<2><<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_s1, d_o8, n1, d_stats);
+        PSEG_HIP(hipGetLastError());
+        PSEG_HIP(hipMemcpyAsync(out_img, d_o8, n1, hipMemcpyDeviceToHost, st));
+        PSEG_HIP(hipMemcpyAsync(out_bin, d_ink1, n1, hipMemcpyDeviceToHost, st));
+    } else {
+        double *d_f1 = nullptr, *d_s2 = nullptr;
+        uint8_t* d_ink2 = nullptr;
+        PSEG_TRY(mem.alloc(&d_f1, n1));
+        PSEG_TRY(mem.alloc(&d_s2, n2));
+        PSEG_TRY(mem.alloc(&d_ink2, n2));
+        prep_map_kernel<1><<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(d_s1, d_f1, n1, d_stats);
+        PSEG_HIP(hipGetLastError());
+        PSEG_TRY(scale_image_dev<double>(mem, d_f1, H1, W1, d_s2, H2, W2, wy2, ry2, wx2, rx2, d_stats, st));
+        prep_map_kernel<3><<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>(d_s2, d_o8, n2, d_stats);
+        PSEG_HIP(hipGetLastError());
+        PSEG_TRY(nearest_dev(d_ink1, H1, W1, 1, d_ink2, H2, W2, st));
+        PSEG_HIP(hipMemcpyAsync(out_img, d_o8, n2, hipMemcpyDeviceToHost, st));
+        PSEG_HIP(hipMemcpyAsync(out_bin, d_ink2, n2, hipMemcpyDeviceToHost, st));
+    }
+    if (out_orig_bin) PSEG_HIP(hipMemcpyAsync(out_orig_bin, d_ink0, n0, hipMemcpyDeviceToHost, st));
+    PSEG_HIP(hipStreamSynchronize(st));
+    return PSEG_OK;
+}
+
+}  // extern "C"

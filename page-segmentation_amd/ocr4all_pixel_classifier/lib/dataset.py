@@ -41,48 +41,32 @@ class Dataset:
         return iter(self.data)
 
 
-def _nearest_rescale(a, scale):
-    """scale_binary (lib/dataset.py:114-119): skimage rescale(order=0): output shape =
-    round(shape * scale), nearest gather."""
-    from .util import preserving_resize
-    H, W = a.shape[:2]
-    out = (int(np.round(H * scale)), int(np.round(W * scale)))
-    return preserving_resize(a, out)
-
-
 def scale_binary(binary, scale):
-    return _nearest_rescale(np.asarray(binary), scale)
+    """lib/dataset.py:114-119: skimage rescale(order=0, no anti-aliasing): output shape =
+    np.round(shape * scale), nearest gather on the GPU; float64 result."""
+    from pseg_amd import engine as _eng
+    from .util import preserving_resize
+    binary = np.asarray(binary)
+    return preserving_resize(binary, _eng.rescale_shape(binary.shape, scale))
 
 
 def scale_image(img, target_shape):
-    """lib/dataset.py:122-128: bicubic resize with Gaussian anti-aliasing when the image has more
-    than two distinct values.  The bicubic / Gaussian GPU kernels are a later SURVEY 8(f) row;
-    until they land this raises instead of silently computing on the CPU."""
-    img = np.asarray(img)
-    if tuple(img.shape[:2]) == tuple(target_shape):
-        return img.astype(np.float64)
-    raise Exception("line-height rescaling (bicubic + Gaussian anti-aliasing) is not built yet in the "
-                    "MI355X engine: pass pages already normalised to the target line height "
-                    "(line_height_px == target_line_height)")
+    """lib/dataset.py:122-128: bicubic resize, Gaussian anti-aliasing when the image has more
+    than two distinct values (GPU: pseg_scale_image); float64 result."""
+    from pseg_amd import engine as _eng
+    return _eng.scale_image(np.asarray(img), target_shape)
 
 
 def prepare_images(image, binary, target_line_height, line_height_px, max_width=None, keep_orig_bin=False):
     """lib/dataset.py:131-150.  image: gray uint8 scan (ink dark); binary: 0/255 or 0/1 with
-    paper = 1 (ink = 0).  Returns the inverted network input (ink bright), ink = 1 binary."""
+    paper = 1 (ink = 0).  Returns the inverted network input (ink bright), ink = 1 binary.  One
+    GPU call (pseg_prepare_images) does the whole chain: nearest rescale of the binary, Gaussian
+    anti-aliasing + bicubic resize of the image, optional max_width stage, inversion, uint8."""
+    from pseg_amd import engine as _eng
     scale = target_line_height / line_height_px
-    binary = np.asarray(binary)
-    orig_bin = binary / 255 if np.max(binary) > 1 else binary
-    bin_ = 1.0 - scale_binary(orig_bin, scale)
-    img = 1.0 - scale_image(image, bin_.shape) / 255
-    if max_width is not None:
-        n_scale = max_width / bin_.shape[1]
-        if n_scale < 1.0:
-            bin_ = scale_binary(bin_, n_scale)
-            img = scale_image(img, bin_.shape)
-    img = (img * 255).astype(np.uint8)
-    bin_ = bin_.astype(np.uint8)
+    img, bin_, orig = _eng.prepare_images(image, binary, scale, max_width)
     if keep_orig_bin:
-        return img, bin_, (1 - orig_bin).astype(np.uint8)
+        return img, bin_, orig
     return img, bin_
 
 

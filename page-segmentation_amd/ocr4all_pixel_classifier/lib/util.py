@@ -18,10 +18,10 @@ def image_to_batch(img):
 
 def preserving_resize(image, target_shape):
     """lib/util.py:21-29: nearest-neighbour resize that keeps values (order 0, no anti-aliasing,
-    preserve_range).  Index arithmetic only (a gather), float64 result like scikit-image's."""
+    preserve_range); float64 result like scikit-image's.  The gather runs on the GPU
+    (pseg_resize_nearest); only the dtype widening happens here."""
+    from pseg_amd import engine as _eng
     image = np.asarray(image)
-    H, W = image.shape[:2]
-    Ho, Wo = int(target_shape[0]), int(target_shape[1])
-    r = np.floor((np.arange(Ho) + 0.5) * (H / Ho)).astype(np.int64).clip(0, H - 1)
-    c = np.floor((np.arange(Wo) + 0.5) * (W / Wo)).astype(np.int64).clip(0, W - 1)
-    return image[r][:, c].astype(np.float64)
+    if image.dtype.itemsize * int(np.prod(image.shape[2:], dtype=np.int64)) not in (1, 2, 3, 4, 8):
+        image = image.astype(np.float64)
+    return _eng.resize_nearest(image, target_shape).astype(np.float64)

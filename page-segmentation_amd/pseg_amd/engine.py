@@ -21,6 +21,8 @@ EXPORTED_SYMBOLS = (
     "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
     "pseg_cc_vote", "pseg_cc_vote_device", "pseg_bbox_fill", "pseg_masks", "pseg_masks_device",
     "pseg_otsu_char_height",
+    "pseg_rescale_shape", "pseg_gaussian_kernel", "pseg_resize_nearest", "pseg_scale_image",
+    "pseg_prepare_images",
 )
 
 
@@ -73,6 +75,12 @@ def lib():
     L.pseg_train_get_gradient.argtypes = [vp, c.c_char_p, vp, i64]
     L.pseg_eval_step.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
     L.pseg_cc_vote.argtypes = [i, vp, vp, i, i, i]
+    d = c.c_double
+    L.pseg_rescale_shape.argtypes = [i, i, d, c.POINTER(i), c.POINTER(i)]
+    L.pseg_gaussian_kernel.argtypes = [d, vp, i, c.POINTER(i)]
+    L.pseg_resize_nearest.argtypes = [i, vp, i, i, i, vp, i, i]
+    L.pseg_scale_image.argtypes = [i, vp, i, i, i, vp, i, i, vp, i, vp, i]
+    L.pseg_prepare_images.argtypes = [i, vp, vp, i, i, i, i, vp, i, vp, i, i, i, vp, i, vp, i, vp, vp, vp, vp]
     L.pseg_cc_vote_device.argtypes = [i, vp, vp, i, i, i, vp]
     L.pseg_bbox_fill.argtypes = [i, vp, vp, i, i, i]
     L.pseg_masks.argtypes = [i, vp, vp, vp, i, i, i, vp, vp, vp, vp]
@@ -290,3 +298,85 @@ def otsu_char_height(gray, inverse=False, device=0):
     _check(lib().pseg_otsu_char_height(int(device), _ptr(g), H, W, int(bool(inverse)),
                                        ctypes.byref(h), ctypes.byref(t)))
     return (None if h.value < 0 else h.value), t.value
+
+
+# ---- line-height normalisation (lib/dataset.py:114-150, lib/util.py:21-29) --------------------------
+
+def rescale_shape(shape, scale):
+    """np.round(scale * shape) of skimage.transform.rescale (half to even)."""
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    _check(lib().pseg_rescale_shape(int(shape[0]), int(shape[1]), float(scale), ctypes.byref(ho), ctypes.byref(wo)))
+    return ho.value, wo.value
+
+
+def aa_kernels(in_shape, out_shape):
+    """The per-axis anti-aliasing kernels exactly as scipy.ndimage.gaussian_filter builds them with
+    this process's NumPy (host set-up arithmetic: a dozen numbers per axis).  -> [(w or None, radius)] x 2."""
+    out = []
+    for n_in, n_out in zip(in_shape[:2], out_shape[:2]):
+        sigma = max(0.0, (float(n_in) / float(n_out) - 1) / 2)
+        if sigma <= 1e-15:
+            out.append((None, 0))
+            continue
+        radius = int(4.0 * sigma + 0.5)
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+        out.append((np.ascontiguousarray((phi / phi.sum())[::-1], dtype=np.float64), radius))
+    return out
+
+
+def _kptr(k):
+    return _ptr(k[0]) if k[0] is not None else None
+
+
+def resize_nearest(image, out_shape, device=0):
+    """Order-0 resize that keeps values and dtype (gather on the GPU); (H,W) or (H,W,C) arrays."""
+    a = np.ascontiguousarray(image)
+    H, W = a.shape[:2]
+    Ho, Wo = int(out_shape[0]), int(out_shape[1])
+    eb = a.itemsize * int(np.prod(a.shape[2:], dtype=np.int64))
+    if a.dtype == np.bool_:
+        a = a.view(np.uint8)
+    out = np.empty((Ho, Wo) + a.shape[2:], a.dtype)
+    _check(lib().pseg_resize_nearest(int(device), _ptr(a), H, W, eb, _ptr(out), Ho, Wo))
+    return out
+
+
+def scale_image(image, out_shape, device=0):
+    """scale_image (lib/dataset.py:122-128) -> float64 (Ho,Wo)."""
+    a = np.asarray(image)
+    f64 = a.dtype != np.uint8
+    a = np.ascontiguousarray(a, dtype=np.float64 if f64 else np.uint8)
+    H, W = a.shape
+    Ho, Wo = int(out_shape[0]), int(out_shape[1])
+    ky, kx = aa_kernels((H, W), (Ho, Wo))
+    out = np.empty((Ho, Wo), np.float64)
+    _check(lib().pseg_scale_image(int(device), _ptr(a), int(f64), H, W, _ptr(out), Ho, Wo,
+                                  _kptr(ky), ky[1], _kptr(kx), kx[1]))
+    return out
+
+
+def prepare_images(image, binary, scale, max_width=None, device=0, want_stage1=False):
+    """prepare_images (lib/dataset.py:131-150) -> (img uint8, bin uint8, orig_bin uint8[, stage1])."""
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    b = np.ascontiguousarray(binary, dtype=np.uint8)
+    if img.ndim != 2 or img.shape != b.shape:
+        raise PsegError("image and binary must be 2-D arrays of one shape, got %s and %s" % (img.shape, b.shape))
+    H0, W0 = img.shape
+    H1, W1 = rescale_shape((H0, W0), scale)
+    H2 = W2 = 0
+    if max_width is not None:
+        n_scale = max_width / W1
+        if n_scale < 1.0:
+            H2, W2 = rescale_shape((H1, W1), n_scale)
+    k1 = aa_kernels((H0, W0), (H1, W1))
+    k2 = aa_kernels((H1, W1), (H2, W2)) if H2 else [(None, 0), (None, 0)]
+    Hf, Wf = (H2, W2) if H2 else (H1, W1)
+    o_img, o_bin = np.empty((Hf, Wf), np.uint8), np.empty((Hf, Wf), np.uint8)
+    o_orig = np.empty((H0, W0), np.uint8)
+    st1 = np.empty((H1, W1), np.float64) if want_stage1 else None
+    _check(lib().pseg_prepare_images(int(device), _ptr(img), _ptr(b), H0, W0, H1, W1,
+                                     _kptr(k1[0]), k1[0][1], _kptr(k1[1]), k1[1][1], H2, W2,
+                                     _kptr(k2[0]), k2[0][1], _kptr(k2[1]), k2[1][1],
+                                     _ptr(o_img), _ptr(o_bin), _ptr(o_orig), _ptr(st1) if st1 is not None else None))
+    return (o_img, o_bin, o_orig, st1) if want_stage1 else (o_img, o_bin, o_orig)

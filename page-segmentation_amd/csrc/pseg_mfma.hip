@@ -165,10 +165,14 @@ enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16, FL_FUSE1
 #define PSEG_DIAG 0   // 1: compile the in-kernel trace stamps / ablation switches (diagnostic builds)
 #endif
 
-template <int MT, int NT, int KS_, int ST_, int SG_, int MODE_, int FL_>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_mfma_kernel(MConv a) {
+// NW_ = waves per workgroup: 4 (two workgroups per CU) or 8 (one workgroup per CU owning all 160 KiB
+// of LDS: a 16-row tile shares one weight stream among twice the pixels -- the mid layers are
+// bound by LDS-DMA bytes per CU).
+template <int MT, int NT, int KS_, int ST_, int SG_, int MODE_, int FL_, int NW_ = 4>
+__global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) void conv_mfma_kernel(MConv a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TH = 2 * MT;  // 4 waves x (MT/2) rows
+    constexpr int NW = NW_, NTHR = NW_ * 64;
+    constexpr int TH = NW * (MT / 2);  // NW waves x (MT/2) rows
     constexpr bool FIXED = KS_ > 0;
     const int c_stride = FIXED ? ST_ : a.stride;
     const int c_sigma = FIXED ? SG_ : a.sigma;
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     set_tile(blockIdx.x);
     const int WBUF = a.GK * NT * 1024;
 
-#define PSEG_STAMP(i) if (c_trace && tid == 0) c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#define PSEG_STAMP(i) if (c_trace && tid == 0) c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + (i)] = __builtin_amdgcn_s_memtime();
     PSEG_STAMP(0)
 
     int pixbase[MT];
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     // ---- weight ring: group q (GK k-steps x NT tiles, zero-padded to full groups on the host)
     // goes to ring slot q % NB by LDS-DMA; every wave issues exactly L = GK*NT/4 loads per group,
     // which is what the counted vmcnt waits below rely on.
-    const int L = a.GK * NT / 4;
+    const int L = (a.GK * NT - wave + NW - 1) / NW;   // pieces wave, wave + NW, ... of a group (wave-uniform)
     const int G = a.G;
     // packed weights are laid out [group][N block][piece][lane][8]: one group of one N block is
     // a contiguous run of GK*NT KiB in exactly the order of its LDS ring slot, so the DMA source
@@ -243,8 +247,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         const uint16_t* src = wsrc + (size_t)q * wgstride;
         char* dstb = w_t + slot * WBUF + wave * 1024;
         for (int j = 0; j < L; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * 2048),
-                                             (__attribute__((address_space(3))) void*)(dstb + j * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)j * (NW * 512)),
+                                             (__attribute__((address_space(3))) void*)(dstb + j * (NW * 1024)), 16, 0, 0);
     };
     // fused tail: the skip-tensor fragments of this lane are requested now, before stage 1; the
     // barriers of the k-loop keep them above it, so their latency hides under the deconv GEMM.
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     int gq = 0;  // global group index
+    long long acc_wait = 0, acc_issue = 0;   // PSEG_DIAG: cycles of wave 0 in group waits / weight-DMA issue
     for (int b = 0; b < a.nblk; ++b) {
         const bool last = (b == a.nblk - 1);
         const int nc = last ? a.nc_last : a.nc_full;
@@ -294,12 +299,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         if (b > 0) lds_barrier();  // every wave is done reading the previous block's tile / table
         // k-chunk offset table of this block: fetched now, written to LDS after the tile DMAs
         // have been issued (the fetch latency hides under the DMA issue)
-        int tabv[4];
+        constexpr int TU = MAX_TAB / NTHR;
+        int tabv[TU];
         {
             const int* tg = last ? a.tab_last : a.tab_full;
             if (first_tile)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = tid + u * 256; tabv[u] = i < ks * 4 ? tg[i] : 0; }
+                for (int u = 0; u < TU; ++u) { const int i = tid + u * NTHR; tabv[u] = i < ks * 4 ? tg[i] : 0; }
         }
         if (b == 0) { PSEG_STAMP(2) }
         // ---- stage the input halo tile of this channel block (zero outside the image) -------
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             // (as conv1_mfma_kernel); the 16x16 result tile has the pixel on the lane and 4 couts
             // in registers = 8 bytes of the [row][pixel][chunk] tile conv2 reads.  Halo pixels
             // outside the canvas are conv2's SAME padding: zeros, not conv1(0).
+            static_assert(!c_fuse1 || NW == 4, "the fused first layer is written for four waves");
             constexpr int HR = TH + 4, HC = TW + 4;          // halo tile of conv2 (k5, stride 1)
             constexpr int UR = HR + 4, UCB = 96;             // uint8 tile rows; bytes per copy row (48 px)
             char* f1 = smem + a.lds_f1_off;                  // [2 copies][UR][48] bf16
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                                      : (unsigned)((ix >> c_up0) * a.nch0 + gc) * 16u);
                 kind[j] = sl >= row_slots ? -1 : (is1 ? 1 : 0);
             }
-            for (int py = wave; py < c_THH; py += 4) {
+            for (int py = wave; py < c_THH; py += NW) {
                 const int iy = iy0 + py;
                 const bool rowv = (iy >= 0 && iy < a.Hin);
                 const unsigned rb0 = rowv ? (unsigned)(iy >> c_up0) * (unsigned)W0 * (unsigned)(a.nch0 * 16) : OOB;
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         } else if (!(c_dbg & 1) && nbi == 0) {
             const int row_items = c_TWH * nc;
             const int J = (row_items + 63) >> 6;          // loads per lane per row
-            const int rows_w = (c_THH - wave + 3) >> 2;   // rows of this wave
+            const int rows_w = (c_THH - wave + NW - 1) / NW;   // rows of this wave
             const int total = rows_w * J;
             const unsigned inv = 65536u / (unsigned)nc + 1u;
             for (int e0 = 0; e0 < total; e0 += STAGE_SLOTS) {
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                     dsto[u] = -1;
                     if (e < total) {
                         const int r = e / J, j = e - r * J;
-                        const int py = wave + 4 * r;
+                        const int py = wave + NW * r;
                         const int iy = iy0 + py;
                         const int i = j * 64 + lane;
                         if (i < row_items) {
@@ -481,17 +488,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
         if (first_tile)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = tid + u * 256; if (i < ks * 4) tab_l[i] = tabv[u]; }
+        for (int u = 0; u < TU; ++u) { const int i = tid + u * NTHR; if (i < ks * 4) tab_l[i] = tabv[u]; }
         if (b == 0) { PSEG_STAMP(3) }
 
         const int groups_b = (ks + a.GK - 1) / a.GK;
         for (int lg = 0; lg < groups_b; ++lg, ++gq) {
             // group gq has landed once at most the loads of the younger groups are pending
             const int younger = min(D - 1, G - 1 - gq);
+            long long tw0 = 0;
+            if (c_trace) tw0 = __builtin_amdgcn_s_memtime();
             wait_vmcnt_le(((c_dbg & 8) || lg == 0) ? 0 : L * (younger > 0 ? younger : 0));
             lds_barrier();
+            if (c_trace) { const long long t1 = __builtin_amdgcn_s_memtime(); acc_wait += t1 - tw0; tw0 = t1; }
             if (b == 0 && lg == 0) { PSEG_STAMP(4) }
             if (gq + D < G) stage_w(gq + D, slot_n);  // reuses the slot of group gq-1: free after the barrier
+            if (c_trace) acc_issue += __builtin_amdgcn_s_memtime() - tw0;
             slot_n = slot_n + 1 == a.NB ? 0 : slot_n + 1;
             const int n = min(a.GK, ks - lg * a.GK);
             const char* wb = w_t + slot_c * WBUF + lane * 16;
@@ -537,6 +548,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
 
     PSEG_STAMP(5)
+    if (c_trace && tid == 0) {
+        c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + 8] = (unsigned long long)acc_wait;
+        c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + 9] = (unsigned long long)acc_issue;
+    }
     do {
     // ---- epilogue -----------------------------------------------------------------------------
     // D layout: lane holds pixel (lane & 15) x couts 4*(lane>>4) .. +3 of each 16x16 tile.
@@ -724,7 +739,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     if (nbi + 1 < NBL) lds_barrier();
     }   // N-block loop
     PSEG_STAMP(6)
-    if (c_trace && tid == 0) { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(x)); c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = x; }
+    if (c_trace && tid == 0) { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(x)); c_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12 + 7] = x; }
 #undef PSEG_STAMP
 }
 
@@ -1080,7 +1095,7 @@ enum PlanKind { PLAN_GENERIC = 0, PLAN_CONV1 = 1, PLAN_LOGITS = 2 };
 
 struct MfmaPlan {
     int kind = PLAN_GENERIC;
-    int MT = 4, NT = 2, KS = 1, stride = 1;
+    int MT = 4, NT = 2, KS = 1, stride = 1, NW = 4;
     int nblk = 1, nc_full = 1, nc_last = 1, ks_full = 1, ks_last = 1;
     int PS2 = 0, row_pitch = 0, THH = 0, TWH = 0, GK = 4, NB = 3, G = 1, lds_w_off = 0, lds_tab_off = 0, lds_bytes = 0;
     int NTtot = 0, nblocks_n = 1, CoP = 0, lds_f1_off = 0;
@@ -1098,6 +1113,11 @@ struct MfmaPlan {
     uint16_t* d_tc_wA2 = nullptr;
     float* d_tc_beta = nullptr;
     int tc_CP = 0, tc_nks0 = 0, tc_nkss = 0;
+    // host copies of the (transformed) kernel / bias: the plan is re-packed when the canvas size
+    // makes the other workgroup shape (NW) the better one
+    std::vector<float> w_keep, b_keep;
+    bool nw8_ok = false;        // an 8-wave kernel instance exists for this layer shape
+    bool nw8_resident = false;  // ... and its whole weight set stays resident beside the 16-row tile
     int cmax = 4;
 };
 
@@ -1248,6 +1268,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     mfma_free_op(op);
     auto* P = new MfmaPlan();
     op.plan = P;
+    P->w_keep = w;
+    P->b_keep = bias;
     const Tensor& s0 = e.tensors[op.src0];
     const Tensor* s1 = op.src1 >= 0 ? &e.tensors[op.src1] : nullptr;
     const int C0 = s0.C, Cs0 = s0.Cs, C1 = s1 ? s1->C : 0, Cs1 = s1 ? s1->Cs : 0;
@@ -1313,7 +1335,11 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     if (getenv("PSEG_MT")) P->MT = atoi(getenv("PSEG_MT")) == 8 && NT <= 2 ? 8 : 4;
     P->KS = KS;
     P->stride = deconv ? 1 : op.stride;
-    const int TH = 2 * P->MT;
+    // 8-wave workgroups (16-row tiles, the whole CU's LDS) exist for the k5 stride-1 mid-layer shapes
+    P->nw8_ok = !deconv && KS == 5 && op.stride == 1 && P->MT == 4 && (NT == 3 || NT == 4) && !op.up0 && !op.up1 &&
+                !op.in_relu && op.add < 0 && op.fuse1 < 0 && P->nblocks_n == 1 && !getenv("PSEG_GENERIC") && !getenv("PSEG_NO_NW8");
+    P->NW = (P->nw8_ok && op.nw_hint == 8) ? 8 : 4;
+    const int TH = P->NW * (P->MT / 2);
     const int totc = (Cs0 + Cs1) / 8;
     P->nc_full = totc <= 5 ? totc : (KS == 1 && totc <= 16 ? totc : 4);
     P->nblk = cdiv(totc, P->nc_full);
@@ -1343,6 +1369,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
             }
         }
     }
+    if (P->NW == 8 && sigma != 6) return fail(PSEG_EUNSUPPORTED, "8-wave plan needs the sigma = 6 tile (got %d)", sigma);
     P->PS2 = sigma * 16;
     P->row_pitch = (P->TWH * sigma + pitch_pad) * 16;
     const auto ord_full = pair_chunks(KS, P->nc_full, sigma, P->row_pitch / 16);
@@ -1368,10 +1395,10 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     const int in_bytes = P->THH * P->row_pitch;
     const int ks_max = std::max(P->ks_full, P->ks_last);
     const int tab_bytes = ks_max * 16;
-    int budget = 80 * 1024;
+    int budget = P->NW == 8 ? 156 * 1024 : 80 * 1024;
     if (const char* ev = getenv("PSEG_LDS_KB")) budget = atoi(ev) * 1024;
     auto total = [&](int gk, int nbuf) { return round_up(in_bytes, 16) + nbuf * gk * NT * 1024 + tab_bytes + 16; };
-    const int gstep = (NT % 4 == 0) ? 1 : (NT % 2 == 0 ? 2 : 4);
+    const int gstep = P->NW == 8 ? 1 : ((NT % 4 == 0) ? 1 : (NT % 2 == 0 ? 2 : 4));
     auto best_gk = [&](int nbuf) {
         int gk = 0;
         for (int c = gstep; c <= 32 && c <= round_up(ks_max, gstep); c += gstep)
@@ -1384,7 +1411,9 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     if (GK < 4 && GK < round_up(ks_max, gstep)) { NB = 2; GK = best_gk(2); }
     if (GK == 0) { NB = 2; GK = gstep; }
     // all weights of a single-block layer resident in one slot: no ring, no group barriers
-    if (P->nblk == 1 && total(round_up(ks_max, gstep), 1) <= budget && round_up(ks_max, gstep) <= 32) {
+    const bool can_reside = P->nblk == 1 && total(round_up(ks_max, gstep), 1) <= budget && round_up(ks_max, gstep) <= 32;
+    P->nw8_resident = P->NW == 8 && can_reside;
+    if (can_reside && !getenv("PSEG_NO_RESIDENT")) {
         NB = 1;
         GK = round_up(ks_max, gstep);
     }
@@ -1527,17 +1556,17 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     return PSEG_OK;
 }
 
-template <int MT, int NT, int KS, int ST, int SG, int MODE, int FL>
+template <int MT, int NT, int KS, int ST, int SG, int MODE, int FL, int NW = 4>
 static int launch_inst(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     PSEG_HIP(hipGetDevice(&dev));
     if (!attr_set[dev & 63]) {
-        PSEG_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT, KS, ST, SG, MODE, FL>,
+        PSEG_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<MT, NT, KS, ST, SG, MODE, FL, NW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev & 63] = true;
     }
-    conv_mfma_kernel<MT, NT, KS, ST, SG, MODE, FL><<<grid, 256, P.lds_bytes, st>>>(a);
+    conv_mfma_kernel<MT, NT, KS, ST, SG, MODE, FL, NW><<<grid, NW * 64, P.lds_bytes, st>>>(a);
     return PSEG_OK;
 }
 
@@ -1549,6 +1578,15 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     const int sg = a.sigma, st_ = a.stride, ks = P.KS;
     if (a.f1_img && !(P.MT == 8 && P.NT == 2 && ks == 5 && sg == 3 && mode == MODE_CONV && (fl & ~FL_PERSIST) == (FL_POOL | FL_FUSE1)))
         return fail(PSEG_EUNSUPPORTED, "first-layer fusion has no kernel instance for this shape");
+#define PSEG_TRY_INST8(MT_, NT_, KS_, ST_, SG_, MODE_, FL_)                                         \
+    if (P.NW == 8 && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == (FL_)) \
+        return launch_inst<MT_, NT_, KS_, ST_, SG_, MODE_, (FL_), 8>(a, P, grid, st);
+    PSEG_TRY_INST8(4, 3, 5, 1, 6, MODE_CONV, 0)           // conv3, deconv3 (16-row tiles)
+    PSEG_TRY_INST8(4, 3, 5, 1, 6, MODE_CONV, FL_POOL)     // conv4
+    PSEG_TRY_INST8(4, 4, 5, 1, 6, MODE_CONV, 0)           // conv5
+    PSEG_TRY_INST8(4, 4, 5, 1, 6, MODE_CONV, FL_POOL)     // conv6
+#undef PSEG_TRY_INST8
+    if (P.NW != 4) return fail(PSEG_EUNSUPPORTED, "no 8-wave kernel instance for this layer shape");
 #define PSEG_TRY_INST(MT_, NT_, KS_, ST_, SG_, MODE_, FL_)                                          \
     if (!getenv("PSEG_GENERIC") && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == (FL_)) \
         return launch_inst<MT_, NT_, KS_, ST_, SG_, MODE_, (FL_)>(a, P, grid, st);
@@ -1586,7 +1624,7 @@ static int launch_generic_any(const MConv& a0, const MfmaPlan& P, dim3 grid, hip
     const char* tr = getenv("PSEG_TRACE");
     if (tr && strcmp(tr, layer) == 0) {
         MConv a = a0;
-        const size_t n = (size_t)grid.x * grid.y * 8;
+        const size_t n = (size_t)grid.x * grid.y * 12;
         PSEG_HIP(hipMalloc((void**)&a.trace, n * 8));
         PSEG_HIP(hipMemset(a.trace, 0, n * 8));
         int rc = launch_generic_any2(a, P, grid, st);
@@ -1660,6 +1698,27 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
             conv1_bf16_kernel<1, 32><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
         return PSEG_OK;
     }
+    if (P->nw8_ok) {
+        // 16-row tiles when they still fill the chip (one workgroup per CU); re-pack on a change
+        // Measured (MI355X, 2048x1536): 16-row tiles pay off where the layer's whole weight set then
+        // stays resident in LDS (conv3: 80 -> 68 us); with a streamed ring they only tie (the halved
+        // weight traffic is offset by losing the second workgroup's overlap).  PSEG_NW=4|8 forces.
+        int want = (cdiv(e.tW(d), TW) * cdiv(e.tH(d), 16) >= 224 && sigma_for(P->nc_full) == 6) ? 8 : 4;
+        const char* ev = getenv("PSEG_NW");
+        if (ev) want = atoi(ev) == 8 ? 8 : 4;
+        if (want != P->NW) {
+            const std::vector<float> w = P->w_keep, b = P->b_keep;
+            op.nw_hint = want;
+            PSEG_TRY(mfma_pack_op(e, op, w, b));
+            P = (MfmaPlan*)op.plan;
+            if (want == 8 && !P->nw8_resident && !ev) {   // ring only: keep two workgroups per CU
+                op.nw_hint = 4;
+                PSEG_TRY(mfma_pack_op(e, op, w, b));
+                P = (MfmaPlan*)op.plan;
+                P->nw8_ok = false;                        // decided for this engine
+            }
+        }
+    }
     MConv a{};
     fill_common(e, op, *P, a);
     a.Hout = e.tH(d);
@@ -1686,7 +1745,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         a.f1_relu = c1.relu;
         a.lds_f1_off = P->lds_f1_off;
     }
-    dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n);
+    dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, P->NW * (P->MT / 2)), P->nblocks_n);
     // persistent instance (opt-in, PSEG_PERSIST=1): resident weights (NB == 1), single channel block, two
     // workgroups per CU walking 12 tiles each.  Measured on MI355X: 0.182 ms vs 0.173 ms for the plain
     // one-tile-per-workgroup launch -- the weight DMA it saves was already hidden by the co-resident

@@ -28,12 +28,14 @@ for ly in layers:
     fn = "gpurun_out/trace_%s.bin" % ly
     if not os.path.exists(fn):
         print(ly, ": no trace written"); continue
-    a = np.fromfile(fn, dtype=np.uint64).reshape(-1, 8)
+    a = np.fromfile(fn, dtype=np.uint64).reshape(-1, 12)
     t = a[:, :7].astype(np.int64)
-    t = t[t[:, 6] > 0]
+    t_ok = t[:, 6] > 0
+    t = t[t_ok]
     d = np.diff(t, axis=1)
     names = ["ring issue", "tab fetch", "tile stage", "wait+barrier", "k-loop", "epilogue"]
     tot = np.median(t[:, 6] - t[:, 0])
     span = t[:, 6].max() - t[:, 0].min()
     print("%-20s WGs %5d  total/WG %6d  kernel span %8d ticks | " % (ly, len(t), tot, span) +
-          "  ".join("%s %d" % (n, np.median(d[:, i])) for i, n in enumerate(names)))
+          "  ".join("%s %d" % (n, np.median(d[:, i])) for i, n in enumerate(names)) +
+          "  | in k-loop: group waits %d  weight-DMA issue %d" % (np.median(a[t_ok, 8].astype(np.int64)), np.median(a[t_ok, 9].astype(np.int64))))

@@ -4,7 +4,7 @@
 import sys
 import numpy as np
 
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 12)
 t = a[:, :7].astype(np.int64)
 ok = t[:, 6] > 0
 t = t[ok]

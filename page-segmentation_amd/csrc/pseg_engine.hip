@@ -331,6 +331,11 @@ int set_canvas(Engine& e, int H, int W) {
             if (t.d) PSEG_HIP(hipMemset(t.d, 0, t.bytes));
     const double px = (double)Hp * Wp;
     for (auto& op : e.ops) e.slots[op.timing_slot].flops = op.flops_per_canvas_px * px;
+    // a launch that also runs a fused-away layer (conv1 inside conv2, logits inside the tail) does that layer's work too
+    for (auto& op : e.ops) {
+        if (op.fuse1 >= 0) e.slots[op.timing_slot].flops += e.ops[op.fuse1].flops_per_canvas_px * px;
+        if (op.tail_logits >= 0) e.slots[op.timing_slot].flops += e.ops[op.tail_logits].flops_per_canvas_px * px;
+    }
     return PSEG_OK;
 }
 

@@ -149,8 +149,11 @@ struct ConvArgs {
     int KH, KW, stride, pt, pl, Hout, Wout, Cout, in_relu, relu;
     const float* mask;   // training dgrad: input value counts only where mask (same layout as src0) > 0
     int dst_pitch;       // pixels per output row (0: Wout) -- crop / canvas-pitched outputs
+    int out_sy, out_sx, out_oy, out_ox;   // MFMA kernel only: output pixel (y*sy + oy, x*sx + ox); 0 strides = 1
+    int deconv4;         // MFMA kernel only: Conv2DTranspose k2 s2 as one GEMM, n = ab*Cout + co -> (2y + a, 2x + b)
 };
 int launch_conv_exact(const ConvArgs& a, hipStream_t st);
+int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st);   // 1 launched, 0 does not fit, < 0 error
 int upload_weights(Engine& e);
 int set_canvas(Engine& e, int H, int W);
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs, int64_t* d_labels,

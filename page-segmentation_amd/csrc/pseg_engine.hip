@@ -267,6 +267,9 @@ static int ensure(void** p, size_t* cap, size_t bytes) {
 // Wc[ky][kx][ci][co] = K[KH-1-ky][KW-1-kx][co][ci].  Conv2DTranspose k2 s2: [a][b][ci][co] =
 // K[a][b][co][ci].
 int launch_conv_exact(const ConvArgs& a, hipStream_t st) {
+    // matrix-core path (same bits, see pseg_exact_mfma.hip) when the all-channel tile fits in LDS
+    const int rc = launch_conv_exact_mfma(a, st);
+    if (rc != 0) return rc < 0 ? rc : PSEG_OK;
     dim3 grid(cdiv(a.Hout * a.Wout, 256), cdiv(a.Cout, COT));
     conv_exact_kernel<<<grid, 256, 0, st>>>(a);
     PSEG_HIP(hipGetLastError());
@@ -383,9 +386,8 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
                 }
                 a.dst = zl;
                 // the kernel indexes src rows with Win: rows of the padded canvas
-                dim3 grid(cdiv(a.Hout * a.Wout, 256), cdiv(op.Cout, COT));
                 // logical input dims stay the canvas; output (y,x) reads input (y,x)
-                conv_exact_kernel<<<grid, 256, 0, st>>>(a);
+                PSEG_TRY(launch_conv_exact(a, st));
                 if (d_probs || d_labels || d_labels_u8) {
                     const size_t n = (size_t)e.H * e.W;
                     const int g2 = (int)std::min<size_t>((n + 255) / 256, 8192);
@@ -407,10 +409,34 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
                 }
                 a.add = op.add >= 0 ? (const float*)e.tensors[op.add].d : nullptr;
                 a.dst = (float*)d.d;
-                dim3 grid(cdiv(a.Hout * a.Wout, 256), cdiv(op.Cout, COT));
-                conv_exact_kernel<<<grid, 256, 0, st>>>(a);
+                PSEG_TRY(launch_conv_exact(a, st));
             }
         } else if (op.type == OP_DECONV2) {
+            // Conv2DTranspose k2 s2 on the matrix cores: one 1x1 GEMM over n = (sub-pixel, cout), same chain
+            // order over ci as deconv2_exact_kernel; the scalar kernel if the all-channel tile does not fit
+            bool done = false;
+            {
+                ConvArgs c{};
+                c.src0 = (const float*)s0.d;
+                c.src1 = s1 ? (const float*)s1->d : nullptr;
+                c.C0 = s0.C;
+                c.C1 = s1 ? s1->C : 0;
+                c.Hin = c.Hout = e.tH(s0);
+                c.Win = c.Wout = e.tW(s0);
+                c.w = op.d_w;
+                c.bias = op.d_b;
+                c.KH = c.KW = 1;
+                c.stride = 1;
+                c.Cout = op.Cout;
+                c.relu = op.relu;
+                c.dst = (float*)e.tensors[op.dst].d;
+                c.dst_pitch = 2 * c.Win;
+                c.deconv4 = 1;
+                const int rc = launch_conv_exact_mfma(c, st);
+                if (rc < 0) return rc;
+                done = rc == 1;
+            }
+            if (!done) {
             DeconvArgs a{};
             a.src0 = (const float*)s0.d;
             a.src1 = s1 ? (const float*)s1->d : nullptr;
@@ -425,6 +451,7 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
             a.relu = op.relu;
             dim3 grid(cdiv(a.Hin * a.Win, 256), cdiv(op.Cout, COT), 4);
             deconv2_exact_kernel<<<grid, 256, 0, st>>>(a);
+            }
         } else if (op.type == OP_POOL) {
             const size_t n = (size_t)(e.tH(s0) / 2) * (e.tW(s0) / 2) * s0.C;
             const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);

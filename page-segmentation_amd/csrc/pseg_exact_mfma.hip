@@ -1,0 +1,249 @@
+// pseg_exact_mfma.hip -- float32-exact convolution on the matrix cores.
+//
+// v_mfma_f32_16x16x4_f32 accumulates its four k-values as the sequential chain
+// acc = fmaf(a[k], b[k], acc), k = 0..3, and continues the chain across instructions (checked on
+// MI355X by tools/microtests/mfma_f32_chain.hip: 256/256 outputs bitwise equal at K = 100).  With
+// k ordered (ky, kx, ci) -- the oracle's loop order -- this kernel therefore produces the SAME
+// bits as conv_exact_kernel / oracle/pseg_oracle.c, at MFMA rate (157 TFLOP/s f32 peak) instead
+// of one scalar FMA chain per thread:
+//   * out-of-image taps and the channel padding to a multiple of four feed x = 0 (and w = 0):
+//     fmaf(0, w, acc) == acc exactly (acc is never -0: it starts at +0);
+//   * then acc + bias (+ residual), ReLU -- the same operation sequence as the scalar kernel.
+// Because the chain runs over ALL input channels inside each tap, the halo tile is staged in LDS
+// with every input channel (float32); layers whose tile does not fit 150 KB even at two output
+// rows per workgroup (unet's 1536-channel concats) stay on the scalar kernel.
+//
+// Layout: D[cout][pixel] per 16x16 tile; lane l = (p16 = l & 15, g = l >> 4).
+//   A (weights):  lane holds w[k = 4s + g][cout = 16t + p16]   (global load, L1/L2 resident)
+//   B (pixels):   lane holds x[pixel p16][channel 4s + g]        (ds_read_b32 from the LDS tile)
+//   D:            lane holds couts 16t + 4g .. +3 of pixel p16  (16-byte store)
+// LDS pixel stride Cp = Cin rounded up to 2 (mod 4) floats: 16 pixels x 2 lane groups hit 32
+// distinct banks (conflict-free ds_read_b32 while the four lane groups stay inside one tap).
+// out_sy/out_sx/out_oy/out_ox scatter the output pixel grid (Conv2DTranspose k2 s2 = four 1x1
+// convolutions, one per sub-pixel, written to (2y + a, 2x + b)).
+#include <algorithm>
+
+#include "pseg_common.h"
+
+namespace pseg {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int XTW = 32;   // output tile width (two 16-pixel MFMA column tiles)
+
+// MT = pixel tiles per wave (4: two rows x two column tiles, 2: one row), NT = cout tiles per workgroup.
+// FLAT = false: k-steps are (tap, four channels), channels zero-padded to a multiple of four per tap
+//               (all lanes of a k-step share the tap: scalar tap loop, no per-lane bookkeeping);
+// FLAT = true : K flattened across taps, k = (ky*KW + kx)*Cin + ci (first layers: Cin = 1 packs four
+//               taps into one MFMA instead of wasting three quarters of it).
+// Both orders are the oracle's chain order; the padded / trailing k feed w = 0 against a finite x.
+template <int MT, int NT, bool FLAT>
+__global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp, int THH, int TWH) {
+    extern __shared__ __attribute__((aligned(16))) float xt[];   // [THH][TWH][Cp]
+    constexpr int RW = MT / 2;            // output rows per wave
+    constexpr int TH = 4 * RW;            // output rows per workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p16 = lane & 15, g = lane >> 4;
+    const int tiles_x = (a.Wout + XTW - 1) / XTW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * XTW;
+    const int iy0 = oy0 * a.stride - a.pt, ix0 = ox0 * a.stride - a.pl;
+    const int Cin = a.C0 + a.C1;
+    const int co_base = blockIdx.y * (NT * 16);
+    const int Ntot = a.deconv4 ? 4 * a.Cout : a.Cout;
+
+    // ---- stage the halo tile: all input channels, zeros outside the image and in the channel pad
+    const int npx = THH * TWH;
+    for (int p = wave; p < npx; p += 4) {            // one pixel per wave trip, lanes over channels
+        const int r = p / TWH, c = p - r * TWH;
+        const int iy = iy0 + r, ix = ix0 + c;
+        const bool in = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        float* d = xt + (size_t)p * Cp;
+        const float* s0 = a.src0 + ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0;
+        const float* s1 = a.src1 ? a.src1 + ((size_t)(iy >> a.up1) * (a.Win >> a.up1) + (ix >> a.up1)) * a.C1 : nullptr;
+        const float* mk = a.mask ? a.mask + ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0 : nullptr;
+        for (int ch = lane; ch < Cp; ch += 64) {
+            float v = 0.0f;
+            if (in && ch < Cin) {
+                if (ch < a.C0) {
+                    v = s0[ch];
+                    if (a.in_relu) v = v > 0.0f ? v : 0.0f;
+                    if (mk) v = mk[ch] > 0.0f ? v : 0.0f;
+                } else {
+                    v = s1[ch - a.C0];
+                    if (a.in_relu) v = v > 0.0f ? v : 0.0f;
+                }
+            }
+            d[ch] = v;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int pixoff[MT];   // float offset of this lane's pixel at tap (0,0), channel 0
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = wave * RW + (m >> 1), col = (m & 1) * 16 + p16;
+        pixoff[m] = (row * a.stride * TWH + col * a.stride) * Cp;
+    }
+    // this lane's weight column per cout tile: w[k*Cout + wcol] (transposed conv k2 s2 as one GEMM over
+    // n = ab*Cout + co: the sub-pixel's kernel starts ab*Cin*Cout further on), or -1 past the layer
+    int wcol[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = co_base + t * 16 + p16;
+        const int ab = a.deconv4 ? n / a.Cout : 0;
+        wcol[t] = n < Ntot ? ab * Cin * a.Cout + (n - ab * a.Cout) : -1;
+    }
+    float xa[MT], wa[NT], xb[MT], wb[NT];
+#define PSEG_XMMA(XF, WF)                                                                        \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                               \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                           \
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(WF[t], XF[m], acc[m][t], 0, 0, 0);
+    if constexpr (!FLAT) {
+        const int nks = (Cin + 3) >> 2;        // k-steps per tap
+        for (int ky = 0; ky < a.KH; ++ky)
+            for (int kx = 0; kx < a.KW; ++kx) {
+                const float* wt = a.w + (size_t)((ky * a.KW + kx) * Cin) * a.Cout;
+                const int toff = (ky * TWH + kx) * Cp + g;
+                auto load = [&](float* xf, float* wf, int s) {
+                    const int ci = 4 * s + g;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) xf[m] = xt[pixoff[m] + toff + 4 * s];
+                    const bool okc = ci < Cin;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) wf[t] = (okc && wcol[t] >= 0) ? wt[(size_t)ci * a.Cout + wcol[t]] : 0.0f;
+                };
+                load(xa, wa, 0);
+                int s = 0;
+                for (; s + 2 <= nks; s += 2) {
+                    load(xb, wb, s + 1);
+                    PSEG_XMMA(xa, wa)
+                    if (s + 2 < nks) load(xa, wa, s + 2);
+                    PSEG_XMMA(xb, wb)
+                }
+                if (s < nks) { PSEG_XMMA(xa, wa) }
+            }
+    } else {
+        const int Ktot = a.KH * a.KW * Cin;
+        const int nks = (Ktot + 3) >> 2;
+        const int wraps = Cin >= 4 ? 1 : 4;          // tap boundaries one step of four can cross
+        int k_l = g, ci_l = g, kx_l = 0, toff_l = 0;  // this lane's k, channel, kernel column, tap offset
+        auto wrap = [&]() {
+            for (int w = 0; w < wraps; ++w) {
+                const bool wr = ci_l >= Cin;
+                ci_l -= wr ? Cin : 0;
+                kx_l += wr ? 1 : 0;
+                toff_l += wr ? Cp : 0;
+                const bool rw = kx_l == a.KW;
+                kx_l = rw ? 0 : kx_l;
+                toff_l += rw ? (TWH - a.KW) * Cp : 0;
+            }
+        };
+        wrap();
+        auto load = [&](float* xf, float* wf) {
+            const bool okk = k_l < Ktot;
+            const int xo = okk ? toff_l + ci_l : 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xf[m] = xt[pixoff[m] + xo];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = (okk && wcol[t] >= 0) ? a.w[(size_t)k_l * a.Cout + wcol[t]] : 0.0f;
+            k_l += 4;
+            ci_l += 4;
+            wrap();
+        };
+        load(xa, wa);
+        int s = 0;
+        for (; s + 2 <= nks; s += 2) {
+            load(xb, wb);
+            PSEG_XMMA(xa, wa)
+            load(xa, wa);
+            PSEG_XMMA(xb, wb)
+        }
+        if (s < nks) { PSEG_XMMA(xa, wa) }
+    }
+#undef PSEG_XMMA
+
+    // ---- epilogue: acc + bias (+ add), ReLU; lane owns n = 4g..4g+3 of pixel p16 in every tile
+    const int osy = a.out_sy ? a.out_sy : 1, osx = a.out_sx ? a.out_sx : 1;
+    const int pitch = a.dst_pitch ? a.dst_pitch : a.Wout;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int y = oy0 + wave * RW + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+        if (y >= a.Hout || x >= a.Wout) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = co_base + t * 16 + 4 * g + r;
+                if (n < Ntot) {
+                    const int ab = a.deconv4 ? n / a.Cout : 0;
+                    const int co = n - ab * a.Cout;
+                    const size_t opix = a.deconv4 ? (size_t)(2 * y + (ab >> 1)) * pitch + (size_t)(2 * x + (ab & 1))
+                                                  : (size_t)(y * osy + a.out_oy) * pitch + (size_t)(x * osx + a.out_ox);
+                    float v = a.bias ? acc[m][t][r] + a.bias[co] : acc[m][t][r];
+                    if (a.add) v = v + a.add[opix * a.Cout + co];
+                    if (a.relu) v = v > 0.0f ? v : 0.0f;
+                    a.dst[opix * a.Cout + co] = v;
+                }
+            }
+    }
+}
+
+template <int MT, int NT, bool FLAT>
+static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    PSEG_HIP(hipGetDevice(&dev));
+    if (!attr_set[dev & 63]) {
+        PSEG_HIP(hipFuncSetAttribute((const void*)conv_exact_mfma_kernel<MT, NT, FLAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[dev & 63] = true;
+    }
+    conv_exact_mfma_kernel<MT, NT, FLAT><<<grid, 256, lds, st>>>(a, Cp, THH, TWH);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+// Returns 1 when the layer was launched on the MFMA kernel, 0 when it does not fit (caller falls
+// back to the scalar kernel), < 0 on error.
+int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st) {
+    if (getenv("PSEG_EXACT_SCALAR")) return 0;
+    const int Cin = a.C0 + a.C1;
+    if (Cin < 1 || a.Cout < 1 || a.KH != a.KW) return 0;
+    const int Ntot = a.deconv4 ? 4 * a.Cout : a.Cout;
+    if (Ntot < 8) return 0;                    // a handful of couts (logits): the scalar kernel wastes less
+    const bool flat = Cin < 8;
+    // tap-aligned k-steps read up to 4*ceil(Cin/4) channels of a pixel: the pad must be the pixel's own zeros
+    int Cp = flat ? std::max(Cin, 2) : 4 * ((Cin + 3) / 4);
+    while (Cp % 4 != 2) ++Cp;                  // LDS pixel stride: 2 (mod 4) floats
+    const size_t budget = 150 * 1024;
+    int MT = 0, THH = 0, TWH = (XTW - 1) * a.stride + a.KW;
+    for (int mt : {4, 2}) {
+        const int th = 4 * (mt / 2);
+        const int thh = (th - 1) * a.stride + a.KH;
+        if ((size_t)thh * TWH * Cp * 4 <= budget) { MT = mt; THH = thh; break; }
+    }
+    if (!MT) return 0;
+    const size_t lds = (size_t)THH * TWH * Cp * 4;
+    const int ntall = cdiv(Ntot, 16);
+    const int NT = ntall <= 4 ? ntall : (ntall == 5 ? 5 : 4);
+    const int TH = 4 * (MT / 2);
+    dim3 grid(cdiv(a.Wout, XTW) * cdiv(a.Hout, TH), cdiv(ntall, NT));
+#define PSEG_XM(MT_, NT_)                                                                        \
+    if (MT == MT_ && NT == NT_) {                                                                \
+        if (flat) PSEG_TRY((launch_xm<MT_, NT_, true>(a, Cp, THH, TWH, grid, lds, st)));         \
+        else PSEG_TRY((launch_xm<MT_, NT_, false>(a, Cp, THH, TWH, grid, lds, st)));             \
+        return 1;                                                                                \
+    }
+    PSEG_XM(4, 1) PSEG_XM(4, 2) PSEG_XM(4, 3) PSEG_XM(4, 4) PSEG_XM(4, 5)
+    PSEG_XM(2, 1) PSEG_XM(2, 2) PSEG_XM(2, 3) PSEG_XM(2, 4) PSEG_XM(2, 5)
+#undef PSEG_XM
+    return 0;
+}
+
+}  // namespace pseg

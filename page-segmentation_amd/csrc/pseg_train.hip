@@ -254,6 +254,137 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     if (a.dB && tap == 0 && (int)threadIdx.x < a.Cout) atomicAdd(&a.dB[threadIdx.x], bsum);
 }
 
+// Matrix-core weight gradient.  dW[tap][ci][co] += sum over pixels of X[pixel + tap][ci] * dY[pixel][co]
+// runs as v_mfma_f32_16x16x4_f32 with the pixel index as the MFMA k dimension: A = X^T (rows = 16
+// input channels, k = 4 pixels), B = dY (k = 4 pixels, columns = 16 output channels).  One
+// workgroup = one tap x one strip of rows; every wave walks its own pixel quads of the strip and
+// loads both operands straight from global memory in fragment layout (lane = (channel, pixel):
+// four 64-byte segments per instruction; nothing is shared between waves, so no LDS staging and
+// no barriers in the loop) for ALL (ci, co) tiles (<= 5 x 5 accumulator tiles = 100 VGPRs).  The
+// tap is the fastest grid dimension: the workgroups of one strip run together and re-read it
+// from L2.  The four waves' partial sums are reduced through LDS and leave as one atomicAdd per
+// element.  Accumulation order is free here (float tolerance against torch autograd, not bit parity).
+typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
+constexpr int WGM_MAXT = 5;   // up to 80 channels per side
+
+// TI x TJ = accumulator tiles (input-channel tiles x output-channel tiles) the instance keeps: small
+// layers get small instances, hence many waves per SIMD to hide the operand-load latency.
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
+    __shared__ float red[256];
+    const int tap = blockIdx.x;
+    const int ky = tap / a.KW, kx = tap % a.KW;
+    const int itW = a.mode == 0 ? a.Wy : a.Wx, itH = a.mode == 0 ? a.Hy : a.Hx;
+    const int r0 = blockIdx.y * a.strip_rows, r1 = min(r0 + a.strip_rows, itH);
+    const int tiles_ci = (a.XC + 15) >> 4, tiles_co = (a.Cout + 15) >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p16 = lane & 15, g = lane >> 4;
+    wg_f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+    float bacc[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) bacc[j] = 0.0f;
+    const bool want_b = a.dB != nullptr && tap == 0;
+
+    auto load = [&](int y, int xq, float* xa, float* yb) {
+        const int x = xq + g;
+        int sy, sx;
+        if (a.mode == 0) { sy = y + ky - a.pt; sx = x + kx - a.pl; } else { sy = y; sx = x; }
+        const bool okx = x < itW && sy >= 0 && sy < a.Hx && sx >= 0 && sx < a.Wx;
+        const float* xp = a.X + ((size_t)sy * a.xpitch + sx) * a.XC + p16;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) xa[i] = (i < tiles_ci && okx && i * 16 + p16 < a.XC) ? xp[i * 16] : 0.0f;
+        const int dy = a.mode == 0 ? y : 2 * y + (tap >> 1), dx = a.mode == 0 ? x : 2 * x + (tap & 1);
+        const size_t o = ((size_t)dy * a.ypitch + dx) * a.Cout + p16;
+        const bool oky = x < itW;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            float v = 0.0f;
+            if (j < tiles_co && oky && j * 16 + p16 < a.Cout) {
+                v = a.dY[o + j * 16];
+                if (a.maskY && !(a.maskY[o + j * 16] > 0.0f)) v = 0.0f;
+            }
+            yb[j] = v;
+        }
+    };
+    // quads of this wave: (row y, columns 4*(wave + 4n) .. +3), walked as one sequence
+    const int qpr = (itW + 15) >> 4;                   // quads per wave per row
+    const int nq = (r1 - r0) * qpr;
+    float xa[TI], yb[TJ], xn[TI], yn[TJ];
+    if (nq > 0) load(r0, wave * 4, xa, yb);
+    for (int q = 0; q < nq; ++q) {
+        if (q + 1 < nq) {
+            const int qn = q + 1, yr = qn / qpr, xc = qn - yr * qpr;
+            load(r0 + yr, (xc * 4 + wave) * 4, xn, yn);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+            if (i < tiles_ci)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    if (j < tiles_co) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+        if (want_b)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bacc[j] += yb[j];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) xa[i] = xn[i];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) yb[j] = yn[j];
+    }
+    // D tile: lane holds rows (ci) 4g..4g+3, column (co) p16.  Reduce the four waves through LDS.
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+        if (i < tiles_ci)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                if (j < tiles_co) {
+                    for (int w = 0; w < 4; ++w) {
+                        if (wave == w) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float* qd = red + (4 * g + r) * 16 + p16;
+                                *qd = w == 0 ? acc[i][j][r] : *qd + acc[i][j][r];
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    {
+                        const int e = threadIdx.x, row = e >> 4, col = e & 15;
+                        const int ci = i * 16 + row, co = j * 16 + col;
+                        if (ci < a.XC && co < a.Cout)
+                            atomicAdd(&a.dW[((size_t)tap * a.Cin + a.ci0 + ci) * a.Cout + co], red[e]);
+                    }
+                    __syncthreads();
+                }
+    if (want_b) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            float v = bacc[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0 && j < tiles_co && j * 16 + p16 < a.Cout) atomicAdd(&a.dB[j * 16 + p16], v);
+        }
+    }
+}
+
+static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
+    // grid = (strips, taps) for the scalar kernel; the matrix-core kernel takes (taps, strips)
+    if (a.XC <= 16 * WGM_MAXT && a.Cout <= 16 * WGM_MAXT && !getenv("PSEG_WGRAD_SCALAR")) {
+        const int ti = (a.XC + 15) / 16, tj = (a.Cout + 15) / 16;
+        const dim3 g2(grid.y, grid.x);
+#define PSEG_WG(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) { wgrad_mfma_kernel<TI_, TJ_><<<g2, 256, 0, st>>>(a); PSEG_HIP(hipGetLastError()); return PSEG_OK; }
+        PSEG_WG(1, 2) PSEG_WG(2, 2) PSEG_WG(2, 3) PSEG_WG(3, 3) PSEG_WG(3, 5) PSEG_WG(5, 3) PSEG_WG(5, 5)
+#undef PSEG_WG
+    } else {
+        const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
+        wgrad_kernel<<<grid, 256, (size_t)WG_PC * (XCp + COp) * 4, st>>>(a);
+    }
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
 // dB[co] += sum over pixels of dY' (dY masked by Y > 0 for ReLU layers)
 __global__ void bias_grad_kernel(const float* dY, const float* maskY, size_t npix, int Cout, float* dB) {
     __shared__ float sh[128];
@@ -428,8 +559,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
                 if ((XCp / 4) * (COp / 4) > 768) return fail(PSEG_EUNSUPPORTED, "wgrad tile count too large for %s", op.layer.c_str());
                 dim3 grid(cdiv(Hy, a.strip_rows), k * k);
-                wgrad_kernel<<<grid, 256, (size_t)WG_PC * (XCp + COp) * 4, st>>>(a);
-                PSEG_HIP(hipGetLastError());
+                PSEG_TRY(launch_wgrad(a, grid, st));
             }
             // ---- dgrad into the source gradients (skipped for the network input) ----
             for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
@@ -461,10 +591,8 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.KW = 2; a.mode = 1;
                 a.strip_rows = std::max(1, cdiv(Hx * 4, strips_target));
                 a.dW = gw; a.dB = nullptr;
-                const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
                 dim3 grid(cdiv(Hx, a.strip_rows), 4);
-                wgrad_kernel<<<grid, 256, (size_t)WG_PC * (XCp + COp) * 4, st>>>(a);
-                PSEG_HIP(hipGetLastError());
+                PSEG_TRY(launch_wgrad(a, grid, st));
             }
             if (op.Cout > 128) return fail(PSEG_EUNSUPPORTED, "bias gradient supports at most 128 channels");
             bias_grad_kernel<<<512, 256, 0, st>>>(dY, op.relu ? Y : nullptr, (size_t)4 * Hx * Wx, op.Cout, gb);
@@ -474,8 +602,19 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 const int c0 = sidx == 0 ? 0 : C0, nc = sidx == 0 ? C0 : C1;
                 PSEG_TRY(ensure_wd((size_t)4 * op.Cout * nc));
                 wd_deconv_kernel<<<64, 256, 0, st>>>(op.d_w, op.Cin, op.Cout, c0, nc, t->d_wd);
-                dim3 grid(cdiv(Hx * Wx, 256), cdiv(nc, COT));
-                deconv2_dgrad_kernel<<<grid, 256, 0, st>>>(dY, Y, op.relu, Hx, Wx, op.Cout, t->d_wd, nc, t->tgrad[src]);
+                // = a k2 stride-2 convolution of the (ReLU-masked) output gradient with wd[ab][co][c],
+                // accumulated in place: the matrix-core kernel when its tile fits, else the scalar one
+                ConvArgs c{};
+                c.src0 = dY; c.C0 = op.Cout; c.mask = op.relu ? Y : nullptr;
+                c.Hin = 2 * Hx; c.Win = 2 * Wx; c.Hout = Hx; c.Wout = Wx;
+                c.w = t->d_wd; c.KH = c.KW = 2; c.stride = 2; c.Cout = nc;
+                c.add = t->tgrad[src]; c.dst = t->tgrad[src];
+                const int rc = launch_conv_exact_mfma(c, st);
+                if (rc < 0) return rc;
+                if (rc == 0) {
+                    dim3 grid(cdiv(Hx * Wx, 256), cdiv(nc, COT));
+                    deconv2_dgrad_kernel<<<grid, 256, 0, st>>>(dY, Y, op.relu, Hx, Wx, op.Cout, t->d_wd, nc, t->tgrad[src]);
+                }
                 PSEG_HIP(hipGetLastError());
             }
         } else if (op.type == OP_POOL) {

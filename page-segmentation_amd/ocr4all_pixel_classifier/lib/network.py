@@ -45,8 +45,8 @@ class Network:
                  ):
         """
         :param type: "train" enables the training state, anything else ("Predict") is inference
-        :param model: weight file written by save_weights(); '.h5' paths are looked up as the
-                      sibling '.npz' (Keras HDF5 needs h5py, which this image lacks)
+        :param model: Keras HDF5 weight / full-model file (read by pseg_amd.h5lite, no h5py needed)
+                      or the .npz written by save_weights(); no extension means '.h5' as in the reference
         :param device: HIP device index (keyword-only extension)
         :param exact: True = float32 sequential-fmaf mode (bit-identical to the CPU oracle),
                       False = bf16 MFMA throughput mode (keyword-only extension)
@@ -85,28 +85,56 @@ class Network:
 
     @staticmethod
     def _resolve(model):
+        """lib/network.py:59: a model name without extension means <name>.h5.  A Keras HDF5 file is read
+        directly (pseg_amd.h5lite); a sibling .npz (this package's native format) is used when the
+        .h5 does not exist."""
         if not model:
             return None
         if '.' not in os.path.basename(model):
-            model = model + '.h5'                    # lib/network.py:59
-        if model.endswith('.h5'):
+            model = model + '.h5'
+        if model.endswith('.h5') and not os.path.exists(model):
             alt = model[:-3] + '.npz'
             if os.path.exists(alt):
                 return alt
-            if os.path.exists(model):
-                raise Exception("Keras HDF5 model files need h5py, which is not available here; "
-                                "convert %s to .npz (name -> array) first" % model)
-            return alt
         return model
 
     # -- weights I/O (replaces ModelCheckpoint / load_weights, lib/network.py:106-107,177-183) --
     def save_weights(self, path):
+        """'.h5' -> a Keras weights file (`model.load_weights` / this class read it back; layer and
+        variable names are Keras' defaults: conv2d/kernel:0, ...); anything else -> .npz."""
+        w = self.model.get_weights()
+        if path.endswith('.h5'):
+            from pseg_amd import h5lite
+            layers = []
+            for name, arr in w.items():
+                lname = name.split('/')[0]
+                if not layers or layers[-1][0] != lname:
+                    layers.append((lname, []))
+                layers[-1][1].append((name + ':0', arr))
+            h5lite.write_keras_weights(path, layers)
+            return path
         if not path.endswith('.npz'):
             path = os.path.splitext(path)[0] + '.npz'
-        np.savez(path, **{k.replace('/', '__'): v for k, v in self.model.get_weights().items()})
+        np.savez(path, **{k.replace('/', '__'): v for k, v in w.items()})
         return path
 
     def load_weights(self, path):
+        if path.endswith('.h5'):
+            # Keras load_weights(by_name=False): layers that own weights are matched BY ORDER (names in a
+            # trained file carry Keras' per-process counters, e.g. conv2d_14), shapes must agree
+            from pseg_amd import h5lite
+            file_w = [(wn, a) for _, ws in h5lite.read_keras_weights(path) for wn, a in ws]
+            specs = self.model.weight_specs()
+            if len(file_w) != len(specs):
+                raise Exception("%s holds %d weight tensors, the %s graph has %d"
+                                % (path, len(file_w), self.architecture, len(specs)))
+            out = {}
+            for (name, shape), (wn, a) in zip(specs, file_w):
+                if tuple(a.shape) != tuple(shape):
+                    raise Exception("%s: %s has shape %s, %s expects %s" % (path, wn, a.shape, name, tuple(shape)))
+                out[name] = np.ascontiguousarray(a, dtype=np.float32)
+            self.model.set_weights(out)
+            return
         with np.load(path, allow_pickle=False) as z:
             self.model.set_weights({k.replace('__', '/'): z[k] for k in z.files})
 

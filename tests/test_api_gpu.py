@@ -44,15 +44,28 @@ def test_predictor_roundtrip_exact_mode(gpu, oracle_mod, tmp_path):
     from ocr4all_pixel_classifier.lib.output import output_data
     output_data(str(tmp_path), want, data, cm)
     assert (tmp_path / "color" / "page.png").exists()
-    # weights round-trip through the engine and the .npz file
+    # weights round-trip through the engine and a Keras HDF5 file (lib/network.py:59: no extension = .h5)
     path = net.save_weights(str(tmp_path / "model.h5"))
-    assert path.endswith(".npz")
+    assert path.endswith(".h5") and open(path, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
     from ocr4all_pixel_classifier.lib.network import Network
     net2 = Network("Predict", n_classes=3, model=str(tmp_path / "model"), exact=True)
     got = net2.model.get_weights()
     assert all(np.array_equal(got[k], Wt[k]) for k in Wt)
     _, _, lab2 = net2.predict_single_data(data)
     assert np.array_equal(lab2, lab_o)
+    # a trained file carries Keras' per-process layer counters (conv2d_14/...): matched by order, like load_weights
+    from pseg_amd import h5lite
+    layers = h5lite.read_keras_weights(path)
+    renamed = [("x%d_%s" % (i, n), [("x%d_%s" % (i, w), a) for w, a in ws]) for i, (n, ws) in enumerate(layers)]
+    h5lite.write_keras_weights(str(tmp_path / "renamed.h5"), [("input_1", [])] + renamed)
+    net3 = Network("Predict", n_classes=3, model=str(tmp_path / "renamed.h5"), exact=True)
+    assert all(np.array_equal(net3.model.get_weights()[k], Wt[k]) for k in Wt)
+    with pytest.raises(Exception, match="weight tensors|shape"):
+        Network("Predict", n_classes=6, model=str(tmp_path / "model.h5"), exact=True)     # wrong class count
+    # the native .npz format still works
+    assert net.save_weights(str(tmp_path / "m2.npz")).endswith(".npz")
+    net4 = Network("Predict", n_classes=3, model=str(tmp_path / "m2.npz"), exact=True)
+    assert all(np.array_equal(net4.model.get_weights()[k], Wt[k]) for k in Wt)
 
 
 def test_char_height_via_api(gpu, oracle_mod, tmp_path):

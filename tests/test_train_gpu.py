@@ -132,7 +132,7 @@ def test_trainer_api_end_to_end(gpu, oracle_mod, tmp_path):
     assert np.mean(hist["loss"][-2:]) < hist["loss"][0]            # it learns
     ev = tr.eval()
     assert set(ev) == {"loss", "accuracy", "jacard_coef", "dice_coef"} and np.isfinite(ev["loss"])
-    assert (tmp_path / "model.npz").exists()
+    assert (tmp_path / "model.h5").exists()                       # lib/network.py:177-178: <output_dir>/model.h5
     net = Network("Predict", n_classes=3, model=str(tmp_path / "model"), exact=True)
     lab = net.predict_single_data(settings.validation_data.data[0])[2]
     assert lab.shape == (96, 96)

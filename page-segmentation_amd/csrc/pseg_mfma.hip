@@ -872,6 +872,77 @@ __global__ __launch_bounds__(256) void tail_composed_kernel(TailC a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone logits layer (1x1 conv -> softmax / argmax) for graphs whose tail does not fuse
+// (unet, res_unet): one MFMA GEMM per 16 pixels, rows = classes, K = channels; every B fragment is
+// one coalesced 16-byte load per lane (no LDS).  HBM-bound: reads the last activation once.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logits_mfma_kernel(const uint16_t* src0, int nch0, const uint16_t* src1, int nch1,
+                                                          int Wp, int H0, int W0, int C, const uint16_t* wA /*[ks][64][8]*/,
+                                                          const float* bias /*[16]*/, float* out_logits, float* out_probs,
+                                                          int64_t* out_labels, uint8_t* out_labels_u8) {
+    const int lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tiles_x = (W0 + 15) >> 4;
+    const int y = wv / tiles_x, x = (wv - y * tiles_x) * 16 + p16;
+    if (y >= H0) return;
+    const bool inb = x < W0;
+    const size_t px = (size_t)y * Wp + (inb ? x : 0);
+    const int nks = (nch0 + nch1 + 3) >> 2;
+    const float4 b = *(const float4*)(bias + 4 * g);
+    f32x4 acc = f32x4{b.x, b.y, b.z, b.w};
+    for (int s = 0; s < nks; ++s) {
+        const int ch = 4 * s + g;
+        uint4 xb = make_uint4(0, 0, 0, 0);
+        if (ch < nch0) xb = *(const uint4*)(src0 + (px * nch0 + ch) * 8);
+        else if (ch < nch0 + nch1) xb = *(const uint4*)(src1 + (px * nch1 + (ch - nch0)) * 8);
+        const bf16x8 w = *(const bf16x8*)(wA + ((size_t)s * 64 + lane) * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+    }
+    // lane (p16, g) holds classes 4g..4g+3 of pixel p16
+    float bv = -3.4e38f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool take = (4 * g + r < C) & (acc[r] > bv);
+        bv = take ? acc[r] : bv;
+        bi = take ? 4 * g + r : bi;
+    }
+    if (C > 4) {
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+            const float ov = __shfl_xor(bv, sh);
+            const int oi = __shfl_xor(bi, sh);
+            const bool take = (ov > bv) | ((ov == bv) & (oi < bi));
+            bv = take ? ov : bv;
+            bi = take ? oi : bi;
+        }
+    }
+    const size_t p = (size_t)y * W0 + x;
+    if (inb && g == 0) {
+        if (out_labels_u8) out_labels_u8[p] = (uint8_t)bi;
+        if (out_labels) out_labels[p] = bi;
+    }
+    if (out_logits && inb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < C) out_logits[p * C + 4 * g + r] = acc[r];
+    if (out_probs) {
+        float ex[4], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ex[r] = (4 * g + r < C) ? expf(acc[r] - bv) : 0.f; sum += ex[r]; }
+        if (C > 4) {
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+        }
+        if (inb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < C) out_probs[p * C + 4 * g + r] = ex[r] / sum;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // first layer, Cin = 1: VALU direct conv straight from the uint8 page (fuses x/255 and the
 // pad-to-32).  0.9 % of the FLOPs; K = 25 is too short for MFMA.  Sequential fmaf chain in tap
@@ -1314,6 +1385,22 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         }
         for (int c = 0; c < Cout; ++c) bb[c] = bias[c];
         PSEG_TRY(upload(&P->d_wf, wf));
+        // MFMA form: A fragments [k-step][lane = (class, g)][8 channels of chunk 4s + g], bias padded to 16
+        const int nks = cdiv((Cs0 + Cs1) / 8, 4);
+        std::vector<uint16_t> wa((size_t)nks * 64 * 8, 0);
+        for (int sidx = 0; sidx < nks; ++sidx)
+            for (int l = 0; l < 64; ++l) {
+                const int cls = l & 15, chunk = 4 * sidx + (l >> 4);
+                if (cls >= Cout) continue;
+                for (int j = 0; j < 8; ++j) {
+                    const int cs = chunk * 8 + j;
+                    if (cs >= Cs0 + Cs1) continue;
+                    const int ci = cs < Cs0 ? (cs < C0 ? cs : -1) : (cs - Cs0 < C1 ? C0 + cs - Cs0 : -1);
+                    if (ci >= 0) wa[((size_t)sidx * 64 + l) * 8 + j] = f2bf(w[(size_t)ci * Cout + cls]);
+                }
+            }
+        PSEG_TRY(upload(&P->d_wpk, wa));
+        bb.resize(16, 0.0f);
         PSEG_TRY(upload(&P->d_bias, bb));
         return PSEG_OK;
     }
@@ -1599,6 +1686,9 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, 0)            // conv5
     PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, FL_POOL)      // conv6
     PSEG_TRY_INST(4, 5, 5, 1, 6, MODE_CONV, 0)            // conv7, deconv1
+    PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, 0)            // unet: k3 convs (64..1024 channels, 32-channel blocks)
+    PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, FL_POOL)      // unet: k3 conv + fused pool
+    PSEG_TRY_INST(4, 4, 2, 1, 6, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv
     PSEG_TRY_INST(4, 5, 1, 1, 10, MODE_DECONV, 0)         // deconv2
     PSEG_TRY_INST(4, 4, 1, 1, 14, MODE_DECONV, 0)         // deconv4 (fcn_skip)
     PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_DECONV, 0)          // deconv4 (fcn)
@@ -1843,6 +1933,13 @@ int mfma_launch_logits(Engine& e, Op& op, float* d_logits, float* d_probs, int64
     const uint16_t* p0 = (const uint16_t*)s0.d;
     const uint16_t* p1 = s1 ? (const uint16_t*)s1->d : nullptr;
     const int n0 = s0.Cs / 8, n1 = s1 ? s1->Cs / 8 : 0;
+    if (!getenv("PSEG_LOGITS_VALU")) {
+        const int waves = e.H * cdiv(e.W, 16);
+        logits_mfma_kernel<<<cdiv(waves, 4), 256, 0, st>>>(p0, n0, p1, n1, e.Wp, e.H, e.W, op.Cout, P->d_wpk, P->d_bias,
+                                                          d_logits, d_probs, d_labels, d_labels_u8);
+        PSEG_HIP(hipGetLastError());
+        return PSEG_OK;
+    }
 #define LG(CM) logits_bf16_kernel<CM><<<grid, 256, 0, st>>>(p0, n0, p1, n1, e.Wp, e.H, e.W, P->d_wf, P->d_bias, \
                                                               op.Cout, d_logits, d_probs, d_labels, d_labels_u8)
     if (P->cmax == 4) LG(4);

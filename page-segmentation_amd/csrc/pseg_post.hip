@@ -50,25 +50,47 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
     }
 }
 
+// Row pass without atomics: a wave covers 64 consecutive pixels; a ballot of the lanes that do NOT
+// continue their left neighbour's run gives every lane the start of its run inside the wave, which
+// becomes its label directly (roots stay the minimum linear index).  Only a run that continues
+// across the wave's first lane needs a union, done by the column kernel after all labels exist.
 template <int MODE>
-__global__ void ccl_init_kernel(const uint8_t* bin, const int64_t* cls, int* L, int n) {
+__global__ __launch_bounds__(256) void ccl_rows_kernel(const uint8_t* bin, const int64_t* cls, int* L, int H, int W) {
+    const int n = H * W;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) L[p] = is_fg<MODE>(bin, cls, p) ? p : -1;
+    const int lane = threadIdx.x & 63;
+    bool fg = false, link = false;
+    if (p < n) {
+        fg = is_fg<MODE>(bin, cls, p);
+        const int x = p % W;
+        link = fg && x > 0 && is_fg<MODE>(bin, cls, p - 1) && connects<MODE>(bin, cls, p, p - 1);
+    }
+    const unsigned long long brk = __ballot(!link);                 // lanes that start a run (or are background)
+    const unsigned long long upto = brk & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const int s = upto ? 63 - __clzll((long long)upto) : 0;          // run start lane (0: the run entered the wave)
+    if (p < n) L[p] = fg ? p - (lane - s) : -1;
 }
 
-// Row pass first (left neighbour) keeps most unions inside a cache line; then the column pass.
+// Column pass + the row unions across wave boundaries.  A vertical union is only issued where an
+// overlap between the run above and this run begins: if the left neighbours are linked along both
+// rows and vertically, their union already joins the same two runs.
 template <int MODE>
-__global__ void ccl_merge_kernel(const uint8_t* bin, const int64_t* cls, int* L, int H, int W,
-                                 int vertical) {
+__global__ __launch_bounds__(256) void ccl_cols_kernel(const uint8_t* bin, const int64_t* cls, int* L, int H, int W) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= H * W) return;
     if (!is_fg<MODE>(bin, cls, p)) return;
     const int y = p / W, x = p - y * W;
-    if (!vertical) {
-        if (x > 0 && connects<MODE>(bin, cls, p, p - 1)) uf_union(L, p, p - 1);
-    } else {
-        if (y > 0 && connects<MODE>(bin, cls, p, p - W)) uf_union(L, p, p - W);
+    const bool link = x > 0 && is_fg<MODE>(bin, cls, p - 1) && connects<MODE>(bin, cls, p, p - 1);
+    if (link && (threadIdx.x & 63) == 0) uf_union(L, p, p - 1);    // run continues from the previous wave
+    if (y == 0) return;
+    const int q = p - W;
+    if (!(is_fg<MODE>(bin, cls, q) && connects<MODE>(bin, cls, p, q))) return;
+    if (link) {
+        const bool link_up = is_fg<MODE>(bin, cls, q - 1) && connects<MODE>(bin, cls, q, q - 1);
+        const bool up_left = is_fg<MODE>(bin, cls, q - 1) && connects<MODE>(bin, cls, p - 1, q - 1);
+        if (link_up && up_left) return;
     }
+    uf_union(L, p, q);
 }
 
 __global__ void ccl_compress_kernel(int* L, int n) {
@@ -81,9 +103,8 @@ static int ccl_run(const uint8_t* d_bin, const int64_t* d_cls, int* d_L, int H, 
                    hipStream_t st) {
     const int n = H * W;
     const int grid = cdiv(n, 256);
-    ccl_init_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, n);
-    ccl_merge_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W, 0);
-    ccl_merge_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W, 1);
+    ccl_rows_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
+    ccl_cols_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
     ccl_compress_kernel<<<grid, 256, 0, st>>>(d_L, n);
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
@@ -138,11 +159,25 @@ static int cc_vote_device(int64_t* d_pred, const uint8_t* d_bin, int H, int W, i
     if ((int64_t)H * W * std::max(ncls, 1) > 0x7fffffffLL)
         return fail(PSEG_EUNSUPPORTED, "page too large for 32-bit component indices");
     const int n = H * W;
-    int* d_L = nullptr;
-    int* d_hist = nullptr;
-    PSEG_HIP(hipMalloc((void**)&d_L, (size_t)n * 4));
-    hipError_t he = hipMalloc((void**)&d_hist, (size_t)n * ncls * 4);
-    if (he != hipSuccess) { (void)hipFree(d_L); return fail(PSEG_ENOMEM, "hipMalloc(hist) failed"); }
+    // label + histogram workspace: grow-only, cached per calling thread and device (a 4096x3072 6-class
+    // page needs 50 + 302 MB; allocating and freeing it per call cost more than the kernels)
+    int dev = 0;
+    PSEG_HIP(hipGetDevice(&dev));
+    struct Ws { void* p = nullptr; size_t bytes = 0; };
+    static thread_local Ws ws[64][2];
+    auto need = [&](int slot, size_t bytes) -> void* {
+        Ws& w = ws[dev & 63][slot];
+        if (w.bytes < bytes) {
+            if (w.p) (void)hipFree(w.p);
+            w.p = nullptr; w.bytes = 0;
+            if (hipMalloc(&w.p, bytes) != hipSuccess) { w.p = nullptr; return nullptr; }
+            w.bytes = bytes;
+        }
+        return w.p;
+    };
+    int* d_L = (int*)need(0, (size_t)n * 4);
+    int* d_hist = (int*)need(1, (size_t)n * ncls * 4);
+    if (!d_L || !d_hist) return fail(PSEG_ENOMEM, "hipMalloc(vote workspace) failed");
     int rc = ccl_run<0>(d_bin, nullptr, d_L, H, W, st);
     if (rc == PSEG_OK) {
         (void)hipMemsetAsync(d_hist, 0, (size_t)n * ncls * 4, st);
@@ -152,10 +187,7 @@ static int cc_vote_device(int64_t* d_pred, const uint8_t* d_bin, int H, int W, i
         vote_apply_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, d_pred, n, ncls);
         if (hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "vote kernel launch failed");
     }
-    (void)hipStreamSynchronize(st);  // workspace is freed below
-    (void)hipFree(d_L);
-    (void)hipFree(d_hist);
-    return rc;
+    return rc;   // asynchronous on `st`; the cached workspace is reused by the next call on this thread (stream order)
 }
 
 // ---------------------------------------------------------------------------------------------

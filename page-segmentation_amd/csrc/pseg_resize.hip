@@ -71,21 +71,43 @@ static inline double ord_dec(unsigned long long e) {
     return d;
 }
 
-// stats[0] = min (encoded), stats[1] = max (encoded)
+// 16-byte vector loads for the two streaming reductions below: VEC elements per thread and trip
+template <typename T> struct Vec16;
+template <> struct Vec16<uint8_t> { static constexpr int N = 16; };
+template <> struct Vec16<double> { static constexpr int N = 2; };
+
+// calls f(value as double) for every element of src[0..n): 16-byte loads over the aligned body, scalar tail
+template <typename T, typename F>
+__device__ __forceinline__ void for_each_vec(const T* src, size_t n, F f) {
+    constexpr int N = Vec16<T>::N;
+    const size_t nv = n / N;
+    const uint4* sv = (const uint4*)src;     // hipMalloc'ed planes: 256-byte aligned
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        const uint4 v = sv[i];
+        T e[N];
+        memcpy(e, &v, 16);
+#pragma unroll
+        for (int k = 0; k < N; ++k) f((double)e[k]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nv * N) f((double)src[nv * N + threadIdx.x]);
+}
+
+// stats[0] = min (encoded), stats[1] = max (encoded); one atomic pair per workgroup
 template <typename T>
 __global__ __launch_bounds__(256) void minmax_kernel(const T* src, size_t n, unsigned long long* stats) {
-    unsigned long long mn = ~0ull, mx = 0ull;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const unsigned long long e = ord_enc((double)src[i]);
-        mn = e < mn ? e : mn;
-        mx = e > mx ? e : mx;
-    }
+    __shared__ unsigned long long smn[4], smx[4];
+    double lo = 1.0e308, hi = -1.0e308;
+    for_each_vec<T>(src, n, [&](double v) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; });
+    unsigned long long mn = ord_enc(lo), mx = ord_enc(hi);
     for (int sh = 32; sh >= 1; sh >>= 1) {
         const unsigned long long a = __shfl_xor(mn, sh), b = __shfl_xor(mx, sh);
         mn = a < mn ? a : mn;
         mx = b > mx ? b : mx;
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; }
         atomicMin(&stats[0], mn);
         atomicMax(&stats[1], mx);
     }
@@ -94,12 +116,12 @@ __global__ __launch_bounds__(256) void minmax_kernel(const T* src, size_t n, uns
 // stats[2] != 0  <=>  some value differs from both min and max  <=>  len(np.unique(img)) > 2
 template <typename T>
 __global__ __launch_bounds__(256) void third_value_kernel(const T* src, size_t n, unsigned long long* stats) {
-    const unsigned long long mn = stats[0], mx = stats[1];
+    const unsigned long long emn = stats[0], emx = stats[1];
+    const unsigned long long umn = (emn >> 63) ? (emn & 0x7fffffffffffffffull) : ~emn;
+    const unsigned long long umx = (emx >> 63) ? (emx & 0x7fffffffffffffffull) : ~emx;
+    const double lo = __longlong_as_double((long long)umn), hi = __longlong_as_double((long long)umx);
     bool any = false;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const unsigned long long e = ord_enc((double)src[i]);
-        any |= (e != mn) & (e != mx);
-    }
+    for_each_vec<T>(src, n, [&](double v) { any |= (v != lo) & (v != hi); });
     if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&stats[2], 1ull);
 }
 
@@ -215,7 +237,7 @@ static int stats_reset(unsigned long long* d_stats, hipStream_t st) {
 template <typename T>
 static int compute_stats(const T* d, size_t n, unsigned long long* d_stats, bool third, hipStream_t st) {
     PSEG_TRY(stats_reset(d_stats, st));
-    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    const int grid = (int)std::min<size_t>((n / Vec16<T>::N + 255) / 256 + 1, 1024);
     minmax_kernel<T><<<grid, 256, 0, st>>>(d, n, d_stats);
     if (third) third_value_kernel<T><<<grid, 256, 0, st>>>(d, n, d_stats);
     PSEG_HIP(hipGetLastError());

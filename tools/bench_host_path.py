@@ -1,0 +1,24 @@
+"""PCIe-inclusive rate of the host-buffer entry pseg_predict (never the bench `value`): uint8 page in
+host memory -> labels (and optionally logits / probabilities) back in host memory."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
+import numpy as np
+import torch
+torch.cuda.is_available()
+from pseg_amd import engine as E, synth
+H, W = 2048, 1536
+eng = E.Engine("fcn_skip", 3, mode=E.MODE_BF16)
+eng.set_weights(synth.glorot_weights(eng.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+img = synth.synth_page(1000, H, W, 3)[0]
+for name, kw in (("labels int64 only", dict(want_logits=False, want_probs=False)),
+                 ("labels + probabilities", dict(want_logits=False, want_probs=True)),
+                 ("logits + probabilities + labels (reference return)", dict())):
+    for _ in range(2):
+        eng.predict(img, **kw)
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        eng.predict(img, **kw)
+    dt = (time.perf_counter() - t0) / n
+    print("%-52s %7.2f ms/page  %7.1f Mpx/s" % (name, dt * 1e3, H * W / dt / 1e6))

@@ -22,6 +22,38 @@ __global__ __launch_bounds__(256) void k(const char* src, size_t span, int iters
     __syncthreads();
     if (threadIdx.x == 0 && lds[5] == 77) sink[0] = 1;
 }
+// same traffic through VGPRs: global_load_dwordx4 then ds_write_b128
+template <int INFLIGHT>
+__global__ __launch_bounds__(256) void kv(const char* src, size_t span, int iters, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    size_t off = ((size_t)blockIdx.x * 7919u * 4096u) % span;
+    for (int it = 0; it < iters; ++it) {
+        uint4 v[INFLIGHT];
+#pragma unroll
+        for (int j = 0; j < INFLIGHT; ++j)
+            v[j] = *(const uint4*)(src + ((off + (size_t)(j * 4 + wave) * 1024) % span) + lane * 16);
+#pragma unroll
+        for (int j = 0; j < INFLIGHT; ++j) *(uint4*)(lds + (j * 4 + wave) * 1024 + lane * 16) = v[j];
+        off = (off + INFLIGHT * 4096) % span;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && lds[5] == 77) sink[0] = 1;
+}
+template <int INFLIGHT>
+static void runv(const char* name, const char* d, size_t span, int wgs, int iters, unsigned* sink) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int lds = INFLIGHT * 4096;
+    hipFuncSetAttribute((const void*)kv<INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    kv<INFLIGHT><<<wgs, 256, lds>>>(d, span, 10, sink);
+    hipEventRecord(a);
+    kv<INFLIGHT><<<wgs, 256, lds>>>(d, span, iters, sink);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    const double bytes = (double)wgs * iters * INFLIGHT * 4096.0;
+    printf("%-28s inflight/wave %2d  WGs %4d: %.3f ms  %.1f GB/s  %.1f B/clk/CU (256 CUs, 2.4 GHz)\n", name, INFLIGHT, wgs, ms,
+           bytes / ms * 1e-6, bytes / (ms * 1e-3) / 256 / 2.4e9);
+}
 template <int INFLIGHT>
 static void run(const char* name, const char* d, size_t span, int wgs, int iters, unsigned* sink) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -45,6 +77,9 @@ int main() {
         run<4>("L2-resident 64 KiB", d, 64 * 1024, wgs, 400, sink);
         run<8>("L2-resident 64 KiB", d, 64 * 1024, wgs, 400, sink);
         run<8>("streamed 1 GiB", d, big, wgs, 400, sink);
+        runv<4>("VGPR path, L2-resident", d, 64 * 1024, wgs, 400, sink);
+        runv<8>("VGPR path, L2-resident", d, 64 * 1024, wgs, 400, sink);
+        runv<8>("VGPR path, streamed", d, big, wgs, 400, sink);
     }
     return 0;
 }

@@ -1415,6 +1415,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     int NTall = cdiv(Ntrue, 16);
     int NT = NTall <= 5 ? NTall : (NTall % 5 == 0 ? 5 : (NTall % 4 == 0 ? 4 : (NTall % 3 == 0 ? 3 : 4)));
     if (tail) NT = 4;   // two sub-pixels (four cout tiles) per N block: 64 accumulators per lane
+    // (all four sub-pixels of a k2 s2 transposed conv in one workgroup, NT = 8, was measured: 58 vs 38 us on
+    // deconv4 -- 128 accumulators spill at two waves per SIMD; two N blocks re-reading the tile from L2 win)
     P->NT = NT;
     P->nblocks_n = cdiv(NTall, NT);
     P->NTtot = P->nblocks_n * NT;
@@ -1690,7 +1692,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, FL_POOL)      // unet: k3 conv + fused pool
     PSEG_TRY_INST(4, 4, 2, 1, 6, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv
     PSEG_TRY_INST(4, 5, 1, 1, 10, MODE_DECONV, 0)         // deconv2
-    PSEG_TRY_INST(4, 4, 1, 1, 14, MODE_DECONV, 0)         // deconv4 (fcn_skip)
+    PSEG_TRY_INST(4, 4, 1, 1, 14, MODE_DECONV, 0)         // deconv4 (fcn_skip), two N blocks
     PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_DECONV, 0)          // deconv4 (fcn)
     PSEG_TRY_INST(4, 4, 1, 1, 10, MODE_TAIL, 0)           // deconv5 + logits (fcn_skip)
     PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_TAIL, 0)            // deconv5 + logits (fcn)
@@ -1706,7 +1708,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
         case 4: return launch_inst<4, 4, -1, -1, -1, -1, -1>(a, P, grid, st);
         case 5: return launch_inst<4, 5, -1, -1, -1, -1, -1>(a, P, grid, st);
     }
-    return fail(PSEG_EUNSUPPORTED, "no kernel instance for NT=%d", P.NT);
+    return fail(PSEG_EUNSUPPORTED, "no kernel instance for NT=%d (sigma %d)", P.NT, sg);
 }
 
 static int launch_generic_any(const MConv& a0, const MfmaPlan& P, dim3 grid, hipStream_t st, const char* layer) {

@@ -196,9 +196,9 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
     char* w_t = smem + a.lds_w_off;
     int* tab_l = (int*)(smem + a.lds_tab_off);
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: SALU address math
-    const int p16 = lane & 15, g = lane >> 4;
+    int tid = threadIdx.x, lane = tid & 63;
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: SALU address math
+    int p16 = lane & 15, g = lane >> 4;
     const int tiles_x = (a.Wout + TW - 1) / TW;
     int oy0, ox0, iy0, ix0;
     auto set_tile = [&](int t) {
@@ -282,6 +282,13 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
 
     for (int tile = blockIdx.x;;) {   // one trip unless FL_PERSIST
     const bool first_tile = !c_persist || tile == (int)blockIdx.x;
+    if constexpr (c_persist) {
+        // make the lane / wave ids opaque per trip: everything derived from them is then recomputed inside
+        // the trip (a few VALU ops) instead of being hoisted and kept live across the whole tile loop,
+        // which had cost the persistent variant its second wave per SIMD
+        asm volatile("" : "+v"(tid), "+v"(lane), "+v"(p16), "+v"(g));
+        asm volatile("" : "+s"(wave));
+    }
     if (c_persist && !first_tile) {
         set_tile(tile);
 #pragma unroll
@@ -357,30 +364,22 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
                 for (int q = 0; q < 2; ++q) w1[s1][q] = *(const bf16x8*)(a.f1_wpk + ((size_t)(s1 * 2 + q) * 64 + lane) * 8);
             const float4 b1a = *(const float4*)(a.f1_bias + 4 * g), b1b = *(const float4*)(a.f1_bias + 16 + 4 * g);
             lds_barrier();   // copies visible; does not drain the weight DMAs already in flight
-            constexpr int NMT = HR * HC / 16;                // 45 pixel tiles of 16 (HR*HC = 720)
-            // 45 tiles over 4 waves: every wave runs 12 (the surplus ones redo tile 44, same values), three
-            // independent tiles per trip so that the LDS-read -> MFMA -> convert -> LDS-write latencies of
-            // neighbouring tiles overlap
-            constexpr int TPW = (NMT + 3) / 4;
-            static_assert(TPW % 3 == 0, "tiles per wave must be a multiple of the unroll factor");
-            for (int j0 = 0; j0 < TPW; j0 += 3) {
-#pragma unroll
-            for (int uu = 0; uu < 3; ++uu) {
-                const int mt = min(wave + 4 * (j0 + uu), NMT - 1);
-                const int pi = mt * 16 + p16;
-                const int hr = (int)(((unsigned)pi * (65536u / HC + 1u)) >> 16), hx = pi - hr * HC;
-                const char* cb = f1 + (hx & 1) * (UR * UCB) + (hx & ~1) * 2;
+            // 20 halo rows x 36 halo columns = per row two full 16-pixel tiles + 4 columns; the remainder
+            // columns of four rows form one more tile (5 in all).  Full tiles: the row is wave-uniform
+            // (wave + 4j), so every address is a per-lane constant plus a scalar / immediate; remainder
+            // tiles carry their row in the lane.  Each wave runs 10 full + 2 remainder tiles (the second
+            // remainder slot is real only for wave 0 -- the others redo theirs, same values).
+            static_assert(HR == 20 && HC == 36, "conv1 tile walk is written for the 16x32 conv2 tile");
+            auto c1_tile = [&](const char* src, char* dst, bool inc) {
                 f32x4 z0 = f32x4{0.f, 0.f, 0.f, 0.f}, z1 = z0;
 #pragma unroll
                 for (int s1 = 0; s1 < 2; ++s1) {
-                    const int ky = s1 == 0 ? g : 4;          // rows past the kernel carry zero weights
-                    const uint32_t* rp = (const uint32_t*)(cb + (hr + ky) * UCB);
+                    // kernel row ky = g (first k-step) or 4 (second; rows past the kernel carry zero weights)
+                    const uint32_t* rp = (const uint32_t*)(src + (s1 == 0 ? g : 4) * UCB);
                     const uint4 xv = make_uint4(rp[0], rp[1], rp[2], rp[3]);
                     z0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s1][0], __builtin_bit_cast(bf16x8, xv), z0, 0, 0, 0);
                     z1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s1][1], __builtin_bit_cast(bf16x8, xv), z1, 0, 0, 0);
                 }
-                const int gy = oy0 - 2 + hr, gx = ox0 - 2 + hx;
-                const bool inc = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
                 float v0 = z0[0] + b1a.x, v1 = z0[1] + b1a.y, v2 = z0[2] + b1a.z, v3 = z0[3] + b1a.w;
                 float u0 = z1[0] + b1b.x, u1 = z1[1] + b1b.y, u2 = z1[2] + b1b.z, u3 = z1[3] + b1b.w;
                 if (a.f1_relu) {
@@ -389,11 +388,37 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
                 }
                 uint2 pa = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16), (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
                 uint2 pb = make_uint2((uint32_t)d_f2bf(u0) | ((uint32_t)d_f2bf(u1) << 16), (uint32_t)d_f2bf(u2) | ((uint32_t)d_f2bf(u3) << 16));
-                if (!inc) { pa = make_uint2(0, 0); pb = make_uint2(0, 0); }
-                char* dp = in_t + hr * a.row_pitch + hx * c_PS2;
-                *(uint2*)(dp + g * 8) = pa;                  // couts 4g .. 4g+3
-                if (g < 2) *(uint2*)(dp + 32 + g * 8) = pb;  // couts 16..19 (g = 0), zero pad 20..23 (g = 1)
+                if (!inc) { pa = make_uint2(0, 0); pb = make_uint2(0, 0); }   // halo outside the canvas = conv2's zero padding
+                *(uint2*)(dst + g * 8) = pa;                  // couts 4g .. 4g+3
+                if (g < 2) *(uint2*)(dst + 32 + g * 8) = pb;  // couts 16..19 (g = 0), zero pad 20..23 (g = 1)
+            };
+            // per-lane constants of the two full column tiles and of the remainder tile
+            const char* srcF[2]; char* dstF[2]; bool colF[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int hx = ct * 16 + p16, gx = ox0 - 2 + hx;
+                srcF[ct] = f1 + (hx & 1) * (UR * UCB) + (hx & ~1) * 2 + wave * UCB;
+                dstF[ct] = in_t + hx * c_PS2 + wave * a.row_pitch;
+                colF[ct] = gx >= 0 && gx < a.Win;
             }
+            const int step_dst = 4 * a.row_pitch;
+#pragma unroll
+            for (int j = 0; j < HR / 4; ++j) {
+                const int gy = oy0 - 2 + wave + 4 * j;
+                const bool rowok = gy >= 0 && gy < a.Hin;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) c1_tile(srcF[ct] + j * 4 * UCB, dstF[ct] + j * step_dst, rowok && colF[ct]);
+            }
+            {
+                const int hxR = 32 + (p16 & 3), hrL = p16 >> 2, gxR = ox0 - 2 + hxR;
+                const bool colR = gxR >= 0 && gxR < a.Win;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int q = (jj == 1 && wave == 0) ? 4 : wave;
+                    const int hr = 4 * q + hrL, gy = oy0 - 2 + hr;
+                    c1_tile(f1 + (hxR & 1) * (UR * UCB) + (hxR & ~1) * 2 + hr * UCB, in_t + hr * a.row_pitch + hxR * c_PS2,
+                            colR && gy >= 0 && gy < a.Hin);
+                }
             }
         } else if (!(c_dbg & 1) && !c_inrelu && nbi == 0) {
             // LDS-DMA staging (buffer_load_dwordx4 ... lds): lane L of one instruction fills
@@ -1838,11 +1863,11 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         a.lds_f1_off = P->lds_f1_off;
     }
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, P->NW * (P->MT / 2)), P->nblocks_n);
-    // persistent instance (opt-in, PSEG_PERSIST=1): resident weights (NB == 1), single channel block, two
-    // workgroups per CU walking 12 tiles each.  Measured on MI355X: 0.182 ms vs 0.173 ms for the plain
-    // one-tile-per-workgroup launch -- the weight DMA it saves was already hidden by the co-resident
-    // workgroup, and the extra live state costs registers (kept for experiments, off by default).
-    if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && getenv("PSEG_PERSIST") && !getenv("PSEG_GENERIC")) {
+    // persistent instance (PSEG_NO_PERSIST=1 disables): resident weights (NB == 1), single channel block, two
+    // workgroups per CU walking 12 tiles each: the 38 KB weight set and the k-chunk table are staged once per
+    // workgroup instead of once per tile.  Worth 1-3 % on the fused conv1+conv2 kernel (the DMA it saves was
+    // mostly hidden by the co-resident workgroup); needs the per-trip opaque lane ids to keep two waves per SIMD.
+    if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && !getenv("PSEG_NO_PERSIST") && !getenv("PSEG_GENERIC")) {
         static int cus = 0;   // one device model per process
         if (!cus) {
             int dev = 0;

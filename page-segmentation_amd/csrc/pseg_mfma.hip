@@ -46,6 +46,13 @@ static inline float bf2f(uint16_t h) {
 }
 
 __device__ __forceinline__ float d_bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+// two floats -> packed bf16 pair in ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, lo in bits 0..15)
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ uint16_t d_f2bf(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even
     return __builtin_bit_cast(uint16_t, b);
@@ -99,6 +106,12 @@ struct MConv {
 __device__ __forceinline__ float vmax(float a, float b) {
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max(v, value of lane ^ 1) in one instruction: DPP quad_perm [1,0,3,2] on the first operand
+__device__ __forceinline__ float vmax_xor1(float v) {
+    float r;
+    asm("v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
     return r;
 }
 // value of the neighbouring lane (lane ^ 1) by DPP quad_perm [1,0,3,2]: one VALU op, no LDS crossbar
@@ -280,6 +293,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
     int slot_n = D % a.NB;      // ring slot the next prefetch goes to
     PSEG_STAMP(1)
 
+    constexpr int F1_NU = 6;
+    float ubf[F1_NU];   // fused first layer: this lane's uint8 page values of the current / next tile
     for (int tile = blockIdx.x;;) {   // one trip unless FL_PERSIST
     const bool first_tile = !c_persist || tile == (int)blockIdx.x;
     if constexpr (c_persist) {
@@ -336,18 +351,21 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
             // LDS addresses are one per-lane base plus immediates; all loads are issued before first use.
             constexpr int NU = UR / 4;                       // 6 byte loads per lane
             static_assert(UR % 4 == 0, "uint8 tile rows must be a multiple of the wave count");
-            const int xg = ox0 - 4 + lane;
-            const bool colok = lane < HC + 4 && xg >= 0 && xg < a.f1_W;
-            const unsigned xo = colok ? (unsigned)xg : 0u;
-            float ubf[NU];
+            static_assert(NU <= F1_NU, "first-layer prefetch registers");
+            auto load_u8 = [&](int oy, int ox) {
+                const int xg = ox - 4 + lane;
+                const bool colok = lane < HC + 4 && xg >= 0 && xg < a.f1_W;
+                const unsigned xo = colok ? (unsigned)xg : 0u;
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int y = oy0 - 4 + wave + 4 * u;                       // wave-uniform
-                const bool rowok = y >= 0 && y < a.f1_H;
-                const uint8_t* rowp = a.f1_img + (size_t)(rowok ? y : 0) * (size_t)a.f1_W;
-                const uint8_t v = rowp[xo];
-                ubf[u] = (colok && rowok) ? (float)v : 0.0f;
-            }
+                for (int u = 0; u < NU; ++u) {
+                    const int y = oy - 4 + wave + 4 * u;                    // wave-uniform
+                    const bool rowok = y >= 0 && y < a.f1_H;
+                    const uint8_t* rowp = a.f1_img + (size_t)(rowok ? y : 0) * (size_t)a.f1_W;
+                    const uint8_t v = rowp[xo];
+                    ubf[u] = (colok && rowok) ? (float)v : 0.0f;
+                }
+            };
+            if (first_tile) load_u8(oy0, ox0);      // later tiles: requested one tile ahead (below)
             if (lane < 48) {
                 char* pA = f1 + wave * UCB + lane * 2;
 #pragma unroll
@@ -355,6 +373,15 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
                 if (lane >= 1) {
 #pragma unroll
                     for (int u = 0; u < NU; ++u) *(uint16_t*)(pA + UR * UCB - 2 + u * 4 * UCB) = d_f2bf(ubf[u] * 0.00392156886f);
+                }
+            }
+            if constexpr (c_persist) {
+                // the next tile's bytes are requested now: their latency hides under this tile's conv1 stage,
+                // k-loop and epilogue instead of opening the next trip
+                const int nt = tile + (int)gridDim.x;
+                if (nt < a.ntiles) {
+                    const int nty = nt / tiles_x, ntx = nt - nty * tiles_x;
+                    load_u8(nty * TH, ntx * TW);
                 }
             }
             bf16x8 w1[2][2];
@@ -386,8 +413,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
                     v0 = vmax(v0, 0.f); v1 = vmax(v1, 0.f); v2 = vmax(v2, 0.f); v3 = vmax(v3, 0.f);
                     u0 = vmax(u0, 0.f); u1 = vmax(u1, 0.f); u2 = vmax(u2, 0.f); u3 = vmax(u3, 0.f);
                 }
-                uint2 pa = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16), (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
-                uint2 pb = make_uint2((uint32_t)d_f2bf(u0) | ((uint32_t)d_f2bf(u1) << 16), (uint32_t)d_f2bf(u2) | ((uint32_t)d_f2bf(u3) << 16));
+                uint2 pa = make_uint2(pk_bf16(v0, v1), pk_bf16(v2, v3));
+                uint2 pb = make_uint2(pk_bf16(u0, u1), pk_bf16(u2, u3));
                 if (!inc) { pa = make_uint2(0, 0); pb = make_uint2(0, 0); }   // halo outside the canvas = conv2's zero padding
                 *(uint2*)(dst + g * 8) = pa;                  // couts 4g .. 4g+3
                 if (g < 2) *(uint2*)(dst + 32 + g * 8) = pb;  // couts 16..19 (g = 0), zero pad 20..23 (g = 1)
@@ -607,10 +634,10 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
                     const float4 b0 = biasr[2 * abl], b1 = biasr[2 * abl + 1];
                     const f32x4 t0 = acc[m][2 * abl], t1 = acc[m][2 * abl + 1];
                     uint4 dq;
-                    dq.x = (uint32_t)d_f2bf(t0[0] + b0.x) | ((uint32_t)d_f2bf(t0[1] + b0.y) << 16);
-                    dq.y = (uint32_t)d_f2bf(t0[2] + b0.z) | ((uint32_t)d_f2bf(t0[3] + b0.w) << 16);
-                    dq.z = (uint32_t)d_f2bf(t1[0] + b1.x) | ((uint32_t)d_f2bf(t1[1] + b1.y) << 16);
-                    dq.w = (uint32_t)d_f2bf(t1[2] + b1.z) | ((uint32_t)d_f2bf(t1[3] + b1.w) << 16);
+                    dq.x = pk_bf16(t0[0] + b0.x, t0[1] + b0.y);
+                    dq.y = pk_bf16(t0[2] + b0.z, t0[3] + b0.w);
+                    dq.z = pk_bf16(t1[0] + b1.x, t1[1] + b1.y);
+                    dq.w = pk_bf16(t1[2] + b1.z, t1[3] + b1.w);
                     f32x4 z = f32x4{lb.x, lb.y, lb.z, lb.w};
                     z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, dq), z, 0, 0, 0);
                     if (a.skip)
@@ -683,8 +710,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
                     v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
                     v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
                 }
-                const uint2 pk = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16),
-                                            (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
+                const uint2 pk = make_uint2(pk_bf16(v0, v1),
+                                            pk_bf16(v2, v3));
                 const size_t o = ((size_t)(2 * y + (ab >> 1)) * (2 * a.Wout) + (2 * x + (ab & 1))) * (a.nch_out * 8) + co;
                 *(uint2*)(a.dst + o) = pk;
             }
@@ -729,8 +756,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[m][r] = vmax(v[m][r], 0.0f);
             }
-            const uint2 pk = make_uint2((uint32_t)d_f2bf(v[m][0]) | ((uint32_t)d_f2bf(v[m][1]) << 16),
-                                        (uint32_t)d_f2bf(v[m][2]) | ((uint32_t)d_f2bf(v[m][3]) << 16));
+            const uint2 pk = make_uint2(pk_bf16(v[m][0], v[m][1]),
+                                        pk_bf16(v[m][2], v[m][3]));
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
         }
         if (c_pool) {
@@ -741,15 +768,14 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
                 float q[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    q[r] = vmax(v[m][r], v[m + 2][r]);
-                    q[r] = vmax(q[r], lane_xor1(q[r]));
+                    q[r] = vmax_xor1(vmax(v[m][r], v[m + 2][r]));
                 }
                 const int y = (oy0 >> 1) + ((wave * (MT / 2) + (m >> 1)) >> 1);
                 const int x = (ox0 >> 1) + (((m & 1) * 16 + p16) >> 1);
                 const bool ok = !(p16 & 1) && y < Ho2 && x < Wo2 && noff != OOBS;
                 const unsigned o = ok ? (unsigned)(y * Wo2 + x) * (unsigned)(CsO * 2) + noff : OOBS;
-                const uint2 pk = make_uint2((uint32_t)d_f2bf(q[0]) | ((uint32_t)d_f2bf(q[1]) << 16),
-                                            (uint32_t)d_f2bf(q[2]) | ((uint32_t)d_f2bf(q[3]) << 16));
+                const uint2 pk = make_uint2(pk_bf16(q[0], q[1]),
+                                            pk_bf16(q[2], q[3]));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rp, o, 0, 0);
             }
         }
@@ -1094,8 +1120,8 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const uint8_t* img, int
                 v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
             }
             if (n < CS)
-                *(uint2*)(dst + o + n) = make_uint2((uint32_t)d_f2bf(v0) | ((uint32_t)d_f2bf(v1) << 16),
-                                                    (uint32_t)d_f2bf(v2) | ((uint32_t)d_f2bf(v3) << 16));
+                *(uint2*)(dst + o + n) = make_uint2(pk_bf16(v0, v1),
+                                                    pk_bf16(v2, v3));
         }
     }
 }

@@ -83,6 +83,13 @@ int pseg_predict(pseg_engine* e, const uint8_t* img, int H, int W, float* logits
 int pseg_predict_device(pseg_engine* e, const uint8_t* d_img, int H, int W, float* d_logits,
                         float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8, void* stream);
 
+/* Predictor.predict (lib/predictor.py:27-30): label maps of a list of pages of individual sizes.
+ * The upload of page i+1 and the download of page i-1 overlap the compute of page i (two staging
+ * slots, separate copy streams).  labels[i] (int64, H[i]*W[i]) and/or labels_u8[i]; either array may
+ * be NULL, not both.  Host pointers; returns when every page is back. */
+int pseg_predict_batch(pseg_engine* e, int n_pages, const uint8_t* const* imgs, const int* H,
+                       const int* W, int64_t* const* labels, uint8_t* const* labels_u8);
+
 /* Copy an intermediate activation to the host as float32 NHWC (true channel count) --
  * layer-by-layer parity tests.  `layer` is the Keras layer name.  dims[3] = {H,W,C} of the
  * padded canvas at that layer.  Valid after a predict call. */

@@ -126,6 +126,7 @@ struct Engine {
     float* d_logit_stage = nullptr;
     size_t lab_stage_bytes = 0, prob_stage_bytes = 0, logit_stage_bytes = 0;
     void* train = nullptr;   // TrainState (pseg_train.hip), f32 mode only
+    void* batch = nullptr;   // BatchState (pseg_predict_batch): copy streams, events, two staging slots
     // timing
     bool timing = false;
     std::vector<TimingSlot> slots;

@@ -502,6 +502,102 @@ static int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* 
     return run_exact(e, d_img, d_logits, d_probs, d_labels, d_labels_u8, st);
 }
 
+// ---- page batches: copies of neighbouring pages overlap the compute of the current one -----------
+struct BatchState {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t up[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, down[2] = {nullptr, nullptr};
+    uint8_t* d_img[2] = {nullptr, nullptr};
+    void* d_lab[2] = {nullptr, nullptr};
+    size_t img_bytes[2] = {0, 0}, lab_bytes[2] = {0, 0};
+};
+
+static void batch_free(Engine& e) {
+    auto* b = (BatchState*)e.batch;
+    if (!b) return;
+    for (int i = 0; i < 2; ++i) {
+        if (b->up[i]) (void)hipEventDestroy(b->up[i]);
+        if (b->done[i]) (void)hipEventDestroy(b->done[i]);
+        if (b->down[i]) (void)hipEventDestroy(b->down[i]);
+        free_dev((void*&)b->d_img[i]);
+        free_dev(b->d_lab[i]);
+    }
+    if (b->s_in) (void)hipStreamDestroy(b->s_in);
+    if (b->s_out) (void)hipStreamDestroy(b->s_out);
+    delete b;
+    e.batch = nullptr;
+}
+
+static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int* H, const int* W,
+                         int64_t* const* labels, uint8_t* const* labels_u8) {
+    PSEG_HIP(hipSetDevice(e.device));
+    if (!e.batch) {
+        auto* nb = new BatchState();
+        e.batch = nb;
+        PSEG_HIP(hipStreamCreateWithFlags(&nb->s_in, hipStreamNonBlocking));
+        PSEG_HIP(hipStreamCreateWithFlags(&nb->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            PSEG_HIP(hipEventCreateWithFlags(&nb->up[i], hipEventDisableTiming));
+            PSEG_HIP(hipEventCreateWithFlags(&nb->done[i], hipEventDisableTiming));
+            PSEG_HIP(hipEventCreateWithFlags(&nb->down[i], hipEventDisableTiming));
+        }
+    }
+    auto* b = (BatchState*)e.batch;
+    const size_t lab_esz = labels ? 8 : 1;
+    auto upload = [&](int i) -> int {        // page i -> slot i % 2 (its previous compute has been waited for)
+        const int s = i & 1;
+        const size_t npx = (size_t)H[i] * W[i];
+        PSEG_TRY(ensure((void**)&b->d_img[s], &b->img_bytes[s], npx * e.in_ch));
+        PSEG_TRY(ensure(&b->d_lab[s], &b->lab_bytes[s], npx * (labels ? 8 : 0) + npx * (labels_u8 ? 1 : 0) + 16));
+        PSEG_HIP(hipStreamWaitEvent(b->s_in, b->done[s], 0));      // slot input consumed (no-op before first record)
+        PSEG_HIP(hipMemcpyAsync(b->d_img[s], imgs[i], npx * e.in_ch, hipMemcpyHostToDevice, b->s_in));
+        PSEG_HIP(hipEventRecord(b->up[s], b->s_in));
+        return PSEG_OK;
+    };
+    auto compute = [&](int i) -> int {
+        const int s = i & 1;
+        const size_t npx = (size_t)H[i] * W[i];
+        // a canvas change re-allocates / clears the activation tensors: the previous page must have left them
+        if (round_up(H[i], 32) != e.Hp || round_up(W[i], 32) != e.Wp) PSEG_HIP(hipStreamSynchronize(e.stream));
+        PSEG_HIP(hipStreamWaitEvent(e.stream, b->up[s], 0));
+        PSEG_HIP(hipStreamWaitEvent(e.stream, b->down[s], 0));      // slot output of page i-2 has left
+        int64_t* dl = labels ? (int64_t*)b->d_lab[s] : nullptr;
+        uint8_t* du = labels_u8 ? (uint8_t*)b->d_lab[s] + (labels ? npx * 8 : 0) : nullptr;
+        PSEG_TRY(predict_device(e, b->d_img[s], H[i], W[i], nullptr, nullptr, dl, du, e.stream));
+        PSEG_HIP(hipEventRecord(b->done[s], e.stream));
+        return PSEG_OK;
+    };
+    auto download = [&](int i) -> int {
+        const int s = i & 1;
+        const size_t npx = (size_t)H[i] * W[i];
+        PSEG_HIP(hipStreamWaitEvent(b->s_out, b->done[s], 0));
+        if (labels) PSEG_HIP(hipMemcpyAsync(labels[i], b->d_lab[s], npx * 8, hipMemcpyDeviceToHost, b->s_out));
+        if (labels_u8)
+            PSEG_HIP(hipMemcpyAsync(labels_u8[i], (uint8_t*)b->d_lab[s] + (labels ? npx * 8 : 0), npx, hipMemcpyDeviceToHost, b->s_out));
+        PSEG_HIP(hipEventRecord(b->down[s], b->s_out));
+        return PSEG_OK;
+    };
+    (void)lab_esz;
+    // a reallocation of a slot must not race with work still using it: drain when sizes grow
+    for (int i = 0; i < n; ++i) {
+        if (H[i] <= 0 || W[i] <= 0 || !imgs[i] || (labels && !labels[i]) || (labels_u8 && !labels_u8[i]))
+            return fail(PSEG_EINVAL, "page %d: empty shape or NULL buffer", i);
+    }
+    size_t max_px = 0;
+    for (int i = 0; i < n; ++i) max_px = std::max(max_px, (size_t)H[i] * W[i]);
+    for (int s = 0; s < 2; ++s) {
+        PSEG_TRY(ensure((void**)&b->d_img[s], &b->img_bytes[s], max_px * e.in_ch));
+        PSEG_TRY(ensure(&b->d_lab[s], &b->lab_bytes[s], max_px * 9 + 16));
+    }
+    if (n > 0) { PSEG_TRY(upload(0)); PSEG_TRY(compute(0)); }
+    for (int i = 0; i < n; ++i) {
+        if (i + 1 < n) { PSEG_TRY(upload(i + 1)); PSEG_TRY(compute(i + 1)); }
+        PSEG_TRY(download(i));
+    }
+    PSEG_HIP(hipStreamSynchronize(b->s_out));
+    PSEG_HIP(hipStreamSynchronize(e.stream));
+    return PSEG_OK;
+}
+
 }  // namespace pseg
 
 // =============================================================================================
@@ -565,6 +661,7 @@ int pseg_destroy(pseg_engine* h) {
     (void)hipSetDevice(e.device);
     if (e.stream) (void)hipStreamSynchronize(e.stream);
     train_free(e);
+    batch_free(e);
     for (auto& t : e.tensors) free_dev(t.d);
     for (auto& op : e.ops) {
         free_dev((void*&)op.d_w);
@@ -659,6 +756,13 @@ int pseg_predict(pseg_engine* h, const uint8_t* img, int H, int W, float* logits
     if (labels) PSEG_HIP(hipMemcpyAsync(labels, e.d_lab_stage, npx * 8, hipMemcpyDeviceToHost, e.stream));
     PSEG_HIP(hipStreamSynchronize(e.stream));
     return PSEG_OK;
+}
+
+int pseg_predict_batch(pseg_engine* h, int n_pages, const uint8_t* const* imgs, const int* H, const int* W,
+                       int64_t* const* labels, uint8_t* const* labels_u8) {
+    if (!h || n_pages < 0 || (n_pages > 0 && (!imgs || !H || !W))) return fail(PSEG_EINVAL, "bad argument");
+    if (!labels && !labels_u8) return fail(PSEG_EINVAL, "no output requested");
+    return predict_batch(h->e, n_pages, imgs, H, W, labels, labels_u8);
 }
 
 // bf16 -> f32 helper for activation read-back

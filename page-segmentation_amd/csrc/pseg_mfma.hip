@@ -1476,8 +1476,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->KS = KS;
     P->stride = deconv ? 1 : op.stride;
     // 8-wave workgroups (16-row tiles, the whole CU's LDS) exist for the k5 stride-1 mid-layer shapes
-    P->nw8_ok = !deconv && KS == 5 && op.stride == 1 && P->MT == 4 && (NT == 3 || NT == 4) && !op.up0 && !op.up1 &&
-                !op.in_relu && op.add < 0 && op.fuse1 < 0 && P->nblocks_n == 1 && !getenv("PSEG_GENERIC") && !getenv("PSEG_NO_NW8");
+    P->nw8_ok = !deconv && (KS == 5 || (KS == 3 && NT == 4)) && op.stride == 1 && P->MT == 4 && (NT == 3 || NT == 4) && !op.up0 && !op.up1 &&
+                !op.in_relu && op.add < 0 && op.fuse1 < 0 && (P->nblocks_n == 1 || KS == 3) && !getenv("PSEG_GENERIC") && !getenv("PSEG_NO_NW8");
     P->NW = (P->nw8_ok && op.nw_hint == 8) ? 8 : 4;
     const int TH = P->NW * (P->MT / 2);
     const int totc = (Cs0 + Cs1) / 8;
@@ -1725,6 +1725,8 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST8(4, 3, 5, 1, 6, MODE_CONV, FL_POOL)     // conv4
     PSEG_TRY_INST8(4, 4, 5, 1, 6, MODE_CONV, 0)           // conv5
     PSEG_TRY_INST8(4, 4, 5, 1, 6, MODE_CONV, FL_POOL)     // conv6
+    PSEG_TRY_INST8(4, 4, 3, 1, 6, MODE_CONV, 0)           // unet k3 convs, 16-row tiles
+    PSEG_TRY_INST8(4, 4, 3, 1, 6, MODE_CONV, FL_POOL)
 #undef PSEG_TRY_INST8
     if (P.NW != 4) return fail(PSEG_EUNSUPPORTED, "no 8-wave kernel instance for this layer shape");
 #define PSEG_TRY_INST(MT_, NT_, KS_, ST_, SG_, MODE_, FL_)                                          \

@@ -61,3 +61,24 @@ def test_predict_errors(gpu, oracle_mod):
     with pytest.raises(gpu.PsegError):      # unknown name
         eng.set_weights({"nope/kernel": np.zeros((1,), np.float32)})
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_predict_batch_matches_single_pages(gpu, oracle_mod, mode):
+    """pseg_predict_batch (overlapped copies, two staging slots) == page-by-page predict, ragged sizes,
+    more pages than slots, both label dtypes, empty batch."""
+    rng = np.random.default_rng(3)
+    shapes = [(64, 96), (33, 50), (96, 64), (64, 96), (70, 17), (128, 160), (32, 32)]
+    pages = [rng.integers(0, 256, s, dtype=np.uint8) for s in shapes]
+    eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16 if mode == "bf16" else gpu.MODE_F32_EXACT)
+    eng.set_weights(oracle_mod.init_weights("fcn_skip", 3, seed=42, gain=1.5, bias_scale=0.05))
+    want = [eng.predict(p, want_logits=False, want_probs=False)[2] for p in pages]
+    got = eng.predict_batch(pages)
+    got8 = eng.predict_batch(pages, dtype=np.uint8)
+    assert len(got) == len(pages) and eng.predict_batch([]) == []
+    for w, g, g8 in zip(want, got, got8):
+        assert g.dtype == np.int64 and g8.dtype == np.uint8
+        assert np.array_equal(g, w) and np.array_equal(g8, w)
+    again = eng.predict_batch(pages[::-1])
+    assert all(np.array_equal(a, w) for a, w in zip(again, want[::-1]))
+    eng.close()

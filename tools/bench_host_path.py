@@ -22,3 +22,12 @@ for name, kw in (("labels int64 only", dict(want_logits=False, want_probs=False)
         eng.predict(img, **kw)
     dt = (time.perf_counter() - t0) / n
     print("%-52s %7.2f ms/page  %7.1f Mpx/s" % (name, dt * 1e3, H * W / dt / 1e6))
+
+pages = [synth.synth_page(1000 + i, H, W, 3)[0] for i in range(8)]
+for dt, name in ((np.int64, "predict_batch, int64 labels (8 pages, reused out)"), (np.uint8, "predict_batch, uint8 labels (8 pages, reused out)")):
+    outs = eng.predict_batch(pages, dtype=dt)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.predict_batch(pages, dtype=dt, out=outs)
+    dt_ = (time.perf_counter() - t0) / (3 * len(pages))
+    print("%-52s %7.2f ms/page  %7.1f Mpx/s" % (name, dt_ * 1e3, H * W / dt_ / 1e6))

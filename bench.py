@@ -49,12 +49,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal knobs (not used by the driver): PSEG_BENCH_BACKEND=gloo and PSEG_BENCH_ONE_GPU=1 run the
+    # N > 1 code path with several ranks on a one-GPU box (gloo barrier / max-reduce, every rank on cuda:0)
+    backend = os.environ.get("PSEG_BENCH_BACKEND", "nccl")
+    if os.environ.get("PSEG_BENCH_ONE_GPU"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(local_rank)
@@ -93,7 +101,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -116,6 +116,13 @@ int pseg_timing_get(pseg_engine* e, int slot, char* name, size_t name_cap, doubl
 int pseg_train_init(pseg_engine* e, float beta1, float beta2, float eps, float clipnorm,
                     float clipvalue);
 
+/* Optimizers (lib/architecture.py:71-90), each with Keras' TF 2.5 default hyper-parameters -- the
+ * reference passes only lr / clipnorm / clipvalue (lib/network.py:92-102).  Default after
+ * pseg_train_init: Adam.  Switching resets the optimizer state and the step count. */
+enum { PSEG_OPT_ADAM = 0, PSEG_OPT_ADAMAX = 1, PSEG_OPT_ADADELTA = 2, PSEG_OPT_ADAGRAD = 3,
+       PSEG_OPT_RMSPROP = 4, PSEG_OPT_SGD = 5, PSEG_OPT_NADAM = 6 };
+int pseg_train_set_optimizer(pseg_engine* e, int optimizer);
+
 /* One sample (batch of one page, as the reference: lib/network.py:151-153): forward, mean sparse
  * softmax cross-entropy + metrics, backward.  img uint8 (H,W), mask uint8 class ids (H,W), host
  * pointers.  metrics = {loss, accuracy, jacard_coef, dice_coef} of this sample.  Gradients stay

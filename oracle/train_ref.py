@@ -82,3 +82,62 @@ class KerasAdam:
             self.m[k], self.v[k] = m, v
             out[k] = (w.astype(np.float64) - lr_t * m / (np.sqrt(v) + self.eps)).astype(np.float32)
         return out
+
+
+class KerasOptimizer:
+    """NumPy restatement (float64) of the TF 2.5 Keras optimizer_v2 update rules with their default
+    hyper-parameters, per-tensor clip_by_norm first -- the reference's Optimizers enum
+    (lib/architecture.py:71-90).  TensorFlow cannot run here: unpinned against TF itself."""
+
+    def __init__(self, name, lr, clipnorm=1.0):
+        self.name, self.lr, self.clipnorm = name, lr, clipnorm
+        self.t = 0
+        self.m, self.v = {}, {}
+        self.m_schedule = 1.0
+
+    def apply(self, Wt, grads):
+        self.t += 1
+        t, lr, b1, b2, eps = self.t, self.lr, 0.9, 0.999, 1e-7
+        for k, w in Wt.items():
+            g = grads[k].astype(np.float64)
+            if self.clipnorm and self.clipnorm > 0:
+                n = np.sqrt((g * g).sum())
+                g = g * self.clipnorm / max(n, self.clipnorm)
+            m = self.m.get(k, np.zeros_like(g))
+            v = self.v.get(k, np.full_like(g, 0.1) if self.name == "adagrad" else np.zeros_like(g))
+            if self.name == "sgd":
+                upd = lr * g
+            elif self.name == "rmsprop":
+                v = v + (g * g - v) * (1 - 0.9)
+                upd = lr * g / np.sqrt(v + eps)
+            elif self.name == "adagrad":
+                v = v + g * g
+                upd = lr * g / (np.sqrt(v) + eps)
+            elif self.name == "adadelta":
+                v = 0.95 * v + 0.05 * g * g
+                u = np.sqrt(m + eps) / np.sqrt(v + eps) * g
+                m = 0.95 * m + 0.05 * u * u
+                upd = lr * u
+            elif self.name == "adamax":
+                m = b1 * m + (1 - b1) * g
+                v = np.maximum(b2 * v, np.abs(g))
+                upd = lr / (1 - b1 ** t) * m / (v + eps)
+            elif self.name == "nadam":
+                if k == next(iter(Wt)):
+                    self._ut = b1 * (1 - 0.5 * 0.96 ** (0.004 * t))
+                    self._ut1 = b1 * (1 - 0.5 * 0.96 ** (0.004 * (t + 1)))
+                    self.m_schedule = self.m_schedule * self._ut
+                ms_new, ms_next = self.m_schedule, self.m_schedule * self._ut1
+                gp = g / (1 - ms_new)
+                m = b1 * m + (1 - b1) * g
+                v = b2 * v + (1 - b2) * g * g
+                mbar = (1 - self._ut) * gp + self._ut1 * (m / (1 - ms_next))
+                upd = lr * mbar / (np.sqrt(v / (1 - b2 ** t)) + eps)
+            elif self.name == "adam":
+                m = b1 * m + (1 - b1) * g
+                v = b2 * v + (1 - b2) * g * g
+                upd = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
+            else:
+                raise ValueError(self.name)
+            self.m[k], self.v[k] = m, v
+            Wt[k] = (w.astype(np.float64) - upd).astype(np.float32)

@@ -23,6 +23,9 @@ constexpr int COT = 16;
 
 struct TrainState {
     float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-7f, clipnorm = 1.0f, clipvalue = 0.0f;
+    int optimizer = PSEG_OPT_ADAM;   // lib/architecture.py:71-90
+    double m_schedule = 1.0;         // Nadam's running product of the momentum schedule
+    bool state_init = false;         // Adagrad: accumulators start at 0.1
     int64_t step = 0;
     // flat buffers: [params in e.params order][metrics: loss, correct, I_c (C), S_c (C)]
     float* d_grad = nullptr;
@@ -416,9 +419,20 @@ __global__ void sumsq_kernel(const float* g, int64_t n, float scale, float* out)
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
-// g <- g*scale; per-tensor clip_by_norm (t * clip / max(norm, clip)); optional clipvalue; Keras Adam
-__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float gscale, const float* sumsq,
-                            float clipnorm, float clipvalue, float lr_t, float b1, float b2, float eps) {
+// g <- g*scale; per-tensor clip_by_norm (t * clip / max(norm, clip)); optional clipvalue; then the update
+// rule of the chosen Keras (TF 2.5 optimizer_v2) optimizer with its default hyper-parameters -- the
+// reference only ever passes lr / clipnorm / clipvalue (lib/network.py:92-102):
+//   adam     m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps)
+//   sgd      p -= lr g
+//   rmsprop  v = .9 v + .1 g^2; p -= lr g / sqrt(v + eps)                      (fused ApplyRMSProp form)
+//   adagrad  v += g^2 (v0 = 0.1); p -= lr g / (sqrt(v) + eps)
+//   adadelta v = .95 v + .05 g^2; u = sqrt(m + eps) / sqrt(v + eps) g; p -= lr u; m = .95 m + .05 u^2
+//   adamax   m = b1 m + (1-b1) g; v = max(b2 v, |g|); p -= lr/(1-b1^t) m / (v + eps)
+//   nadam    Keras' momentum-schedule form; the four schedule scalars c0..c3 come from the host
+struct OptScalars { float lr, b1, b2, eps, inv_ms_new, inv_ms_next, inv_b2t, u_t, u_t1; };
+
+__global__ void opt_kernel(int kind, float* p, const float* g, float* m, float* v, int64_t n, float gscale, const float* sumsq,
+                           float clipnorm, float clipvalue, OptScalars o) {
     float cn = 1.0f;
     if (clipnorm > 0.0f) {
         const float norm = sqrtf(*sumsq);
@@ -427,12 +441,51 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gscale * cn;
         if (clipvalue > 0.0f) gi = fminf(fmaxf(gi, -clipvalue), clipvalue);
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        switch (kind) {
+            case PSEG_OPT_ADAM: {
+                const float mi = o.b1 * m[i] + (1.0f - o.b1) * gi;
+                const float vi = o.b2 * v[i] + (1.0f - o.b2) * gi * gi;
+                m[i] = mi; v[i] = vi;
+                p[i] -= o.lr * mi / (sqrtf(vi) + o.eps);      // o.lr = lr_t
+            } break;
+            case PSEG_OPT_SGD: p[i] -= o.lr * gi; break;
+            case PSEG_OPT_RMSPROP: {
+                const float vi = v[i] + (gi * gi - v[i]) * (1.0f - 0.9f);
+                v[i] = vi;
+                p[i] -= o.lr * gi / sqrtf(vi + o.eps);
+            } break;
+            case PSEG_OPT_ADAGRAD: {
+                const float vi = v[i] + gi * gi;
+                v[i] = vi;
+                p[i] -= o.lr * gi / (sqrtf(vi) + o.eps);
+            } break;
+            case PSEG_OPT_ADADELTA: {
+                const float vi = 0.95f * v[i] + 0.05f * gi * gi;
+                const float u = sqrtf(m[i] + o.eps) / sqrtf(vi + o.eps) * gi;
+                v[i] = vi;
+                m[i] = 0.95f * m[i] + 0.05f * u * u;
+                p[i] -= o.lr * u;
+            } break;
+            case PSEG_OPT_ADAMAX: {
+                const float mi = o.b1 * m[i] + (1.0f - o.b1) * gi;
+                const float vi = fmaxf(o.b2 * v[i], fabsf(gi));
+                m[i] = mi; v[i] = vi;
+                p[i] -= o.lr * mi / (vi + o.eps);             // o.lr = lr / (1 - b1^t)
+            } break;
+            case PSEG_OPT_NADAM: {
+                const float gp = gi * o.inv_ms_new;
+                const float mi = o.b1 * m[i] + (1.0f - o.b1) * gi;
+                const float vi = o.b2 * v[i] + (1.0f - o.b2) * gi * gi;
+                m[i] = mi; v[i] = vi;
+                const float mbar = (1.0f - o.u_t) * gp + o.u_t1 * (mi * o.inv_ms_next);
+                p[i] -= o.lr * mbar / (sqrtf(vi * o.inv_b2t) + o.eps);
+            } break;
+        }
     }
+}
+
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -654,8 +707,27 @@ static int train_apply(Engine& e, float lr, float gscale) {
     PSEG_HIP(hipSetDevice(e.device));
     hipStream_t st = e.stream;
     t->step += 1;
+    OptScalars o{};
+    o.lr = lr; o.b1 = t->beta1; o.b2 = t->beta2; o.eps = t->eps;
     const double b1t = std::pow((double)t->beta1, (double)t->step), b2t = std::pow((double)t->beta2, (double)t->step);
-    const float lr_t = (float)(lr * std::sqrt(1.0 - b2t) / (1.0 - b1t));
+    if (t->optimizer == PSEG_OPT_ADAM) o.lr = (float)(lr * std::sqrt(1.0 - b2t) / (1.0 - b1t));
+    if (t->optimizer == PSEG_OPT_ADAMAX) o.lr = (float)(lr / (1.0 - b1t));
+    if (t->optimizer == PSEG_OPT_NADAM) {
+        // Keras nadam.py: u_t = b1 (1 - 0.5 * 0.96^(0.004 t)); m_schedule is the running product of the u's
+        const double ut = t->beta1 * (1.0 - 0.5 * std::pow(0.96, 0.004 * (double)t->step));
+        const double ut1 = t->beta1 * (1.0 - 0.5 * std::pow(0.96, 0.004 * (double)(t->step + 1)));
+        const double ms_new = t->m_schedule * ut, ms_next = ms_new * ut1;
+        t->m_schedule = ms_new;
+        o.inv_ms_new = (float)(1.0 / (1.0 - ms_new));
+        o.inv_ms_next = (float)(1.0 / (1.0 - ms_next));
+        o.inv_b2t = (float)(1.0 / (1.0 - b2t));
+        o.u_t = (float)ut;
+        o.u_t1 = (float)ut1;
+    }
+    if (t->optimizer == PSEG_OPT_ADAGRAD && !t->state_init) {
+        fill_kernel<<<1024, 256, 0, st>>>(t->d_v, t->nparam, 0.1f);      // initial_accumulator_value
+        t->state_init = true;
+    }
     PSEG_HIP(hipMemsetAsync(t->d_norm, 0, e.params.size() * 4, st));
     // parameter -> device buffer (kernels: op.d_w in correlation layout; biases: op.d_b)
     for (auto& op : e.ops) {
@@ -667,8 +739,8 @@ static int train_apply(Engine& e, float lr, float gscale) {
             float* p = which == 0 ? op.d_w : op.d_b;
             const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
             if (t->clipnorm > 0.0f) sumsq_kernel<<<grid, 256, 0, st>>>(g, n, gscale, t->d_norm + pi);
-            adam_kernel<<<grid, 256, 0, st>>>(p, g, t->d_m + t->off[pi], t->d_v + t->off[pi], n, gscale, t->d_norm + pi,
-                                             t->clipnorm, t->clipvalue, lr_t, t->beta1, t->beta2, t->eps);
+            opt_kernel<<<grid, 256, 0, st>>>(t->optimizer, p, g, t->d_m + t->off[pi], t->d_v + t->off[pi], n, gscale,
+                                            t->d_norm + pi, t->clipnorm, t->clipvalue, o);
         }
     }
     PSEG_HIP(hipGetLastError());
@@ -716,6 +788,22 @@ int pseg_train_init(pseg_engine* h, float beta1, float beta2, float eps, float c
     if (!h) return fail(PSEG_EINVAL, "NULL engine");
     PSEG_HIP(hipSetDevice(h->e.device));
     return train_init(h->e, beta1, beta2, eps, clipnorm, clipvalue);
+}
+
+int pseg_train_set_optimizer(pseg_engine* h, int optimizer) {
+    if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    if (optimizer < PSEG_OPT_ADAM || optimizer > PSEG_OPT_NADAM) return fail(PSEG_EINVAL, "unknown optimizer id %d", optimizer);
+    TrainState* t = TS(h->e);
+    if (!t) return fail(PSEG_EINVAL, "pseg_train_init has not been called");
+    PSEG_HIP(hipSetDevice(h->e.device));
+    PSEG_HIP(hipStreamSynchronize(h->e.stream));
+    PSEG_HIP(hipMemset(t->d_m, 0, (size_t)t->nparam * 4));
+    PSEG_HIP(hipMemset(t->d_v, 0, (size_t)t->nparam * 4));
+    t->optimizer = optimizer;
+    t->step = 0;
+    t->m_schedule = 1.0;
+    t->state_init = false;
+    return PSEG_OK;
 }
 
 int pseg_train_forward_backward(pseg_engine* h, const uint8_t* img, const uint8_t* mask, int H, int W, float metrics[4]) {

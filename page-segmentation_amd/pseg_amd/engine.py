@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = (
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
     "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_get_activation", "pseg_flops_per_pixel",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
-    "pseg_train_init", "pseg_train_forward_backward", "pseg_train_grad_buffer", "pseg_train_metrics",
+    "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_forward_backward", "pseg_train_grad_buffer", "pseg_train_metrics",
     "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
     "pseg_cc_vote", "pseg_cc_vote_device", "pseg_bbox_fill", "pseg_masks", "pseg_masks_device",
     "pseg_otsu_char_height",
@@ -69,6 +69,7 @@ def lib():
                                   c.POINTER(i64), c.POINTER(c.c_double)]
     f = c.c_float
     L.pseg_train_init.argtypes = [vp, f, f, f, f, f]
+    L.pseg_train_set_optimizer.argtypes = [vp, i]
     L.pseg_train_forward_backward.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
     L.pseg_train_grad_buffer.argtypes = [vp, c.POINTER(vp), c.POINTER(i64)]
     L.pseg_train_metrics.argtypes = [vp, c.POINTER(f)]
@@ -224,6 +225,14 @@ class Engine:
     def train_init(self, beta1=0.9, beta2=0.999, eps=1e-7, clipnorm=1.0, clipvalue=0.0):
         """Keras Adam defaults; clipnorm is per tensor (lib/network.py:97), <= 0 disables."""
         _check(lib().pseg_train_init(self._h, beta1, beta2, eps, clipnorm, clipvalue))
+
+    OPTIMIZERS = {"adam": 0, "adamax": 1, "adadelta": 2, "adagrad": 3, "rmsprop": 4, "sgd": 5, "nadam": 6}
+
+    def train_set_optimizer(self, name):
+        """One of the reference's Optimizers enum values (lib/architecture.py:71-78), Keras defaults."""
+        if name not in self.OPTIMIZERS:
+            raise PsegError("unknown optimizer %r" % (name,))
+        _check(lib().pseg_train_set_optimizer(self._h, self.OPTIMIZERS[name]))
 
     def _img_mask(self, image, mask):
         img = np.ascontiguousarray(image, dtype=np.uint8)

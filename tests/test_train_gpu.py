@@ -177,3 +177,33 @@ def test_trained_weights_bf16_labels_agree_with_exact(gpu, oracle_mod):
     assert np.array_equal(zo, z96)                               # trained weights: still bit-identical to the oracle
     e32.close()
     eb.close()
+
+
+@pytest.mark.parametrize("name,lr", [("sgd", 1e-2), ("rmsprop", 1e-3), ("adagrad", 1e-2), ("adadelta", 1.0),
+                                     ("adamax", 2e-3), ("nadam", 2e-3), ("adam", 1e-3)])
+def test_other_keras_optimizers(gpu, oracle_mod, name, lr):
+    """The reference's Optimizers enum (lib/architecture.py:71-90): three steps of each update rule against
+    the NumPy restatement of the TF 2.5 Keras formulas."""
+    from oracle import train_ref
+    from pseg_amd import synth
+    Wt = oracle_mod.init_weights("fcn", 3, seed=3, gain=1.0, bias_scale=0.05)
+    eng = gpu.Engine("fcn", 3, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    eng.train_init(clipnorm=1.0)
+    eng.train_set_optimizer(name)
+    ref = {k: v.copy() for k, v in Wt.items()}
+    opt = train_ref.KerasOptimizer(name, lr, clipnorm=1.0)
+    for step in range(3):
+        img, _, mask = synth.synth_page(step, 64, 64, 3)
+        eng.train_forward_backward(img, mask)
+        grads = eng.gradients()          # the update rule is what is under test: both sides get the same gradients
+        eng.train_apply(lr)              # (the gradients themselves are checked against torch above)
+        opt.apply(ref, grads)
+        assert all(np.isfinite(v).all() for v in ref.values())
+    got = eng.get_weights()
+    for k in ref:
+        scale = max(np.abs(ref[k] - Wt[k]).max(), 1e-12)
+        assert np.abs(got[k] - ref[k]).max() <= 2e-4 * scale + 2e-7, (name, k)
+    with pytest.raises(Exception):
+        eng.train_set_optimizer("lion")
+    eng.close()

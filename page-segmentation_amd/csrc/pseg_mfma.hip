@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) v
         if (b > 0) lds_barrier();  // every wave is done reading the previous block's tile / table
         // k-chunk offset table of this block: fetched now, written to LDS after the tile DMAs
         // have been issued (the fetch latency hides under the DMA issue)
-        constexpr int TU = MAX_TAB / NTHR;
+        constexpr int TU = (MAX_TAB + NTHR - 1) / NTHR;
         int tabv[TU];
         {
             const int* tg = last ? a.tab_last : a.tab_full;
@@ -1238,6 +1238,7 @@ struct MfmaPlan {
     // host copies of the (transformed) kernel / bias: the plan is re-packed when the canvas size
     // makes the other workgroup shape (NW) the better one
     std::vector<float> w_keep, b_keep;
+    int nw_tried = 0;
     bool nw8_ok = false;        // an 8-wave kernel instance exists for this layer shape
     bool nw8_resident = false;  // ... and its whole weight set stays resident beside the 16-row tile
     int cmax = 4;
@@ -1509,7 +1510,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
             }
         }
     }
-    if (P->NW == 8 && sigma != 6) return fail(PSEG_EUNSUPPORTED, "8-wave plan needs the sigma = 6 tile (got %d)", sigma);
+    if (P->NW != 4 && sigma != 6) return fail(PSEG_EUNSUPPORTED, "6/8-wave plan needs the sigma = 6 tile (got %d)", sigma);
     P->PS2 = sigma * 16;
     P->row_pitch = (P->TWH * sigma + pitch_pad) * 16;
     const auto ord_full = pair_chunks(KS, P->nc_full, sigma, P->row_pitch / 16);
@@ -1538,7 +1539,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     int budget = P->NW == 8 ? 156 * 1024 : 80 * 1024;
     if (const char* ev = getenv("PSEG_LDS_KB")) budget = atoi(ev) * 1024;
     auto total = [&](int gk, int nbuf) { return round_up(in_bytes, 16) + nbuf * gk * NT * 1024 + tab_bytes + 16; };
-    const int gstep = P->NW == 8 ? 1 : ((NT % 4 == 0) ? 1 : (NT % 2 == 0 ? 2 : 4));
+    const int gstep = P->NW != 4 ? 1 : ((NT % 4 == 0) ? 1 : (NT % 2 == 0 ? 2 : 4));
     auto best_gk = [&](int nbuf) {
         int gk = 0;
         for (int c = gstep; c <= 32 && c <= round_up(ks_max, gstep); c += gstep)
@@ -1728,7 +1729,10 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST8(4, 4, 3, 1, 6, MODE_CONV, 0)           // unet k3 convs, 16-row tiles
     PSEG_TRY_INST8(4, 4, 3, 1, 6, MODE_CONV, FL_POOL)
 #undef PSEG_TRY_INST8
-    if (P.NW != 4) return fail(PSEG_EUNSUPPORTED, "no 8-wave kernel instance for this layer shape");
+    // (six-wave workgroups -- 12-row tiles, two per CU, three waves per SIMD -- were measured too: conv3 113 vs
+    // 79 us, conv4 131 vs 93 us; 2064 workgroups on 512 slots leave a nearly empty fifth round and the smaller
+    // ring doubles the group barriers)
+    if (P.NW != 4) return fail(PSEG_EUNSUPPORTED, "no %d-wave kernel instance for this layer shape", P.NW);
 #define PSEG_TRY_INST(MT_, NT_, KS_, ST_, SG_, MODE_, FL_)                                          \
     if (!getenv("PSEG_GENERIC") && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == (FL_)) \
         return launch_inst<MT_, NT_, KS_, ST_, SG_, MODE_, (FL_)>(a, P, grid, st);
@@ -1851,11 +1855,12 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         int want = (cdiv(e.tW(d), TW) * cdiv(e.tH(d), 16) >= 224 && sigma_for(P->nc_full) == 6) ? 8 : 4;
         const char* ev = getenv("PSEG_NW");
         if (ev) want = atoi(ev) == 8 ? 8 : 4;
-        if (want != P->NW) {
+        if (want != P->NW && want != P->nw_tried) {
             const std::vector<float> w = P->w_keep, b = P->b_keep;
             op.nw_hint = want;
             PSEG_TRY(mfma_pack_op(e, op, w, b));
             P = (MfmaPlan*)op.plan;
+            P->nw_tried = want;      // the shape may not have an instance for `want`: do not re-pack every launch
             if (want == 8 && !P->nw8_resident && !ev) {   // ring only: keep two workgroups per CU
                 op.nw_hint = 4;
                 PSEG_TRY(mfma_pack_op(e, op, w, b));

@@ -123,6 +123,12 @@ enum { PSEG_OPT_ADAM = 0, PSEG_OPT_ADAMAX = 1, PSEG_OPT_ADADELTA = 2, PSEG_OPT_A
        PSEG_OPT_RMSPROP = 4, PSEG_OPT_SGD = 5, PSEG_OPT_NADAM = 6 };
 int pseg_train_set_optimizer(pseg_engine* e, int optimizer);
 
+/* Loss functions (lib/metrics.py:8-9,72-133; `Loss` enum).  metrics[0] of the step calls is the selected
+ * loss; the three other metrics stay accuracy / jacard_coef / dice_coef.  Default: cross-entropy. */
+enum { PSEG_LOSS_CE = 0, PSEG_LOSS_JACCARD = 1, PSEG_LOSS_DICE = 2, PSEG_LOSS_HINGE = 3, PSEG_LOSS_FOCAL = 4,
+       PSEG_LOSS_DICE_CE = 5 };
+int pseg_train_set_loss(pseg_engine* e, int loss);
+
 /* One sample (batch of one page, as the reference: lib/network.py:151-153): forward, mean sparse
  * softmax cross-entropy + metrics, backward.  img uint8 (H,W), mask uint8 class ids (H,W), host
  * pointers.  metrics = {loss, accuracy, jacard_coef, dice_coef} of this sample.  Gradients stay

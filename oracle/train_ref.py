@@ -7,8 +7,9 @@ from collections import OrderedDict
 import numpy as np
 
 
-def fcn_loss_and_grads(arch, Wt, image_u8, mask_u8):
-    """-> (loss, acc, jaccard, dice, grads dict in Keras layouts)."""
+def fcn_loss_and_grads(arch, Wt, image_u8, mask_u8, loss_kind="categorical_crossentropy"):
+    """-> (loss, acc, jaccard, dice, grads dict in Keras layouts).  loss_kind: a value of the reference's
+    Loss enum (lib/metrics.py:116-121); Keras reduces the tensor a loss function returns by a plain mean."""
     import torch
     import torch.nn.functional as F
     skip = arch == "fcn_skip"
@@ -46,7 +47,27 @@ def fcn_loss_and_grads(arch, Wt, image_u8, mask_u8):
     z = F.conv2d(d5, T["logits/kernel"].permute(3, 2, 0, 1), T["logits/bias"])[0].permute(1, 2, 0)   # (H,W,C)
     y = torch.from_numpy(mask_u8.astype(np.int64))
     C = z.shape[-1]
-    loss = F.cross_entropy(z.reshape(-1, C), y.reshape(-1))                      # lib/metrics.py:8-9
+    if loss_kind == "categorical_crossentropy":
+        loss = F.cross_entropy(z.reshape(-1, C), y.reshape(-1))                  # lib/metrics.py:8-9
+    else:
+        oh_l = F.one_hot(y, C).float()
+        if loss_kind in ("dice", "jaccard", "dice_and_crossentropy"):            # :60-85,107-109
+            p_l = torch.softmax(z, -1)
+            I = (oh_l * p_l).abs().sum((0, 1))
+            S = (oh_l + p_l).abs().sum((0, 1))
+            coef = (I + 100) / (S - I + 100) if loss_kind == "jaccard" else (2.0 * I + 100) / (S + 100)
+            loss = (-torch.log(coef)).mean()
+            if loss_kind == "dice_and_crossentropy":                             # alpha = 1: (1*dice + 0*ce) / 2
+                loss = loss / 2
+        elif loss_kind == "categorical_hinge":                                   # :88-95 (on the raw logits)
+            pos = (oh_l * z).sum(-1)
+            neg = ((1.0 - oh_l) * z).max(-1).values
+            loss = torch.clamp(neg - pos + 1, min=0.0).mean()
+        elif loss_kind == "categorical_focal":                                   # :98-105 (raw logits clipped)
+            pc = torch.clamp(z, 1e-7, 1.0 - 1e-7)
+            loss = (-oh_l * (0.25 * (1 - pc) ** 2 * torch.log(pc))).mean() * 100
+        else:
+            raise ValueError(loss_kind)
     loss.backward()
     with torch.no_grad():
         acc = (z.argmax(-1) == y).float().mean().item()                          # :12-17

@@ -24,6 +24,7 @@ constexpr int COT = 16;
 struct TrainState {
     float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-7f, clipnorm = 1.0f, clipvalue = 0.0f;
     int optimizer = PSEG_OPT_ADAM;   // lib/architecture.py:71-90
+    int loss_kind = PSEG_LOSS_CE;    // lib/metrics.py:116-133
     double m_schedule = 1.0;         // Nadam's running product of the momentum schedule
     bool state_init = false;         // Adagrad: accumulators start at 0.1
     int64_t step = 0;
@@ -92,6 +93,80 @@ __global__ void ce_metrics_kernel(const float* logits, const uint8_t* labels, in
     }
     __syncthreads();
     if (threadIdx.x < 2 + 2 * C) atomicAdd(&acc[threadIdx.x], sh[threadIdx.x]);
+}
+
+// Gradient of the alternative losses of lib/metrics.py:72-112 with respect to the logits (second pass:
+// the per-class sums I_c = sum p_c 1_c and S_c = sum (p_c + 1_c) of the first pass are final).  Keras
+// reduces whatever tensor the loss function returns with a mean over all of its elements:
+//   dice     L = mean_c -log D_c, D_c = (2 I_c + 100) / (S_c + 100)            (softmax inside)
+//   jaccard  L = mean_c -log J_c, J_c = (I_c + 100) / (S_c - I_c + 100)        (softmax inside)
+//   dice_and_crossentropy (alpha = 1): dice / 2
+//   categorical_hinge on the raw logits: mean_px max(0, max(0, max_{c != y} z_c) - z_y + 1)
+//   categorical_focal on the raw logits clipped to [1e-7, 1 - 1e-7] ("y_pred" is what the model outputs):
+//            100 * mean over (pixel, class) of -1_c * 0.25 (1 - z_c)^2 log z_c
+// acc[2 + 2*16] accumulates the hinge / focal loss sum.
+__global__ void loss_grad_kernel(int kind, const float* logits, const uint8_t* labels, int n, int C, float inv_n,
+                                 const float* acc, float* dlogits, float* alt_sum) {
+    __shared__ float sh;
+    if (threadIdx.x == 0) sh = 0.0f;
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) {
+        const float* z = logits + (size_t)p * C;
+        float* dz = dlogits + (size_t)p * C;
+        const int y = labels[p];
+        if (kind == PSEG_LOSS_DICE || kind == PSEG_LOSS_JACCARD || kind == PSEG_LOSS_DICE_CE) {
+            float m = z[0];
+            for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
+            float s = 0.0f, pr[16], dp[16], dot = 0.0f;
+            for (int c = 0; c < C; ++c) { pr[c] = expf(z[c] - m); s += pr[c]; }
+            const float scale = (kind == PSEG_LOSS_DICE_CE ? 0.5f : 1.0f) / (float)C;
+            for (int c = 0; c < C; ++c) {
+                pr[c] /= s;
+                const float I = acc[2 + c], S = acc[2 + C + c];
+                const float oh = (c == y) ? 1.0f : 0.0f;
+                float coef, dcoef;
+                if (kind == PSEG_LOSS_JACCARD) {
+                    const float den = S - I + 100.0f;
+                    coef = (I + 100.0f) / den;
+                    dcoef = (oh * den - (I + 100.0f) * (1.0f - oh)) / (den * den);
+                } else {
+                    const float den = S + 100.0f;
+                    coef = (2.0f * I + 100.0f) / den;
+                    dcoef = (2.0f * oh * den - (2.0f * I + 100.0f)) / (den * den);
+                }
+                dp[c] = -scale * dcoef / coef;           // dL/dp_c at this pixel
+                dot += dp[c] * pr[c];
+            }
+            for (int c = 0; c < C; ++c) dz[c] = pr[c] * (dp[c] - dot);      // softmax Jacobian
+        } else if (kind == PSEG_LOSS_HINGE) {
+            float neg = 0.0f;
+            int an = -1;
+            for (int c = 0; c < C; ++c)
+                if (c != y && z[c] > neg) { neg = z[c]; an = c; }
+            const float pos = (y < C) ? z[y] : 0.0f;
+            const float l = neg - pos + 1.0f;
+            for (int c = 0; c < C; ++c) dz[c] = 0.0f;
+            if (l > 0.0f) {
+                atomicAdd(&sh, l);
+                if (y < C) dz[y] = -inv_n;
+                if (an >= 0) dz[an] = inv_n;
+            }
+        } else {   // focal
+            for (int c = 0; c < C; ++c) dz[c] = 0.0f;
+            if (y < C) {
+                const float eps = 1e-7f;
+                const float zc = z[y];
+                const float pc = fminf(fmaxf(zc, eps), 1.0f - eps);
+                const float k = 100.0f * inv_n / (float)C;
+                atomicAdd(&sh, -0.25f * (1.0f - pc) * (1.0f - pc) * logf(pc) * 100.0f / (float)C);
+                if (zc > eps && zc < 1.0f - eps)
+                    dz[y] = k * 0.25f * (2.0f * (1.0f - pc) * logf(pc) - (1.0f - pc) * (1.0f - pc) / pc);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && sh != 0.0f) atomicAdd(alt_sum, sh);
 }
 
 // forward conv weights [KH][KW][Cin][Cout] -> dgrad weights of the channel range [c0, c0+nc):
@@ -522,7 +597,7 @@ static int train_init(Engine& e, float b1, float b2, float eps, float clipnorm, 
         o = (o + 3) & ~(int64_t)3;
     }
     t->nparam = o;
-    t->nflat = o + 2 + 2 * 16;
+    t->nflat = o + 2 + 2 * 16 + 1;   // + the hinge / focal loss sum
     PSEG_HIP(hipMalloc((void**)&t->d_grad, (size_t)t->nflat * 4));
     PSEG_HIP(hipMalloc((void**)&t->d_m, (size_t)t->nparam * 4));
     PSEG_HIP(hipMalloc((void**)&t->d_v, (size_t)t->nparam * 4));
@@ -562,6 +637,9 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     if (backward) PSEG_HIP(hipMemsetAsync(t->d_grad, 0, (size_t)t->nflat * 4, st));
     else PSEG_HIP(hipMemsetAsync(acc, 0, (size_t)(t->nflat - t->nparam) * 4, st));
     ce_metrics_kernel<<<cdiv((int)npx, 256), 256, 0, st>>>(t->d_logits, t->d_mask, (int)npx, C, 1.0f / (float)npx, t->d_dlogits, acc);
+    if (t->loss_kind != PSEG_LOSS_CE)
+        loss_grad_kernel<<<cdiv((int)npx, 256), 256, 0, st>>>(t->loss_kind, t->d_logits, t->d_mask, (int)npx, C, 1.0f / (float)npx,
+                                                            acc, t->d_dlogits, acc + 2 + 2 * 16);
     PSEG_HIP(hipGetLastError());
     if (!backward) return PSEG_OK;
 
@@ -684,7 +762,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
 static int train_metrics(Engine& e, float out[4]) {
     TrainState* t = TS(e);
     const int C = e.n_classes;
-    std::vector<float> acc(2 + 2 * 16);
+    std::vector<float> acc(2 + 2 * 16 + 1);
     PSEG_HIP(hipStreamSynchronize(e.stream));
     PSEG_HIP(hipMemcpy(acc.data(), t->d_grad + t->nparam, acc.size() * 4, hipMemcpyDeviceToHost));
     const double n = (double)t->H * t->W;
@@ -698,6 +776,19 @@ static int train_metrics(Engine& e, float out[4]) {
     }
     out[2] = (float)(jac / C);
     out[3] = (float)(dice / C);
+    // metrics[0] is the compiled loss (Keras reports `loss`)
+    if (t->loss_kind == PSEG_LOSS_DICE || t->loss_kind == PSEG_LOSS_JACCARD || t->loss_kind == PSEG_LOSS_DICE_CE) {
+        double l = 0;
+        for (int c = 0; c < C; ++c) {
+            const double I = acc[2 + c], S = acc[2 + C + c];
+            l += -std::log(t->loss_kind == PSEG_LOSS_JACCARD ? (I + 100.0) / (S - I + 100.0) : (2.0 * I + 100.0) / (S + 100.0));
+        }
+        out[0] = (float)(l / C * (t->loss_kind == PSEG_LOSS_DICE_CE ? 0.5 : 1.0));
+    } else if (t->loss_kind == PSEG_LOSS_HINGE) {
+        out[0] = (float)(acc[2 + 2 * 16] / n);
+    } else if (t->loss_kind == PSEG_LOSS_FOCAL) {
+        out[0] = (float)(acc[2 + 2 * 16] / n);
+    }
     return PSEG_OK;
 }
 
@@ -803,6 +894,16 @@ int pseg_train_set_optimizer(pseg_engine* h, int optimizer) {
     t->step = 0;
     t->m_schedule = 1.0;
     t->state_init = false;
+    return PSEG_OK;
+}
+
+int pseg_train_set_loss(pseg_engine* h, int loss) {
+    if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    if (loss < PSEG_LOSS_CE || loss > PSEG_LOSS_DICE_CE) return fail(PSEG_EINVAL, "unknown loss id %d", loss);
+    TrainState* t = TS(h->e);
+    if (!t) return fail(PSEG_EINVAL, "pseg_train_init has not been called");
+    if (h->e.n_classes > 16) return fail(PSEG_EUNSUPPORTED, "losses other than cross-entropy support at most 16 classes");
+    t->loss_kind = loss;
     return PSEG_OK;
 }
 

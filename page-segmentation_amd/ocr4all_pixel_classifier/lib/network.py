@@ -179,11 +179,11 @@ class Network:
         if self.model.mode != _eng.MODE_F32_EXACT:
             raise Exception("training needs the float32 engine: construct Network(..., exact=True) "
                             "(Trainer does this)")
-        if self.loss_func is not None and getattr(self.loss_func, "value", "categorical_crossentropy") != "categorical_crossentropy":
-            raise Exception("only the categorical cross-entropy loss (the reference default) is built")
         self.model.train_init(clipnorm=self.optimizer_norm_clip_value if self.optimizer_norm_clipping else 0.0,
                               clipvalue=self.optimizer_clip_value if self.optimizer_clipping else 0.0)
         self.model.train_set_optimizer(self.optimizer.value)      # Optimizers enum value = Keras name
+        if self.loss_func is not None:
+            self.model.train_set_loss(getattr(self.loss_func, "value", self.loss_func))   # Loss enum member or its value
         self._train_ready = True
 
     def _samples(self, dataset):

@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = (
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
     "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_get_activation", "pseg_flops_per_pixel",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
-    "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_forward_backward", "pseg_train_grad_buffer", "pseg_train_metrics",
+    "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_set_loss", "pseg_train_forward_backward", "pseg_train_grad_buffer", "pseg_train_metrics",
     "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
     "pseg_cc_vote", "pseg_cc_vote_device", "pseg_bbox_fill", "pseg_masks", "pseg_masks_device",
     "pseg_otsu_char_height",
@@ -70,6 +70,7 @@ def lib():
     f = c.c_float
     L.pseg_train_init.argtypes = [vp, f, f, f, f, f]
     L.pseg_train_set_optimizer.argtypes = [vp, i]
+    L.pseg_train_set_loss.argtypes = [vp, i]
     L.pseg_train_forward_backward.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
     L.pseg_train_grad_buffer.argtypes = [vp, c.POINTER(vp), c.POINTER(i64)]
     L.pseg_train_metrics.argtypes = [vp, c.POINTER(f)]
@@ -233,6 +234,15 @@ class Engine:
         if name not in self.OPTIMIZERS:
             raise PsegError("unknown optimizer %r" % (name,))
         _check(lib().pseg_train_set_optimizer(self._h, self.OPTIMIZERS[name]))
+
+    LOSSES = {"categorical_crossentropy": 0, "jaccard": 1, "dice": 2, "categorical_hinge": 3, "categorical_focal": 4,
+              "dice_and_crossentropy": 5}
+
+    def train_set_loss(self, name):
+        """One of the reference's Loss enum values (lib/metrics.py:116-121)."""
+        if name not in self.LOSSES:
+            raise PsegError("unknown loss %r" % (name,))
+        _check(lib().pseg_train_set_loss(self._h, self.LOSSES[name]))
 
     def _img_mask(self, image, mask):
         img = np.ascontiguousarray(image, dtype=np.uint8)

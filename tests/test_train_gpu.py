@@ -207,3 +207,34 @@ def test_other_keras_optimizers(gpu, oracle_mod, name, lr):
     with pytest.raises(Exception):
         eng.train_set_optimizer("lion")
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["dice", "jaccard", "dice_and_crossentropy", "categorical_hinge", "categorical_focal"])
+def test_alternative_losses(gpu, oracle_mod, name):
+    """The reference's Loss enum (lib/metrics.py:72-133): loss value and every gradient against torch
+    autograd of the same definition (bar as for cross-entropy: loss 1e-4 relative)."""
+    from oracle import train_ref
+    from pseg_amd import synth
+    gain = 0.35 if name == "categorical_focal" else 1.0      # focal clips the raw logits to (0, 1): keep some inside
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=5, gain=gain, bias_scale=0.3 if name == "categorical_focal" else 0.05)
+    img, _, mask = synth.synth_page(2, 64, 96, 3)
+    eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    eng.train_init(clipnorm=1.0)
+    eng.train_set_loss(name)
+    loss, acc, jac, dice = eng.train_forward_backward(img, mask)
+    g = eng.gradients()
+    rl, ra, rj, rd, rg = train_ref.fcn_loss_and_grads("fcn_skip", Wt, img, mask, loss_kind=name)
+    assert abs(loss - rl) <= 1e-4 * max(abs(rl), 1e-3), (loss, rl)
+    assert abs(acc - ra) < 1e-6 and abs(jac - rj) < 1e-5 and abs(dice - rd) < 1e-5
+    nonzero = 0
+    for k in rg:
+        scale = np.abs(rg[k]).max()
+        nonzero += scale > 0
+        assert np.abs(g[k] - rg[k]).max() <= 2e-4 * scale + 1e-9, (name, k, scale)
+    assert nonzero >= len(rg) - 2
+    ev = eng.eval_step(img, mask)
+    assert abs(ev[0] - rl) <= 1e-4 * max(abs(rl), 1e-3)
+    with pytest.raises(Exception):
+        eng.train_set_loss("mse")
+    eng.close()

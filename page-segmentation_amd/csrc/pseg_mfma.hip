@@ -1500,6 +1500,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
             const int in_b = P->THH * ((P->TWH * sg + pad) * 16);
             return P->nblk == 1 && in_b + round_up(ksf, 4) * NT * 1024 + ksf * 16 + 64 <= 80 * 1024;
         };
+        // (the dense tile was also tried where it is not needed for residency -- conv3 at sigma = 4: 78.7 vs 79.0 us,
+        // neither the third of the DMA lanes spent on pad slots nor the read conflicts matter there)
         if (!getenv("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16)) {
             sigma = P->nc_full;
             int best_cyc = 1 << 30;

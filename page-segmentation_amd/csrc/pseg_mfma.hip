@@ -182,7 +182,7 @@ enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16, FL_FUSE1
 // of LDS: a 16-row tile shares one weight stream among twice the pixels -- the mid layers are
 // bound by LDS-DMA bytes per CU).
 template <int MT, int NT, int KS_, int ST_, int SG_, int MODE_, int FL_, int NW_ = 4>
-__global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu(2))) void conv_mfma_kernel(MConv a) {
+__global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT == 4 && NT == 4 && NW_ == 4 && (KS_ == 5 || KS_ == 3 || KS_ == 2) && (SG_ == 4 || SG_ == 5) && MODE_ == 0) ? 3 : 2))) void conv_mfma_kernel(MConv a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = NW_, NTHR = NW_ * 64;
     constexpr int TH = NW * (MT / 2);  // NW waves x (MT/2) rows
@@ -1239,6 +1239,7 @@ struct MfmaPlan {
     // makes the other workgroup shape (NW) the better one
     std::vector<float> w_keep, b_keep;
     int nw_tried = 0;
+    bool wg3 = false;           // dense tile + 53 KB plan: three workgroups per CU
     bool nw8_ok = false;        // an 8-wave kernel instance exists for this layer shape
     bool nw8_resident = false;  // ... and its whole weight set stays resident beside the 16-row tile
     int cmax = 4;
@@ -1502,7 +1503,17 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         };
         // (the dense tile was also tried where it is not needed for residency -- conv3 at sigma = 4: 78.7 vs 79.0 us,
         // neither the third of the DMA lanes spent on pad slots nor the read conflicts matter there)
-        if (!getenv("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16)) {
+        // Three workgroups per CU (12 waves, three per SIMD) for the NT = 3 k5 layers: their instances need 147
+        // registers, so only LDS limits the occupancy.  The dense tile (sigma = chunks per pixel, row pitch chosen
+        // by the bank model) plus a two-slot ring fit 53 KB.  A workgroup's life is prologue -> k-loop ->
+        // epilogue with the MFMA pipe used only in the middle; a third resident workgroup fills more of the
+        // gaps: conv3 78 -> 67 us, deconv3 79 -> 66 us, better than the 16-row resident variant (70 us).
+        P->wg3 = P->NW == 4 && !deconv && ((KS == 5 && (NT == 3 || NT == 4) && P->nblocks_n == 1) || (KS == 3 && NT == 4 && !getenv("PSEG_NO_WG3_K3")) ||
+                                                 (KS == 2 && NT == 4 && op.up0 && !s1 && !getenv("PSEG_NO_WG3_K3"))) &&
+                 (P->nc_full == 4 || P->nc_full == 5) && op.stride == 1 &&
+                 (!op.up0 || KS == 2) && !op.up1 && !op.in_relu && op.add < 0 && op.fuse1 < 0 &&
+                 !getenv("PSEG_GENERIC") && !getenv("PSEG_NO_WG3");
+        if (P->wg3 || (!getenv("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16))) {
             sigma = P->nc_full;
             int best_cyc = 1 << 30;
             for (int pad = 0; pad < 16; ++pad) {
@@ -1540,6 +1551,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     const int tab_bytes = ks_max * 16;
     int budget = P->NW == 8 ? 156 * 1024 : 80 * 1024;
     if (const char* ev = getenv("PSEG_LDS_KB")) budget = atoi(ev) * 1024;
+    if (P->wg3) budget = 53 * 1024;
     auto total = [&](int gk, int nbuf) { return round_up(in_bytes, 16) + nbuf * gk * NT * 1024 + tab_bytes + 16; };
     const int gstep = P->NW != 4 ? 1 : ((NT % 4 == 0) ? 1 : (NT % 2 == 0 ? 2 : 4));
     auto best_gk = [&](int nbuf) {
@@ -1744,11 +1756,21 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(8, 2, 5, 1, 6, MODE_CONV, FL_POOL)      // conv2 (padded tile)
     PSEG_TRY_INST(4, 3, 5, 1, 6, MODE_CONV, 0)            // conv3, deconv3
     PSEG_TRY_INST(4, 3, 5, 1, 6, MODE_CONV, FL_POOL)      // conv4
+    PSEG_TRY_INST(4, 3, 5, 1, 4, MODE_CONV, 0)            // conv3, deconv3: dense 64-byte pixels, three workgroups per CU
+    PSEG_TRY_INST(4, 3, 5, 1, 5, MODE_CONV, FL_POOL)      // conv4: dense 80-byte pixels, three workgroups per CU
+    PSEG_TRY_INST(4, 3, 5, 1, 5, MODE_CONV, 0)
+    PSEG_TRY_INST(4, 4, 5, 1, 5, MODE_CONV, 0)            // conv5: dense, three workgroups per CU (165 registers + 8 spilled)
+    PSEG_TRY_INST(4, 4, 5, 1, 4, MODE_CONV, FL_POOL)      // conv6
+    PSEG_TRY_INST(4, 4, 5, 1, 4, MODE_CONV, 0)
+    PSEG_TRY_INST(4, 4, 5, 1, 5, MODE_CONV, FL_POOL)
     PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, 0)            // conv5
     PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, FL_POOL)      // conv6
     PSEG_TRY_INST(4, 5, 5, 1, 6, MODE_CONV, 0)            // conv7, deconv1
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, 0)            // unet: k3 convs (64..1024 channels, 32-channel blocks)
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, FL_POOL)      // unet: k3 conv + fused pool
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, 0)            // unet: dense tile, three workgroups per CU
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_POOL)
+    PSEG_TRY_INST(4, 4, 2, 1, 4, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv, dense tile
     PSEG_TRY_INST(4, 4, 2, 1, 6, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv
     PSEG_TRY_INST(4, 5, 1, 1, 10, MODE_DECONV, 0)         // deconv2
     PSEG_TRY_INST(4, 4, 1, 1, 14, MODE_DECONV, 0)         // deconv4 (fcn_skip), two N blocks
@@ -1854,7 +1876,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         // Measured (MI355X, 2048x1536): 16-row tiles pay off where the layer's whole weight set then
         // stays resident in LDS (conv3: 80 -> 68 us); with a streamed ring they only tie (the halved
         // weight traffic is offset by losing the second workgroup's overlap).  PSEG_NW=4|8 forces.
-        int want = (cdiv(e.tW(d), TW) * cdiv(e.tH(d), 16) >= 224 && sigma_for(P->nc_full) == 6) ? 8 : 4;
+        int want = (cdiv(e.tW(d), TW) * cdiv(e.tH(d), 16) >= 224 && sigma_for(P->nc_full) == 6 && !P->wg3) ? 8 : 4;
         const char* ev = getenv("PSEG_NW");
         if (ev) want = atoi(ev) == 8 ? 8 : 4;
         if (want != P->NW && want != P->nw_tried) {

@@ -173,7 +173,7 @@ constexpr int STAGE_SLOTS = 12;  // 16-byte loads a lane keeps in flight while s
 // "read it from the argument block" (generic fallback).  With ~50 runtime geometry fields the
 // compiler hoists and spills scalars by the hundred; with constants the prologue collapses.
 enum { MODE_CONV = 0, MODE_DECONV = 1, MODE_TAIL = 2 };
-enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16, FL_FUSE1 = 32, FL_PERSIST = 64 };
+enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16, FL_FUSE1 = 32, FL_PERSIST = 64, FL_LOGITS = 128 };
 #ifndef PSEG_DIAG
 #define PSEG_DIAG 0   // 1: compile the in-kernel trace stamps / ablation switches (diagnostic builds)
 #endif
@@ -714,6 +714,77 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
                                             pk_bf16(v2, v3));
                 const size_t o = ((size_t)(2 * y + (ab >> 1)) * (2 * a.Wout) + (2 * x + (ab & 1))) * (a.nch_out * 8) + co;
                 *(uint2*)(a.dst + o) = pk;
+            }
+        }
+        break;
+    }
+
+    if constexpr (FIXED && (FL_ & FL_LOGITS) != 0 && NT == 4) {
+        // Fused logits (unet tail): the 64 couts of a pixel sit in four accumulator tiles, i.e. they already
+        // are the B operands (k x pixel) of two logits MFMAs (k = 8g+j <-> cout 16(2q) + 4g + j for j < 4,
+        // 16(2q+1) + 4g + (j-4) otherwise; the host packs the logits kernel in that order).  +bias, ReLU and
+        // the bf16 rounding of the layer output happen in registers; the 64-channel tensor is never stored.
+        const bf16x8 wq0 = *(const bf16x8*)(a.tail_wa + lane * 8), wq1 = *(const bf16x8*)(a.tail_wb + lane * 8);
+        const float4 lb = *(const float4*)(a.tail_bias + 4 * g);
+        const int C = a.tail_C;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int y = oy0 + wave * (MT / 2) + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+            const bool inb = y < a.H0 && x < a.W0;
+            uint32_t pk[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float v0 = acc[m][t][0] + biasr[t].x, v1 = acc[m][t][1] + biasr[t].y;
+                float v2 = acc[m][t][2] + biasr[t].z, v3 = acc[m][t][3] + biasr[t].w;
+                if (a.relu) { v0 = vmax(v0, 0.f); v1 = vmax(v1, 0.f); v2 = vmax(v2, 0.f); v3 = vmax(v3, 0.f); }
+                pk[t][0] = pk_bf16(v0, v1);
+                pk[t][1] = pk_bf16(v2, v3);
+            }
+            f32x4 z = f32x4{lb.x, lb.y, lb.z, lb.w};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq0, __builtin_bit_cast(bf16x8, make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1])), z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq1, __builtin_bit_cast(bf16x8, make_uint4(pk[2][0], pk[2][1], pk[3][0], pk[3][1])), z, 0, 0, 0);
+            float bv = -3.4e38f;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * g + r;
+                const bool take = (c < C) & (z[r] > bv);
+                bv = take ? z[r] : bv;
+                bi = take ? c : bi;
+            }
+            if (C > 4) {
+#pragma unroll
+                for (int sh = 16; sh <= 32; sh <<= 1) {
+                    const float ov = __shfl_xor(bv, sh);
+                    const int oi = __shfl_xor(bi, sh);
+                    const bool take = (ov > bv) | ((ov == bv) & (oi < bi));
+                    bv = take ? ov : bv;
+                    bi = take ? oi : bi;
+                }
+            }
+            const size_t p = (size_t)y * a.W0 + x;
+            if (inb) {
+                if (g == 0) {
+                    if (a.out_labels_u8) a.out_labels_u8[p] = (uint8_t)bi;
+                    if (a.out_labels) a.out_labels[p] = bi;
+                }
+                if (a.out_logits)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * g + r < C) a.out_logits[p * C + 4 * g + r] = z[r];
+            }
+            if (a.out_probs) {
+                float ex[4], sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ex[r] = (4 * g + r < C) ? expf(z[r] - bv) : 0.f; sum += ex[r]; }
+                if (C > 4) {
+                    sum += __shfl_xor(sum, 16);
+                    sum += __shfl_xor(sum, 32);
+                }
+                if (inb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * g + r < C) a.out_probs[p * C + 4 * g + r] = ex[r] / sum;
             }
         }
         break;
@@ -1279,6 +1350,24 @@ int mfma_plan_graph(Engine& e) {
             e.tensors[e.ops[pi].dst].fused = true;
             lg.fused_away = true;
         }
+    // conv (64 couts = one N block of four tiles, stride 1) feeding only the logits layer -> logits / softmax /
+    // argmax in that conv's epilogue (unet): its 64-channel full-resolution output is never written
+    if (!getenv("PSEG_NO_TAIL_FUSION") && !getenv("PSEG_NO_CONV_LOGITS"))
+        for (size_t li = 0; li < e.ops.size(); ++li) {
+            Op& lg = e.ops[li];
+            if (lg.type != OP_LOGITS || lg.fused_away || e.n_classes > 16 || lg.src1 >= 0) continue;
+            const int pi = producer_of(e, lg.src0);
+            if (pi < 0) continue;
+            Op& cv = e.ops[pi];
+            if (cv.type != OP_CONV || cv.Cout != 64 || cv.stride != 1 || cv.k != 3 || cv.up0 || cv.up1 || cv.in_relu ||
+                cv.add >= 0 || cv.transposed || cv.pool_dst >= 0) continue;
+            int users = 0;
+            for (auto& o : e.ops) users += (o.src0 == lg.src0) + (o.src1 == lg.src0) + (o.add == lg.src0);
+            if (users != 1) continue;
+            cv.tail_logits = (int)li;
+            e.tensors[cv.dst].fused = true;
+            lg.fused_away = true;
+        }
     // first layer (Cin = 1, k5, 20 couts) feeding only one k5 conv -> recomputed inside that conv
     if (!getenv("PSEG_NO_CONV1_FUSION") && e.in_ch == 1)
         for (size_t ci = 0; ci < e.ops.size(); ++ci) {
@@ -1629,6 +1718,31 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         else { const int ab = n / P->CoP, co = n % P->CoP; if (ab < 4 && co < Cout) bb[n] = bias[co]; }
     }
     PSEG_TRY(upload(&P->d_bias, bb));
+    if (!deconv && op.tail_logits >= 0) {
+        // conv + logits fusion: logits kernel (Keras (1,1,64,C): w[co*C + c]) in the fragment order of the two
+        // epilogue MFMAs: lane l = (class = l & 15, g = l >> 4), MFMA q, element j <-> cout
+        // co = j < 4 ? 16(2q) + 4g + j : 16(2q+1) + 4g + (j - 4)
+        if (NT != 4 || P->nblocks_n != 1) return fail(PSEG_EUNSUPPORTED, "conv + logits fusion needs a 64-cout layer");
+        const Op& lg = e.ops[op.tail_logits];
+        const std::vector<float>& lw = e.params[lg.kparam].host;
+        const std::vector<float>& lbias = e.params[lg.bparam].host;
+        const int C = lg.Cout;
+        std::vector<uint16_t> wq[2] = {std::vector<uint16_t>(64 * 8, 0), std::vector<uint16_t>(64 * 8, 0)};
+        for (int q = 0; q < 2; ++q)
+            for (int l = 0; l < 64; ++l) {
+                const int cls = l & 15, gg = l >> 4;
+                if (cls >= C) continue;
+                for (int j = 0; j < 8; ++j) {
+                    const int co = j < 4 ? 16 * (2 * q) + 4 * gg + j : 16 * (2 * q + 1) + 4 * gg + (j - 4);
+                    if (co < Cout) wq[q][l * 8 + j] = f2bf(lw[(size_t)co * C + cls]);
+                }
+            }
+        std::vector<float> tb(16, 0.0f);
+        for (int c = 0; c < C; ++c) tb[c] = lbias[c];
+        PSEG_TRY(upload(&P->d_tail_wa, wq[0]));
+        PSEG_TRY(upload(&P->d_tail_wb, wq[1]));
+        PSEG_TRY(upload(&P->d_tail_bias, tb));
+    }
     if (tail) {
         // logits weights (Keras (1,1,Cin,C): w[ci*C + c]) in the fragment order of the fused
         // tail: lane l = (class = l & 15, g = l >> 4), element j <-> deconv channel
@@ -1729,7 +1843,8 @@ static int launch_inst(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t
 static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hipStream_t st) {
     const int mode = a.tail ? MODE_TAIL : (a.deconv ? MODE_DECONV : MODE_CONV);
     const int fl = (a.pool_dst ? FL_POOL : 0) | (a.add ? FL_ADD : 0) | (a.in_relu ? FL_INRELU : 0) |
-                   (a.up0 ? FL_UP0 : 0) | (a.up1 ? FL_UP1 : 0) | (a.f1_img ? FL_FUSE1 : 0) | (a.ntiles > 0 ? FL_PERSIST : 0);
+                   (a.up0 ? FL_UP0 : 0) | (a.up1 ? FL_UP1 : 0) | (a.f1_img ? FL_FUSE1 : 0) | (a.ntiles > 0 ? FL_PERSIST : 0) |
+                   ((!a.deconv && a.tail_wa) ? FL_LOGITS : 0);
     const int sg = a.sigma, st_ = a.stride, ks = P.KS;
     if (a.f1_img && !(P.MT == 8 && P.NT == 2 && ks == 5 && sg == 3 && mode == MODE_CONV && (fl & ~FL_PERSIST) == (FL_POOL | FL_FUSE1)))
         return fail(PSEG_EUNSUPPORTED, "first-layer fusion has no kernel instance for this shape");
@@ -1771,6 +1886,9 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, 0)            // unet: dense tile, three workgroups per CU
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_POOL)
     PSEG_TRY_INST(4, 4, 2, 1, 4, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv, dense tile
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_LOGITS)    // unet: last conv + logits + argmax
+    PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, FL_LOGITS)
+    if (fl & FL_LOGITS) return fail(PSEG_EUNSUPPORTED, "conv + logits fusion has no kernel instance for this shape");
     PSEG_TRY_INST(4, 4, 2, 1, 6, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv
     PSEG_TRY_INST(4, 5, 1, 1, 10, MODE_DECONV, 0)         // deconv2
     PSEG_TRY_INST(4, 4, 1, 1, 14, MODE_DECONV, 0)         // deconv4 (fcn_skip), two N blocks
@@ -1907,6 +2025,19 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     if (op.pool_dst >= 0) { const Tensor& pt = e.tensors[op.pool_dst]; a.pool_bytes = (unsigned)((size_t)e.tH(pt) * e.tW(pt) * pt.Cs * 2); }
     a.add = op.add >= 0 ? (const uint16_t*)e.tensors[op.add].d : nullptr;
     a.deconv = 0;
+    if (op.tail_logits >= 0) {   // logits / softmax / argmax in this conv's epilogue
+        const Op& lg = e.ops[op.tail_logits];
+        a.tail_C = lg.Cout;
+        a.H0 = e.H;
+        a.W0 = e.W;
+        a.tail_wa = P->d_tail_wa;
+        a.tail_wb = P->d_tail_wb;
+        a.tail_bias = P->d_tail_bias;
+        a.out_logits = e.cur_logits;
+        a.out_probs = e.cur_probs;
+        a.out_labels = e.cur_labels;
+        a.out_labels_u8 = e.cur_labels_u8;
+    }
     if (op.fuse1 >= 0) {
         const Op& c1 = e.ops[op.fuse1];
         auto* P1 = (MfmaPlan*)c1.plan;

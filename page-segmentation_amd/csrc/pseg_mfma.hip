@@ -396,7 +396,7 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             // (wave + 4j), so every address is a per-lane constant plus a scalar / immediate; remainder
             // tiles carry their row in the lane.  Each wave runs 10 full + 2 remainder tiles (the second
             // remainder slot is real only for wave 0 -- the others redo theirs, same values).
-            static_assert(HR == 20 && HC == 36, "conv1 tile walk is written for the 16x32 conv2 tile");
+            static_assert(HR % 4 == 0 && HC == 36, "conv1 tile walk: halo rows in fours, two 16-pixel tiles + 4 columns per row");
             auto c1_tile = [&](const char* src, char* dst, bool inc) {
                 f32x4 z0 = f32x4{0.f, 0.f, 0.f, 0.f}, z1 = z0;
 #pragma unroll
@@ -439,9 +439,10 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             {
                 const int hxR = 32 + (p16 & 3), hrL = p16 >> 2, gxR = ox0 - 2 + hxR;
                 const bool colR = gxR >= 0 && gxR < a.Win;
+                constexpr int NREM = HR / 4;                     // remainder tiles (4 rows x 4 columns each)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int q = (jj == 1 && wave == 0) ? 4 : wave;
+                for (int jj = 0; jj < (NREM + 3) / 4; ++jj) {
+                    const int q = min(wave + 4 * jj, NREM - 1);  // surplus slots redo the last tile (same values)
                     const int hr = 4 * q + hrL, gy = oy0 - 2 + hr;
                     c1_tile(f1 + (hxR & 1) * (UR * UCB) + (hxR & ~1) * 2 + hr * UCB, in_t + hr * a.row_pitch + hxR * c_PS2,
                             colR && gy >= 0 && gy < a.Hin);
@@ -1563,6 +1564,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->nblocks_n = cdiv(NTall, NT);
     P->NTtot = P->nblocks_n * NT;
     P->MT = (NT <= 2 && !deconv) ? 8 : 4;
+    // (the fused conv1+conv2 kernel was also tried with 8-row tiles -- 136 registers, 42 KB, three workgroups per
+    // CU: 182 vs 164 us; the halo recompute of conv1 grows from 1.41x to 1.69x and the weights stream twice as often)
     if (getenv("PSEG_MT")) P->MT = atoi(getenv("PSEG_MT")) == 8 && NT <= 2 ? 8 : 4;
     P->KS = KS;
     P->stride = deconv ? 1 : op.stride;

@@ -223,12 +223,14 @@ int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st) {
     while (Cp % 4 != 2) ++Cp;                  // LDS pixel stride: 2 (mod 4) floats
     const size_t budget = 150 * 1024;
     int MT = 0, THH = 0, TWH = (XTW - 1) * a.stride + a.KW;
-    for (int mt : {4, 2}) {
-        const int th = 4 * (mt / 2);
-        const int thh = (th - 1) * a.stride + a.KH;
-        if ((size_t)thh * TWH * Cp * 4 <= budget) { MT = mt; THH = thh; break; }
-    }
+    // 8-row tiles unless that leaves a single workgroup per CU and 4-row tiles fit twice (the MFMA pipe idles while
+    // the only resident workgroup stages its tile or stores its results)
+    auto lds_of = [&](int mt) { return (size_t)((4 * (mt / 2) - 1) * a.stride + a.KH) * TWH * Cp * 4; };
+    const size_t l4 = lds_of(4), l2 = lds_of(2);
+    if (l4 <= budget && (160 * 1024 / l4 >= 2 || l2 > budget || 160 * 1024 / l2 < 2 || getenv("PSEG_EXACT_MT4"))) MT = 4;
+    else if (l2 <= budget) MT = 2;
     if (!MT) return 0;
+    THH = (4 * (MT / 2) - 1) * a.stride + a.KH;
     const size_t lds = (size_t)THH * TWH * Cp * 4;
     const int ntall = cdiv(Ntot, 16);
     const int NT = ntall <= 4 ? ntall : (ntall == 5 ? 5 : 4);

@@ -347,34 +347,42 @@ constexpr int WGM_MAXT = 5;   // up to 80 channels per side
 
 // TI x TJ = accumulator tiles (input-channel tiles x output-channel tiles) the instance keeps: small
 // layers get small instances, hence many waves per SIMD to hide the operand-load latency.
-template <int TI, int TJ>
+// KXN = kernel columns handled by one workgroup (1, or the whole kernel row of a k5 layer when
+// 5 x TI x TJ accumulator tiles fit): the dY fragments of a pixel quad are then loaded once for the
+// five taps of the row instead of five times.
+template <int TI, int TJ, int KXN>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
     __shared__ float red[256];
-    const int tap = blockIdx.x;
-    const int ky = tap / a.KW, kx = tap % a.KW;
+    const int tap0 = blockIdx.x * KXN;                 // first tap of this workgroup
+    const int ky = tap0 / a.KW, kx0 = tap0 % a.KW;
     const int itW = a.mode == 0 ? a.Wy : a.Wx, itH = a.mode == 0 ? a.Hy : a.Hx;
     const int r0 = blockIdx.y * a.strip_rows, r1 = min(r0 + a.strip_rows, itH);
     const int tiles_ci = (a.XC + 15) >> 4, tiles_co = (a.Cout + 15) >> 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p16 = lane & 15, g = lane >> 4;
-    wg_f32x4 acc[TI][TJ];
+    wg_f32x4 acc[KXN][TI][TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int k = 0; k < KXN; ++k)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[k][i][j] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
     float bacc[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) bacc[j] = 0.0f;
-    const bool want_b = a.dB != nullptr && tap == 0;
+    const bool want_b = a.dB != nullptr && tap0 == 0;
 
-    auto load = [&](int y, int xq, float* xa, float* yb) {
+    auto load = [&](int y, int xq, float (*xa)[TI], float* yb) {
         const int x = xq + g;
-        int sy, sx;
-        if (a.mode == 0) { sy = y + ky - a.pt; sx = x + kx - a.pl; } else { sy = y; sx = x; }
-        const bool okx = x < itW && sy >= 0 && sy < a.Hx && sx >= 0 && sx < a.Wx;
-        const float* xp = a.X + ((size_t)sy * a.xpitch + sx) * a.XC + p16;
 #pragma unroll
-        for (int i = 0; i < TI; ++i) xa[i] = (i < tiles_ci && okx && i * 16 + p16 < a.XC) ? xp[i * 16] : 0.0f;
-        const int dy = a.mode == 0 ? y : 2 * y + (tap >> 1), dx = a.mode == 0 ? x : 2 * x + (tap & 1);
+        for (int k = 0; k < KXN; ++k) {
+            int sy, sx;
+            if (a.mode == 0) { sy = y + ky - a.pt; sx = x + kx0 + k - a.pl; } else { sy = y; sx = x; }
+            const bool okx = x < itW && sy >= 0 && sy < a.Hx && sx >= 0 && sx < a.Wx;
+            const float* xp = a.X + ((size_t)sy * a.xpitch + sx) * a.XC + p16;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) xa[k][i] = (i < tiles_ci && okx && i * 16 + p16 < a.XC) ? xp[i * 16] : 0.0f;
+        }
+        const int dy = a.mode == 0 ? y : 2 * y + (tap0 >> 1), dx = a.mode == 0 ? x : 2 * x + (tap0 & 1);
         const size_t o = ((size_t)dy * a.ypitch + dx) * a.Cout + p16;
         const bool oky = x < itW;
 #pragma unroll
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
     // quads of this wave: (row y, columns 4*(wave + 4n) .. +3), walked as one sequence
     const int qpr = (itW + 15) >> 4;                   // quads per wave per row
     const int nq = (r1 - r0) * qpr;
-    float xa[TI], yb[TJ], xn[TI], yn[TJ];
+    float xa[KXN][TI], yb[TJ], xn[KXN][TI], yn[TJ];
     if (nq > 0) load(r0, wave * 4, xa, yb);
     for (int q = 0; q < nq; ++q) {
         if (q + 1 < nq) {
@@ -398,20 +406,26 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
             load(r0 + yr, (xc * 4 + wave) * 4, xn, yn);
         }
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
-            if (i < tiles_ci)
+        for (int k = 0; k < KXN; ++k)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    if (j < tiles_co) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TI; ++i)
+                if (i < tiles_ci)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        if (j < tiles_co) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[k][i], yb[j], acc[k][i][j], 0, 0, 0);
         if (want_b)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) bacc[j] += yb[j];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) xa[i] = xn[i];
+        for (int k = 0; k < KXN; ++k)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) xa[k][i] = xn[k][i];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) yb[j] = yn[j];
     }
     // D tile: lane holds rows (ci) 4g..4g+3, column (co) p16.  Reduce the four waves through LDS.
+#pragma unroll
+    for (int k = 0; k < KXN; ++k)
 #pragma unroll
     for (int i = 0; i < TI; ++i)
         if (i < tiles_ci)
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 float* qd = red + (4 * g + r) * 16 + p16;
-                                *qd = w == 0 ? acc[i][j][r] : *qd + acc[i][j][r];
+                                *qd = w == 0 ? acc[k][i][j][r] : *qd + acc[k][i][j][r];
                             }
                         }
                         __syncthreads();
@@ -432,7 +446,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
                         const int e = threadIdx.x, row = e >> 4, col = e & 15;
                         const int ci = i * 16 + row, co = j * 16 + col;
                         if (ci < a.XC && co < a.Cout)
-                            atomicAdd(&a.dW[((size_t)tap * a.Cin + a.ci0 + ci) * a.Cout + co], red[e]);
+                            atomicAdd(&a.dW[((size_t)(tap0 + k) * a.Cin + a.ci0 + ci) * a.Cout + co], red[e]);
                     }
                     __syncthreads();
                 }
@@ -451,8 +465,17 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     // grid = (strips, taps) for the scalar kernel; the matrix-core kernel takes (taps, strips)
     if (a.XC <= 16 * WGM_MAXT && a.Cout <= 16 * WGM_MAXT && !getenv("PSEG_WGRAD_SCALAR")) {
         const int ti = (a.XC + 15) / 16, tj = (a.Cout + 15) / 16;
+        // a whole kernel row per workgroup for the small k5 layers (mode 0: taps of a row share dY)
+        if (a.mode == 0 && a.KW == 5 && grid.y % 5 == 0 && !getenv("PSEG_WGRAD_KX1")) {
+            WgradArgs a5 = a;                                  // five times fewer "taps": five times more strips
+            a5.strip_rows = std::max(1, a.strip_rows / 5);
+            const dim3 g5(grid.y / 5, cdiv(a.Hy, a5.strip_rows));
+#define PSEG_WG5(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) { wgrad_mfma_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a5); PSEG_HIP(hipGetLastError()); return PSEG_OK; }
+            PSEG_WG5(1, 2) PSEG_WG5(2, 2) PSEG_WG5(2, 3)
+#undef PSEG_WG5
+        }
         const dim3 g2(grid.y, grid.x);
-#define PSEG_WG(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) { wgrad_mfma_kernel<TI_, TJ_><<<g2, 256, 0, st>>>(a); PSEG_HIP(hipGetLastError()); return PSEG_OK; }
+#define PSEG_WG(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) { wgrad_mfma_kernel<TI_, TJ_, 1><<<g2, 256, 0, st>>>(a); PSEG_HIP(hipGetLastError()); return PSEG_OK; }
         PSEG_WG(1, 2) PSEG_WG(2, 2) PSEG_WG(2, 3) PSEG_WG(3, 3) PSEG_WG(3, 5) PSEG_WG(5, 3) PSEG_WG(5, 5)
 #undef PSEG_WG
     } else {

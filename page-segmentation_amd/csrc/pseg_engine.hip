@@ -277,6 +277,8 @@ int launch_conv_exact(const ConvArgs& a, hipStream_t st) {
 }
 
 int upload_weights(Engine& e) {
+    // the copies below are ordered on the null stream only: earlier asynchronous predicts must have finished
+    PSEG_HIP(hipDeviceSynchronize());
     for (auto& op : e.ops) {
         if (op.kparam < 0) continue;
         const Param& kp = e.params[op.kparam];
@@ -309,12 +311,17 @@ int upload_weights(Engine& e) {
     return PSEG_OK;
 }
 
-int set_canvas(Engine& e, int H, int W) {
+int set_canvas(Engine& e, int H, int W, hipStream_t st) {
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     const int Hp = round_up(H, 32), Wp = round_up(W, 32);
     e.H = H;
     e.W = W;
     if (Hp == e.Hp && Wp == e.Wp) return PSEG_OK;
+    // A canvas change re-allocates and clears the activation tensors.  Work of earlier calls may still be in
+    // flight on the engine's (non-blocking) stream or on a caller's stream: drain the device first, and clear on
+    // the stream the coming kernels run on -- a hipMemset on the null stream is NOT ordered with non-blocking
+    // streams (that race corrupted the first predict after shrinking from a 4096x3072 canvas).
+    PSEG_HIP(hipDeviceSynchronize());
     e.Hp = Hp;
     e.Wp = Wp;
     const size_t esz = e.mode == PSEG_MODE_BF16 ? 2 : 4;
@@ -325,13 +332,11 @@ int set_canvas(Engine& e, int H, int W) {
             t.bytes = 0;
             PSEG_HIP(hipMalloc(&t.d, bytes));
             t.bytes = bytes;
-            PSEG_HIP(hipMemset(t.d, 0, bytes));
         }
+        // float32 mode: fresh buffers start at zero; bf16 mode: the pad channels no kernel writes must read as
+        // zero after every layout change
+        if (t.d && bytes) PSEG_HIP(hipMemsetAsync(t.d, 0, bytes, st));
     }
-    // bf16 pad channels that no kernel writes must read as zero after a layout change
-    if (e.mode == PSEG_MODE_BF16)
-        for (auto& t : e.tensors)
-            if (t.d) PSEG_HIP(hipMemset(t.d, 0, t.bytes));
     const double px = (double)Hp * Wp;
     for (auto& op : e.ops) e.slots[op.timing_slot].flops = op.flops_per_canvas_px * px;
     // a launch that also runs a fused-away layer (conv1 inside conv2, logits inside the tail) does that layer's work too
@@ -496,7 +501,7 @@ static int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* 
     for (auto& p : e.params)
         if (!p.set) return fail(PSEG_EINVAL, "weight '%s' was never set", p.name.c_str());
     if (e.weights_dirty) PSEG_TRY(upload_weights(e));
-    PSEG_TRY(set_canvas(e, H, W));
+    PSEG_TRY(set_canvas(e, H, W, st));
     if (e.mode == PSEG_MODE_BF16)
         return run_bf16(e, d_img, d_logits, d_probs, d_labels, d_labels_u8, st);
     return run_exact(e, d_img, d_logits, d_probs, d_labels, d_labels_u8, st);

@@ -640,7 +640,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     for (auto& p : e.params)
         if (!p.set) return fail(PSEG_EINVAL, "weight '%s' was never set", p.name.c_str());
     if (e.weights_dirty) PSEG_TRY(upload_weights(e));
-    PSEG_TRY(set_canvas(e, H, W));
+    PSEG_TRY(set_canvas(e, H, W, e.stream));
     hipStream_t st = e.stream;
     const int C = e.n_classes;
     const size_t npx = (size_t)H * W;

@@ -126,3 +126,42 @@ def test_full_size_page_properties(gpu, oracle_mod):
     assert int(overlay.astype(np.int64).sum() + inverted.astype(np.int64).sum()) == int(color.astype(np.int64).sum())
     e32.close()
     eb.close()
+
+
+def test_config5_size_pipeline_properties(gpu, oracle_mod):
+    """BASELINE configs[4] size: 4096x3072, 6 classes, predict + cc_majority vote + masks on the GPU.  The
+    oracle cannot run this size in test time, so: determinism, interior-window agreement with a sub-page
+    (the receptive field is local), vote idempotence / label-set preservation, mask identities, and the
+    uint8 label map equal to the int64 one."""
+    import torch
+    from pseg_amd import synth
+    H, W, C = 4096, 3072, 6
+    img, binary, _ = synth.synth_page(5, H, W, C)
+    Wt = oracle_mod.init_weights("fcn_skip", C, seed=42, gain=1.5, bias_scale=0.05)
+    eb = gpu.Engine("fcn_skip", C, mode=gpu.MODE_BF16)
+    eb.set_weights(Wt)
+    _, _, lab = eb.predict(img, want_logits=False, want_probs=False)
+    _, _, lab2 = eb.predict(img, want_logits=False, want_probs=False)
+    assert lab.shape == (H, W) and lab.dtype == np.int64 and np.array_equal(lab, lab2)
+    assert 0 <= lab.min() and lab.max() < C
+    # device entry with a uint8 label map
+    d_img = torch.from_numpy(img).cuda()
+    d_u8 = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+    eb.predict_device(d_img.data_ptr(), H, W, d_labels_u8=d_u8.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_u8.cpu().numpy(), lab)
+    # interior window == same window of a 640x640 sub-page (borders > 72 px away)
+    y0, x0 = 2048, 1536
+    sub = np.ascontiguousarray(img[y0:y0 + 640, x0:x0 + 640])
+    zs, _, ls = eb.predict(sub, want_probs=False)
+    zf, _, _ = eb.predict(np.ascontiguousarray(img[y0 - 256:y0 + 896, x0 - 256:x0 + 896]), want_probs=False)
+    assert np.array_equal(zs[96:544, 96:544], zf[256 + 96:256 + 544, 256 + 96:256 + 544])
+    assert np.array_equal(ls[96:544, 96:544], lab[y0 + 96:y0 + 544, x0 + 96:x0 + 544])
+    # post-process at full size
+    v1 = gpu.cc_vote(lab.copy(), binary, C)
+    assert np.array_equal(gpu.cc_vote(v1.copy(), binary, C), v1)
+    assert np.array_equal(v1[binary == 0], lab[binary == 0]) and set(np.unique(v1)) <= set(np.unique(lab))
+    lut = np.array([[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255]], np.uint8)
+    color, overlay, inverted, fg = gpu.masks(v1, binary, lut)
+    assert np.array_equal(color, lut[v1]) and (overlay[binary == 1] == 0).all() and np.array_equal(inverted, fg)
+    eb.close()

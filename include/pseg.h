@@ -158,6 +158,9 @@ int pseg_eval_step(pseg_engine* e, const uint8_t* img, const uint8_t* mask, int 
  * `binary` (non-zero = ink); each takes its most frequent class in pred (ties -> lowest).
  * pred int64 (H,W) is updated in place, as the reference does. Host pointers. */
 int pseg_cc_vote(int device, int64_t* pred, const uint8_t* binary, int H, int W, int n_classes);
+/* Device variant: asynchronous on `stream`.  The label / histogram workspace is cached per calling thread
+ * and device and reused by the next call in stream order: issue the calls of one thread on one stream (or
+ * synchronise between streams). */
 int pseg_cc_vote_device(int device, int64_t* d_pred, const uint8_t* d_binary, int H, int W,
                         int n_classes, void* stream);
 

@@ -78,3 +78,15 @@ def test_otsu_char_height(gpu, oracle_mod):
     flat = np.full((64, 64), 200, np.uint8)
     h2, _ = gpu.otsu_char_height(flat)
     assert h2 is None and oracle_mod.compute_char_height_from_gray(flat) is None
+
+
+def test_post_process_call_sequences(gpu, oracle_mod):
+    """The cached vote workspace and the resize scratch must not leak between calls of different sizes."""
+    rng = np.random.default_rng(23)
+    cases = []
+    for H, W, C in [(300, 517, 4), (64, 5, 6), (1200, 900, 3), (97, 131, 3), (1, 1, 3)]:
+        pred, binary = _case(rng, H, W, C)
+        cases.append((pred, binary, C, oracle_mod.vote_connected_component_class(pred, binary)))
+    for k in rng.integers(0, len(cases), 25):
+        pred, binary, C, want = cases[int(k)]
+        assert np.array_equal(gpu.cc_vote(pred.copy(), binary, C), want)

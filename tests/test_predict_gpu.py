@@ -82,3 +82,50 @@ def test_predict_batch_matches_single_pages(gpu, oracle_mod, mode):
     again = eng.predict_batch(pages[::-1])
     assert all(np.array_equal(a, w) for a, w in zip(again, want[::-1]))
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_call_sequences_do_not_leak_state(gpu, oracle_mod, mode):
+    """One engine driven through a random sequence of host / device / batch predicts, canvas growth and
+    shrinkage and weight changes must return exactly what a fresh engine returns for each input."""
+    import torch
+    m = gpu.MODE_BF16 if mode == "bf16" else gpu.MODE_F32_EXACT
+    rng = np.random.default_rng(17)
+    shapes = [(64, 96), (1024, 1536), (33, 50), (512, 384), (2048, 1024), (96, 64)]
+    pages = {s: rng.integers(0, 256, s, dtype=np.uint8) for s in shapes}
+    weights = [oracle_mod.init_weights("fcn_skip", 3, seed=sd, gain=1.5, bias_scale=0.05) for sd in (1, 2)]
+    want = {}
+    for wi, Wt in enumerate(weights):
+        for s in shapes:
+            f = gpu.Engine("fcn_skip", 3, mode=m)
+            f.set_weights(Wt)
+            want[(wi, s)] = f.predict(pages[s], want_probs=False)
+            f.close()
+    eng = gpu.Engine("fcn_skip", 3, mode=m)
+    wi = 0
+    eng.set_weights(weights[wi])
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(40):
+        op = int(rng.integers(0, 5))
+        s = shapes[int(rng.integers(0, len(shapes)))]
+        if op == 0:                                              # change the weights
+            wi = 1 - wi
+            eng.set_weights(weights[wi])
+        elif op == 1:                                            # host entry with logits
+            z, _, l = eng.predict(pages[s], want_probs=False)
+            assert np.array_equal(z, want[(wi, s)][0]) and np.array_equal(l, want[(wi, s)][2]), (step, s)
+        elif op == 2:                                            # host entry, labels only
+            l = eng.predict(pages[s], want_logits=False, want_probs=False)[2]
+            assert np.array_equal(l, want[(wi, s)][2]), (step, s)
+        elif op == 3:                                            # device entry on torch's stream, uint8 labels
+            d_img = torch.from_numpy(pages[s]).cuda()
+            d_u8 = torch.empty(s, dtype=torch.uint8, device="cuda")
+            eng.predict_device(d_img.data_ptr(), s[0], s[1], d_labels_u8=d_u8.data_ptr(), stream=st)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_u8.cpu().numpy(), want[(wi, s)][2]), (step, s)
+        else:                                                    # batch of three ragged pages
+            ss = [shapes[int(i)] for i in rng.integers(0, len(shapes), 3)]
+            out = eng.predict_batch([pages[q] for q in ss])
+            for q, o in zip(ss, out):
+                assert np.array_equal(o, want[(wi, q)][2]), (step, q)
+    eng.close()

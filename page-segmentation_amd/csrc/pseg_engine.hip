@@ -307,6 +307,9 @@ int upload_weights(Engine& e) {
         PSEG_HIP(hipMemcpy(op.d_b, bp.host.data(), (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
         if (e.mode == PSEG_MODE_BF16) PSEG_TRY(mfma_pack_op(e, op, w, bp.host));
     }
+    // copies from pageable memory may still be in their final DMA when hipMemcpy returns, and the null stream is
+    // not ordered with the engine's non-blocking stream: finish them before any kernel can read the weights
+    PSEG_HIP(hipDeviceSynchronize());
     e.weights_dirty = false;
     return PSEG_OK;
 }
@@ -656,6 +659,7 @@ int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
         delete h;
         return fail(PSEG_EHIP, "LUT upload failed");
     }
+    (void)hipDeviceSynchronize();
     *out = h;
     return PSEG_OK;
 }

@@ -627,6 +627,7 @@ static int train_init(Engine& e, float b1, float b2, float eps, float clipnorm, 
     PSEG_HIP(hipMalloc((void**)&t->d_norm, e.params.size() * 4));
     PSEG_HIP(hipMemset(t->d_m, 0, (size_t)t->nparam * 4));
     PSEG_HIP(hipMemset(t->d_v, 0, (size_t)t->nparam * 4));
+    PSEG_HIP(hipDeviceSynchronize());   // null-stream memsets are not ordered with the engine's non-blocking stream
     t->tgrad.assign(e.tensors.size(), nullptr);
     t->tbytes.assign(e.tensors.size(), 0);
     return PSEG_OK;
@@ -913,6 +914,7 @@ int pseg_train_set_optimizer(pseg_engine* h, int optimizer) {
     PSEG_HIP(hipStreamSynchronize(h->e.stream));
     PSEG_HIP(hipMemset(t->d_m, 0, (size_t)t->nparam * 4));
     PSEG_HIP(hipMemset(t->d_v, 0, (size_t)t->nparam * 4));
+    PSEG_HIP(hipDeviceSynchronize());   // null-stream memsets are not ordered with the engine's non-blocking stream
     t->optimizer = optimizer;
     t->step = 0;
     t->m_schedule = 1.0;

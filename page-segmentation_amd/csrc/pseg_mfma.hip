@@ -204,6 +204,7 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     // weights and the k-chunk table are staged once, then the workgroup walks several tiles
     constexpr bool c_persist = FIXED && (FL_ & FL_PERSIST) != 0;
     const int c_dbg = PSEG_DIAG ? a.dbg : 0;
+    const bool getenv_vgpr_inrelu = (a.dbg & 16) != 0;   // host knob PSEG_INRELU_VGPR: old VGPR staging path for pre-activation ReLU
     unsigned long long* const c_trace = PSEG_DIAG ? a.trace : nullptr;
     char* in_t = smem;
     char* w_t = smem + a.lds_w_off;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
                             colR && gy >= 0 && gy < a.Hin);
                 }
             }
-        } else if (!(c_dbg & 1) && !c_inrelu && nbi == 0) {
+        } else if (!(c_dbg & 1) && (!c_inrelu || !getenv_vgpr_inrelu) && nbi == 0) {
             // LDS-DMA staging (buffer_load_dwordx4 ... lds): lane L of one instruction fills
             // the 16-byte slot (j*64 + L) of a tile row, slot = pixel*sigma + chunk.  A lane
             // whose pixel lies outside the image, or whose slot is row padding (chunk >= nc),
@@ -554,6 +555,16 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             lds_barrier();
             if (c_trace) { const long long t1 = __builtin_amdgcn_s_memtime(); acc_wait += t1 - tw0; tw0 = t1; }
             if (b == 0 && lg == 0) { PSEG_STAMP(4) }
+            if (c_inrelu && lg == 0 && !getenv_vgpr_inrelu) {
+                // pre-activation ReLU (res_unet) on the tile the DMA just delivered: one in-place pass over
+                // the LDS tile (zeros of the padding stay zeros), then every wave may read it
+                const int tile_bytes = c_THH * a.row_pitch;
+                for (int i = tid * 16; i < tile_bytes; i += NTHR * 16) {
+                    uint4* q = (uint4*)(in_t + i);
+                    *q = relu_bf16x8(*q);
+                }
+                lds_barrier();
+            }
             if (gq + D < G) stage_w(gq + D, slot_n);  // reuses the slot of group gq-1: free after the barrier
             if (c_trace) acc_issue += __builtin_amdgcn_s_memtime() - tw0;
             slot_n = slot_n + 1 == a.NB ? 0 : slot_n + 1;
@@ -733,10 +744,23 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             const int y = oy0 + wave * (MT / 2) + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
             const bool inb = y < a.H0 && x < a.W0;
             uint32_t pk[NT][2];
+            uint2 adr[NT];
+            if (c_add) {   // residual operand of the block (res_unet): same pixel, this lane's four couts per tile
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.add, 0, a.dst_bytes, 0x00020000);
+                const bool inp = y < a.Hout && x < a.Wout;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    adr[t] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(
+                        ra, inp ? (unsigned)(y * a.Wout + x) * (unsigned)(a.nch_out * 16) + (unsigned)(t * 16 + 4 * g) * 2u : 0xfffffff0u, 0, 0));
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 float v0 = acc[m][t][0] + biasr[t].x, v1 = acc[m][t][1] + biasr[t].y;
                 float v2 = acc[m][t][2] + biasr[t].z, v3 = acc[m][t][3] + biasr[t].w;
+                if (c_add) {
+                    v0 += d_bf2f((uint16_t)(adr[t].x & 0xffff)); v1 += d_bf2f((uint16_t)(adr[t].x >> 16));
+                    v2 += d_bf2f((uint16_t)(adr[t].y & 0xffff)); v3 += d_bf2f((uint16_t)(adr[t].y >> 16));
+                }
                 if (a.relu) { v0 = vmax(v0, 0.f); v1 = vmax(v1, 0.f); v2 = vmax(v2, 0.f); v3 = vmax(v3, 0.f); }
                 pk[t][0] = pk_bf16(v0, v1);
                 pk[t][1] = pk_bf16(v2, v3);
@@ -813,14 +837,23 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
         const int n = (nb * NT + t) * 16 + 4 * g;
         const unsigned noff = n < CsO ? (unsigned)n * 2u : OOBS;
         float v[MT][4];
+        // residual operand (res_unet): the MT loads of this cout tile are all requested before the first use
+        uint2 adr[MT];
+        if (c_add) {
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.add, 0, a.dst_bytes, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const unsigned o = (pixoff[m] == OOBS || noff == OOBS) ? OOBS : pixoff[m] + noff;
+                adr[m] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(ra, o, 0, 0));
+            }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             v[m][0] = acc[m][t][0] + biasr[t].x; v[m][1] = acc[m][t][1] + biasr[t].y;
             v[m][2] = acc[m][t][2] + biasr[t].z; v[m][3] = acc[m][t][3] + biasr[t].w;
             const unsigned o = (pixoff[m] == OOBS || noff == OOBS) ? OOBS : pixoff[m] + noff;
             if (c_add) {
-                const uint2 ad = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(
-                    __builtin_amdgcn_make_buffer_rsrc((void*)a.add, 0, a.dst_bytes, 0x00020000), o, 0, 0));
+                const uint2 ad = adr[m];
                 v[m][0] += d_bf2f((uint16_t)(ad.x & 0xffff)); v[m][1] += d_bf2f((uint16_t)(ad.x >> 16));
                 v[m][2] += d_bf2f((uint16_t)(ad.y & 0xffff)); v[m][3] += d_bf2f((uint16_t)(ad.y >> 16));
             }
@@ -1360,8 +1393,9 @@ int mfma_plan_graph(Engine& e) {
             const int pi = producer_of(e, lg.src0);
             if (pi < 0) continue;
             Op& cv = e.ops[pi];
-            if (cv.type != OP_CONV || cv.Cout != 64 || cv.stride != 1 || cv.k != 3 || cv.up0 || cv.up1 || cv.in_relu ||
-                cv.add >= 0 || cv.transposed || cv.pool_dst >= 0) continue;
+            if (cv.type != OP_CONV || cv.Cout != 64 || cv.stride != 1 || cv.k != 3 || cv.up0 || cv.up1 ||
+                cv.transposed || cv.pool_dst >= 0) continue;
+            if ((cv.in_relu != 0) != (cv.add >= 0)) continue;    // plain conv (unet) or pre-activation + residual add (res_unet)
             int users = 0;
             for (auto& o : e.ops) users += (o.src0 == lg.src0) + (o.src1 == lg.src0) + (o.add == lg.src0);
             if (users != 1) continue;
@@ -1603,7 +1637,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         P->wg3 = P->NW == 4 && !deconv && ((KS == 5 && (NT == 3 || NT == 4) && P->nblocks_n == 1) || (KS == 3 && NT == 4 && !getenv("PSEG_NO_WG3_K3")) ||
                                                  (KS == 2 && NT == 4 && op.up0 && !s1 && !getenv("PSEG_NO_WG3_K3"))) &&
                  (P->nc_full == 4 || P->nc_full == 5) && op.stride == 1 &&
-                 (!op.up0 || KS == 2) && !op.up1 && !op.in_relu && op.add < 0 && op.fuse1 < 0 &&
+                 (!op.up0 || KS == 2 || KS == 3) && !op.up1 && ((!op.in_relu && op.add < 0) || (KS == 3 && !getenv("PSEG_NO_WG3_RES"))) && op.fuse1 < 0 &&
                  !getenv("PSEG_GENERIC") && !getenv("PSEG_NO_WG3");
         if (P->wg3 || (!getenv("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16))) {
             sigma = P->nc_full;
@@ -1889,8 +1923,13 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, 0)            // unet: dense tile, three workgroups per CU
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_POOL)
     PSEG_TRY_INST(4, 4, 2, 1, 4, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv, dense tile
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_UP0)                   // res_unet decoder: shortcut conv on [up, skip]
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_UP0 | FL_INRELU)       // res_unet decoder: first conv of the block
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_INRELU | FL_ADD)       // res_unet: second conv + residual add
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_INRELU)                // res_unet bridge
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_LOGITS)    // unet: last conv + logits + argmax
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, FL_LOGITS)
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_INRELU | FL_ADD | FL_LOGITS)   // res_unet: last block + logits + argmax
     if (fl & FL_LOGITS) return fail(PSEG_EUNSUPPORTED, "conv + logits fusion has no kernel instance for this shape");
     PSEG_TRY_INST(4, 4, 2, 1, 6, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv
     PSEG_TRY_INST(4, 5, 1, 1, 10, MODE_DECONV, 0)         // deconv2
@@ -1964,6 +2003,7 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.nb_loop = 1;
     a.nb_total = P.nblocks_n;
     a.dbg = (PSEG_DIAG && getenv("PSEG_DBG")) ? atoi(getenv("PSEG_DBG")) : 0;
+    if (getenv("PSEG_INRELU_VGPR")) a.dbg |= 16;
 }
 
 int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {

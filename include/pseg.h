@@ -136,6 +136,11 @@ int pseg_train_set_loss(pseg_engine* e, int loss);
 int pseg_train_forward_backward(pseg_engine* e, const uint8_t* img, const uint8_t* mask, int H,
                                 int W, float metrics[4]);
 
+/* Same with a float32 page on the 0..255 scale (an augmented sample, lib/network.py:149-161: the cubic warp
+ * leaves non-integer values); the network input is img / 255.0f. */
+int pseg_train_forward_backward_f32(pseg_engine* e, const float* img, const uint8_t* mask, int H, int W,
+                                    float metrics[4]);
+
 /* The flat device gradient buffer (all parameters in weight-table order, then the metric
  * accumulators): data-parallel training all-reduces exactly this buffer (one RCCL call), then
  * applies with grad_scale = 1/world. */
@@ -207,6 +212,13 @@ int pseg_resize_nearest(int device, const void* src, int H, int W, int elem_byte
  * per-axis kernels with radii ry / rx (NULL: built with pseg_gaussian_kernel). */
 int pseg_scale_image(int device, const void* src, int src_is_f64, int H, int W, double* dst,
                      int Ho, int Wo, const double* wy, int ry, const double* wx, int rx);
+
+/* Augmentation warp (lib/data_generator.py / lib/network.py:149-161: keras-preprocessing's
+ * apply_affine_transform -> scipy.ndimage.affine_transform(x, m, off, order, mode='nearest')): output pixel
+ * (r, c) samples the input at m (r, c) + off; order 3 = cubic B-spline with prefilter (image), order 0 =
+ * nearest (binary, mask).  float32 (H,W) planes, host pointers. */
+int pseg_affine_warp(int device, const float* src, int H, int W, const double m[4], const double off[2],
+                     int order, float* dst);
 
 /* prepare_images (lib/dataset.py:131-150), all pixel work on the device in one call.
  * image, binary: uint8 (H0,W0) scan and binarisation (paper = 1 or 255).  (H1,W1) =

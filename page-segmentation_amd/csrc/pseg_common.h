@@ -127,6 +127,7 @@ struct Engine {
     size_t lab_stage_bytes = 0, prob_stage_bytes = 0, logit_stage_bytes = 0;
     void* train = nullptr;   // TrainState (pseg_train.hip), f32 mode only
     void* batch = nullptr;   // BatchState (pseg_predict_batch): copy streams, events, two staging slots
+    const float* cur_img_f32 = nullptr;   // float32 exact mode: float page (0..255 scale) instead of the uint8 one (augmented training samples)
     // timing
     bool timing = false;
     std::vector<TimingSlot> slots;

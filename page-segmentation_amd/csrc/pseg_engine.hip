@@ -176,6 +176,18 @@ __global__ void preprocess_exact_kernel(const uint8_t* img, int H, int W, int C,
     }
 }
 
+// float page (augmented training samples, values on the 0..255 scale): preprocess = x / 255.0f (numpy float32 / python float)
+__global__ void preprocess_exact_f32_kernel(const float* img, int H, int W, int C, float* dst, int Hp, int Wp) {
+    const size_t n = (size_t)Hp * Wp * C;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const size_t p = t / C;
+        const int x = (int)(p % Wp), y = (int)(p / Wp);
+        dst[t] = (y < H && x < W) ? img[((size_t)y * W + x) * C + c] / 255.0f : 0.0f;
+    }
+}
+
 // softmax(-1) and argmax(-1) of the float32 logits (lib/network.py:258-259): max-subtracted
 // exp / sum in f32 (scipy.special.softmax on f32 input); argmax first-maximum-wins.
 __global__ void softmax_argmax_kernel(const float* logits, size_t n, int C, float* probs,
@@ -356,8 +368,11 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
     {
         const size_t n = (size_t)e.Hp * e.Wp * in.C;
         const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-        preprocess_exact_kernel<<<grid, 256, 0, st>>>(d_img, e.H, e.W, in.C, e.d_lut, (float*)in.d,
-                                                      e.Hp, e.Wp);
+        if (e.cur_img_f32)
+            preprocess_exact_f32_kernel<<<grid, 256, 0, st>>>(e.cur_img_f32, e.H, e.W, in.C, (float*)in.d, e.Hp, e.Wp);
+        else
+            preprocess_exact_kernel<<<grid, 256, 0, st>>>(d_img, e.H, e.W, in.C, e.d_lut, (float*)in.d,
+                                                          e.Hp, e.Wp);
     }
     for (auto& op : e.ops) {
         hipEvent_t ev0;

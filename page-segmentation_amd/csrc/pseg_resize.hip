@@ -201,6 +201,95 @@ __global__ __launch_bounds__(256) void prep_map_kernel(const void* src, void* ds
     }
 }
 
+// ---- affine warp of the augmentation pipeline (lib/data_generator.py -> keras-preprocessing
+// apply_affine_transform -> scipy.ndimage.affine_transform, mode 'nearest') -------------------------------
+// order 3: scipy edge-pads the plane by 12 pixels, runs the cubic B-spline prefilter (pole sqrt(3) - 2, gain 6,
+// mirror initialisation) along both axes in float64 and evaluates the four-tap B-spline at
+// M (r, c) + offset with coordinates clamped to the padded plane; order 0: floor(coord + 0.5), clamped.
+constexpr int WARP_PAD = 12;
+
+__global__ __launch_bounds__(256) void warp_pad_kernel(const float* src, int H, int W, double* dst) {
+    const int Wp = W + 2 * WARP_PAD, Hp = H + 2 * WARP_PAD;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= Wp || y >= Hp) return;
+    const int sy = min(max(y - WARP_PAD, 0), H - 1), sx = min(max(x - WARP_PAD, 0), W - 1);
+    dst[(size_t)y * Wp + x] = (double)src[(size_t)sy * W + sx];
+}
+
+// one thread = one line (row: AXIS 1, column: AXIS 0) of the padded plane, in place
+template <int AXIS>
+__global__ __launch_bounds__(64) void spline3_prefilter_kernel(double* c, int Hp, int Wp) {
+    const int line = blockIdx.x * 64 + threadIdx.x;
+    const int nlines = AXIS == 1 ? Hp : Wp, n = AXIS == 1 ? Wp : Hp;
+    if (line >= nlines) return;
+    double* p = AXIS == 1 ? c + (size_t)line * Wp : c + line;
+    const size_t st = AXIS == 1 ? 1 : (size_t)Wp;
+    const double z = -0.2679491924311227;          // sqrt(3) - 2
+    for (int i = 0; i < n; ++i) p[i * st] *= 6.0;   // gain (1 - z)(1 - 1/z)
+    // causal initialisation, mirror boundary: c+[0] = sum_k z^k c[k] (|z|^k < 1e-15 after 27 terms)
+    {
+        const int hor = min(n, 28);
+        double zi = z, sum = p[0];
+        if (hor < n) {
+            for (int i = 1; i < hor; ++i) { sum += zi * p[i * st]; zi *= z; }
+        } else {
+            const double iz = 1.0 / z;
+            double z2 = 1.0;
+            for (int i = 0; i < n - 1; ++i) z2 *= z;          // z^(n-1)
+            double z2n = z2;
+            sum = p[0] + z2 * p[(size_t)(n - 1) * st];
+            z2 = z2 * z2 * iz;
+            zi = z;
+            for (int i = 1; i < n - 1; ++i) { sum += (zi + z2) * p[i * st]; zi *= z; z2 *= iz; }
+            sum /= (1.0 - z2n * z2n);
+        }
+        p[0] = sum;
+    }
+    for (int i = 1; i < n; ++i) p[i * st] += z * p[(i - 1) * st];
+    p[(size_t)(n - 1) * st] = (z / (z * z - 1.0)) * (n > 1 ? z * p[(size_t)(n - 2) * st] + p[(size_t)(n - 1) * st] : p[0] * (1.0 + z));
+    for (int i = n - 2; i >= 0; --i) p[i * st] = z * (p[(i + 1) * st] - p[i * st]);
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void affine_warp_kernel(const double* coef, const float* src, int H, int W, float* dst,
+                                                          double m00, double m01, double m10, double m11, double o0, double o1) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const double y = m00 * (double)r + m01 * (double)c + o0, x = m10 * (double)r + m11 * (double)c + o1;
+    if (ORDER == 0) {
+        const int iy = min(max((int)floor(y + 0.5), 0), H - 1), ix = min(max((int)floor(x + 0.5), 0), W - 1);
+        dst[(size_t)r * W + c] = src[(size_t)iy * W + ix];
+        return;
+    }
+    const int Hp = H + 2 * WARP_PAD, Wp = W + 2 * WARP_PAD;
+    const double yp = fmin(fmax(y + WARP_PAD, 0.0), (double)(Hp - 1)), xp = fmin(fmax(x + WARP_PAD, 0.0), (double)(Wp - 1));
+    const int y0 = (int)floor(yp), x0 = (int)floor(xp);
+    const double ty = yp - y0, tx = xp - x0;
+    auto w3 = [](double t, double* w) {
+        const double u = 1.0 - t;
+        w[0] = u * u * u / 6.0;
+        w[1] = (4.0 - 6.0 * t * t + 3.0 * t * t * t) / 6.0;
+        w[2] = (4.0 - 6.0 * u * u + 3.0 * u * u * u) / 6.0;
+        w[3] = t * t * t / 6.0;
+    };
+    double wy[4], wx[4];
+    w3(ty, wy);
+    w3(tx, wx);
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = min(max(y0 - 1 + i, 0), Hp - 1);
+        double row = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = min(max(x0 - 1 + j, 0), Wp - 1);
+            row += wx[j] * coef[(size_t)yy * Wp + xx];
+        }
+        acc += wy[i] * row;
+    }
+    dst[(size_t)r * W + c] = (float)acc;
+}
+
 static void warp_coeffs(int n_in, int n_out, double* f, double* t) {
     *f = (double)n_in / (double)n_out;
     *t = *f * 0.5 - 0.5;
@@ -379,6 +468,35 @@ int pseg_scale_image(int device, const void* src, int src_is_f64, int H, int W, 
         PSEG_TRY(scale_image_dev<uint8_t>(mem, d_s, H, W, d_out, Ho, Wo, wy, ry, wx, rx, d_stats, nullptr));
     }
     PSEG_HIP(hipMemcpy(dst, d_out, no * 8, hipMemcpyDeviceToHost));
+    return PSEG_OK;
+}
+
+int pseg_affine_warp(int device, const float* src, int H, int W, const double m[4], const double off[2], int order,
+                     float* dst) {
+    if (!src || !dst || !m || !off) return fail(PSEG_EINVAL, "NULL argument");
+    if (order != 0 && order != 3) return fail(PSEG_EUNSUPPORTED, "interpolation order %d (0 and 3 are built)", order);
+    PSEG_TRY(check_shape(H, W, H, W));
+    PSEG_TRY(rz_set_dev(device));
+    DevMem mem;
+    const size_t n = (size_t)H * W;
+    float *d_s = nullptr, *d_d = nullptr;
+    PSEG_TRY(mem.alloc(&d_s, n));
+    PSEG_TRY(mem.alloc(&d_d, n));
+    PSEG_HIP(hipMemcpy(d_s, src, n * 4, hipMemcpyHostToDevice));
+    const dim3 grid(cdiv(W, 256), H);
+    if (order == 0) {
+        affine_warp_kernel<0><<<grid, 256>>>(nullptr, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1]);
+    } else {
+        const int Hp = H + 2 * WARP_PAD, Wp = W + 2 * WARP_PAD;
+        double* d_c = nullptr;
+        PSEG_TRY(mem.alloc(&d_c, (size_t)Hp * Wp));
+        warp_pad_kernel<<<dim3(cdiv(Wp, 256), Hp), 256>>>(d_s, H, W, d_c);
+        spline3_prefilter_kernel<0><<<cdiv(Wp, 64), 64>>>(d_c, Hp, Wp);     // axis 0 first, as scipy's spline_filter
+        spline3_prefilter_kernel<1><<<cdiv(Hp, 64), 64>>>(d_c, Hp, Wp);
+        affine_warp_kernel<3><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1]);
+    }
+    PSEG_HIP(hipGetLastError());
+    PSEG_HIP(hipMemcpy(dst, d_d, n * 4, hipMemcpyDeviceToHost));
     return PSEG_OK;
 }
 

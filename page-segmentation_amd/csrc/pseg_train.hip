@@ -634,7 +634,8 @@ static int train_init(Engine& e, float b1, float b2, float eps, float clipnorm, 
 }
 
 // forward + loss/metrics (+ backward when `backward`); inputs are host pointers
-static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int H, int W, bool backward) {
+static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int H, int W, bool backward,
+                         const float* img_f32 = nullptr) {
     TrainState* t = TS(e);
     if (!t) return fail(PSEG_EINVAL, "pseg_train_init has not been called");
     PSEG_HIP(hipSetDevice(e.device));
@@ -645,7 +646,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     hipStream_t st = e.stream;
     const int C = e.n_classes;
     const size_t npx = (size_t)H * W;
-    PSEG_TRY(ensure_buf((void**)&t->d_img, &t->img_bytes, npx * e.in_ch));
+    PSEG_TRY(ensure_buf((void**)&t->d_img, &t->img_bytes, npx * e.in_ch * (img_f32 ? 4 : 1)));
     PSEG_TRY(ensure_buf((void**)&t->d_mask, &t->mask_bytes, npx));
     size_t lb = t->logits_bytes;
     PSEG_TRY(ensure_buf((void**)&t->d_logits, &lb, npx * C * 4));
@@ -653,9 +654,13 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     PSEG_TRY(ensure_buf((void**)&t->d_dlogits, &lb, npx * C * 4));
     t->logits_bytes = lb;
     t->H = H; t->W = W;
-    PSEG_HIP(hipMemcpyAsync(t->d_img, img, npx * e.in_ch, hipMemcpyHostToDevice, st));
+    if (img_f32) PSEG_HIP(hipMemcpyAsync(t->d_img, img_f32, npx * e.in_ch * 4, hipMemcpyHostToDevice, st));
+    else PSEG_HIP(hipMemcpyAsync(t->d_img, img, npx * e.in_ch, hipMemcpyHostToDevice, st));
     PSEG_HIP(hipMemcpyAsync(t->d_mask, mask, npx, hipMemcpyHostToDevice, st));
-    PSEG_TRY(run_exact(e, t->d_img, t->d_logits, nullptr, nullptr, nullptr, st));
+    e.cur_img_f32 = img_f32 ? (const float*)t->d_img : nullptr;
+    const int rc_fwd = run_exact(e, t->d_img, t->d_logits, nullptr, nullptr, nullptr, st);
+    e.cur_img_f32 = nullptr;
+    PSEG_TRY(rc_fwd);
     float* acc = t->d_grad + t->nparam;
     // a backward pass starts from zeroed parameter gradients; an evaluation step only resets the metric slots
     if (backward) PSEG_HIP(hipMemsetAsync(t->d_grad, 0, (size_t)t->nflat * 4, st));
@@ -936,6 +941,14 @@ int pseg_train_forward_backward(pseg_engine* h, const uint8_t* img, const uint8_
     if (!h || !img || !mask) return fail(PSEG_EINVAL, "NULL argument");
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     PSEG_TRY(train_fwd_bwd(h->e, img, mask, H, W, true));
+    if (metrics) PSEG_TRY(train_metrics(h->e, metrics));
+    return PSEG_OK;
+}
+
+int pseg_train_forward_backward_f32(pseg_engine* h, const float* img, const uint8_t* mask, int H, int W, float metrics[4]) {
+    if (!h || !img || !mask) return fail(PSEG_EINVAL, "NULL argument");
+    if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
+    PSEG_TRY(train_fwd_bwd(h->e, nullptr, mask, H, W, true, img));
     if (metrics) PSEG_TRY(train_metrics(h->e, metrics));
     return PSEG_OK;
 }

@@ -154,10 +154,14 @@ class Network:
         foreground masking, batch of one; keys 'input_1' / 'input_2' / 'logits'."""
         from .architecture import default_preprocess
         from .util import image_to_batch
-        if self.type == 'train' and data_augmentation:
-            raise Exception("data augmentation (keras-preprocessing affine warps) is not built in the "
-                            "MI355X engine yet; train with data_augmentation=False (the reference default)")
+        augment = self.type == 'train' and data_augmentation
+        if augment:
+            if data_augmentation_settings is None:
+                from .trainer import AugmentationSettings
+                data_augmentation_settings = AugmentationSettings()
+            image_gen, binary_gen, mask_gen = self._create_data_augmentation(data_augmentation_settings)
         data = train_data.data
+        seed = 0
         while True:
             if self.type == 'train' and shuffle:
                 np.random.shuffle(data)
@@ -170,8 +174,23 @@ class Network:
                     assert i.dtype == np.uint8
                 if self.foreground_masks:
                     m[b != 1] = 0
-                yield ({'input_1': image_to_batch(default_preprocess(i)), 'input_2': image_to_batch(b)},
-                       {'logits': image_to_batch(m)})
+                if augment:
+                    seed += 1                                   # one seed per sample, shared by the three generators
+                    i_n = next(image_gen.flow(image_to_batch(i), seed=seed, batch_size=1))
+                    b_n = next(binary_gen.flow(image_to_batch(b), seed=seed, batch_size=1))
+                    m_n = next(mask_gen.flow(image_to_batch(m), seed=seed, batch_size=1))
+                    yield ({'input_1': default_preprocess(i_n), 'input_2': b_n}, {'logits': m_n})
+                else:
+                    yield ({'input_1': image_to_batch(default_preprocess(i)), 'input_2': image_to_batch(b)},
+                           {'logits': image_to_batch(m)})
+
+    def _create_data_augmentation(self, data_augmentation_settings):
+        """lib/network.py:109-125: image (cubic), binary and mask (nearest) generators with shared settings."""
+        from .data_generator import ImageDataGeneratorCustom
+        image_gen = ImageDataGeneratorCustom(**data_augmentation_settings.to_image_params(), data_format='channels_last')
+        binary_gen = ImageDataGeneratorCustom(**data_augmentation_settings.to_binary_params(), data_format='channels_last')
+        mask_gen = ImageDataGeneratorCustom(**data_augmentation_settings.to_mask_params(), data_format='channels_last')
+        return image_gen, binary_gen, mask_gen
 
     def _ensure_train_state(self):
         if getattr(self, "_train_ready", False):
@@ -222,16 +241,29 @@ class Network:
                    "val_loss": [], "val_accuracy": [], "lr": []}
         train = s.train_data.data
         n = len(train)
+        if s.data_augmentation:
+            image_gen, _, mask_gen = self._create_data_augmentation(s.data_augmentation_settings)
         it = 0
         for epoch in range(s.n_epoch):
             np.random.shuffle(train)                      # lib/network.py:134-135 (in place)
-            def fb(k):
+            def fb(k, epoch=epoch):
                 d = train[k]
                 img = gray_to_rgb(d.image) if self._rgb else d.image
                 m = d.mask
                 if self.foreground_masks and d.binary is not None:
                     m[d.binary != 1] = 0
-                return self.model.train_forward_backward(img, m)
+                if not s.data_augmentation:
+                    return self.model.train_forward_backward(img, m)
+                # lib/network.py:149-161: one seed per sample (1, 2, ... in draw order; here epoch * n + k + 1,
+                # the same numbers at world 1 and independent of the rank count), shared by the image (cubic)
+                # and mask (nearest) warps; the float page keeps the 0..255 scale, the engine divides by 255
+                seed = epoch * n + k + 1
+                from .util import image_to_batch
+                i_n = next(image_gen.flow(image_to_batch(img), seed=seed, batch_size=1))[0]
+                m_n = next(mask_gen.flow(image_to_batch(m), seed=seed, batch_size=1))[0, ..., 0]
+                if i_n.shape[-1] == 1:
+                    i_n = i_n[..., 0]
+                return self.model.train_forward_backward_float(i_n, m_n.astype(np.uint8))
 
             def apply(scale):
                 nonlocal it

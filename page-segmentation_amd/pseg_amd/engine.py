@@ -17,12 +17,12 @@ EXPORTED_SYMBOLS = (
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
     "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_get_activation", "pseg_flops_per_pixel",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
-    "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_set_loss", "pseg_train_forward_backward", "pseg_train_grad_buffer", "pseg_train_metrics",
+    "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_set_loss", "pseg_train_forward_backward", "pseg_train_forward_backward_f32", "pseg_train_grad_buffer", "pseg_train_metrics",
     "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
     "pseg_cc_vote", "pseg_cc_vote_device", "pseg_bbox_fill", "pseg_masks", "pseg_masks_device",
     "pseg_otsu_char_height",
     "pseg_rescale_shape", "pseg_gaussian_kernel", "pseg_resize_nearest", "pseg_scale_image",
-    "pseg_prepare_images",
+    "pseg_prepare_images", "pseg_affine_warp",
 )
 
 
@@ -72,6 +72,7 @@ def lib():
     L.pseg_train_set_optimizer.argtypes = [vp, i]
     L.pseg_train_set_loss.argtypes = [vp, i]
     L.pseg_train_forward_backward.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
+    L.pseg_train_forward_backward_f32.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
     L.pseg_train_grad_buffer.argtypes = [vp, c.POINTER(vp), c.POINTER(i64)]
     L.pseg_train_metrics.argtypes = [vp, c.POINTER(f)]
     L.pseg_train_apply.argtypes = [vp, f, f]
@@ -84,6 +85,7 @@ def lib():
     L.pseg_resize_nearest.argtypes = [i, vp, i, i, i, vp, i, i]
     L.pseg_scale_image.argtypes = [i, vp, i, i, i, vp, i, i, vp, i, vp, i]
     L.pseg_prepare_images.argtypes = [i, vp, vp, i, i, i, i, vp, i, vp, i, i, i, vp, i, vp, i, vp, vp, vp, vp]
+    L.pseg_affine_warp.argtypes = [i, vp, i, i, vp, vp, i, vp]
     L.pseg_cc_vote_device.argtypes = [i, vp, vp, i, i, i, vp]
     L.pseg_bbox_fill.argtypes = [i, vp, vp, i, i, i]
     L.pseg_masks.argtypes = [i, vp, vp, vp, i, i, i, vp, vp, vp, vp]
@@ -258,6 +260,16 @@ class Engine:
         _check(lib().pseg_train_forward_backward(self._h, _ptr(img), _ptr(msk), img.shape[0], img.shape[1], m))
         return tuple(float(v) for v in m)
 
+    def train_forward_backward_float(self, image, mask):
+        """As train_forward_backward with a float32 page on the 0..255 scale (augmented sample)."""
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        if img.shape[:2] != m.shape[:2]:
+            raise PsegError("image %r and mask %r differ in shape" % (img.shape, m.shape))
+        out = (ctypes.c_float * 4)()
+        _check(lib().pseg_train_forward_backward_f32(self._h, _ptr(img), _ptr(m), img.shape[0], img.shape[1], out))
+        return tuple(float(v) for v in out)
+
     def eval_step(self, image, mask):
         img, msk = self._img_mask(image, mask)
         m = (ctypes.c_float * 4)()
@@ -428,3 +440,16 @@ def prepare_images(image, binary, scale, max_width=None, device=0, want_stage1=F
                                      _kptr(k2[0]), k2[0][1], _kptr(k2[1]), k2[1][1],
                                      _ptr(o_img), _ptr(o_bin), _ptr(o_orig), _ptr(st1) if st1 is not None else None))
     return (o_img, o_bin, o_orig, st1) if want_stage1 else (o_img, o_bin, o_orig)
+
+
+def affine_warp(plane, matrix, offset, order, device=0):
+    """scipy.ndimage.affine_transform(plane, matrix, offset, order=order, mode='nearest') for a float32 (H,W)
+    plane, order 0 or 3, on the GPU (the augmentation warp of lib/data_generator.py)."""
+    a = np.ascontiguousarray(plane, dtype=np.float32)
+    if a.ndim != 2:
+        raise PsegError("affine_warp takes one (H,W) plane")
+    m = np.ascontiguousarray(matrix, dtype=np.float64).reshape(4)
+    o = np.ascontiguousarray(offset, dtype=np.float64).reshape(2)
+    out = np.empty_like(a)
+    _check(lib().pseg_affine_warp(int(device), _ptr(a), a.shape[0], a.shape[1], _ptr(m), _ptr(o), int(order), _ptr(out)))
+    return out

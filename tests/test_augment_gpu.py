@@ -1,0 +1,122 @@
+"""Augmentation (lib/data_generator.py, lib/network.py:109-125,149-161) on the GPU: the affine warp against the
+installed scipy.ndimage.affine_transform (float32 rounding apart), the parameter stream of the generator, and
+the augmented sample stream of Network.create_dataset_inputs."""
+import numpy as np
+import pytest
+
+from oracle import augment as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(h, w, theta, tx, ty, zx, zy, shear=0.0):
+    from ocr4all_pixel_classifier.lib.data_generator import ImageDataGeneratorCustom as G
+    return G.affine_matrix({'theta': theta, 'tx': tx, 'ty': ty, 'shear': shear, 'zx': zx, 'zy': zy}, h, w)
+
+
+@pytest.mark.parametrize("shape", [(64, 96), (33, 50), (257, 131), (7, 5)])
+@pytest.mark.parametrize("order", [0, 3])
+def test_affine_warp_matches_scipy(gpu, shape, order):
+    from pseg_amd import engine as E
+    rng = np.random.default_rng(shape[0] * 10 + order)
+    x = (rng.random(shape) * 255).astype(np.float32)
+    if order == 0:
+        x = np.round(x / 50)                               # label-like
+    for theta, tx, ty, zx, zy in [(2.5, 1.6, -2.4, 0.95, 1.05), (-1.3, 0.0, 0.0, 1.0, 1.0), (0.0, 3.0, 2.0, 1.0, 1.0),
+                                  (40.0, 5.0, -7.0, 0.7, 1.4)]:
+        m, off = _params(shape[0], shape[1], theta, tx, ty, zx, zy)
+        got = E.affine_warp(x, m, off, order)
+        want = A.affine_transform(x, m, off, order)
+        assert got.dtype == np.float32 and got.shape == want.shape
+        if order == 0:
+            assert (got != want).mean() <= 0.002            # exact .5 coordinate ties only
+        else:
+            assert np.abs(got - want).max() <= 2e-3 * 255    # B-spline overshoot scale; typically 1e-5
+
+
+def test_generator_parameter_stream_and_flow(gpu):
+    from ocr4all_pixel_classifier.lib.data_generator import ImageDataGeneratorCustom as G
+    from ocr4all_pixel_classifier.lib.trainer import AugmentationSettings
+    s = AugmentationSettings()
+    gi, gb = G(**s.to_image_params(), data_format='channels_last'), G(**s.to_binary_params(), data_format='channels_last')
+    assert gi.interpolation_order == 3 and gb.interpolation_order == 0
+    # same seed -> same parameters for image, binary and mask generators (lib/network.py:149-153)
+    np.random.seed(7)
+    np.random.permutation(1)
+    p1 = gi.get_random_transform((64, 96, 1))
+    np.random.seed(7)
+    np.random.permutation(1)
+    p2 = gb.get_random_transform((64, 96, 1))
+    assert p1 == p2 and abs(p1['theta']) <= 2.5 and abs(p1['tx']) <= 0.025 * 64 and 0.95 <= p1['zx'] <= 1.05
+    # the draw order of keras-preprocessing: theta, tx, ty, (shear), zoom pair, two flip draws
+    np.random.seed(7)
+    exp_theta = np.random.uniform(-2.5, 2.5)
+    exp_tx = np.random.uniform(-0.025, 0.025) * 64
+    exp_ty = np.random.uniform(-0.025, 0.025) * 96
+    exp_z = np.random.uniform(0.95, 1.05, 2)
+    assert (p1['theta'], p1['tx'], p1['ty'], p1['zx'], p1['zy']) == (exp_theta, exp_tx, exp_ty, exp_z[0], exp_z[1])
+    rng = np.random.default_rng(1)
+    img = (rng.random((1, 64, 96, 1)) * 255).astype(np.uint8)
+    a = next(gi.flow(img, seed=11, batch_size=1))
+    b = next(gi.flow(img, seed=11, batch_size=1))
+    c = next(gi.flow(img, seed=12, batch_size=1))
+    assert a.shape == (1, 64, 96, 1) and a.dtype == np.float32 and np.array_equal(a, b) and not np.array_equal(a, c)
+    m, off = G.affine_matrix(gi.get_random_transform((64, 96, 1), seed=11), 64, 96)
+    assert np.abs(a[0, ..., 0] - A.affine_transform(img[0, ..., 0].astype(np.float32), m, off, 3)).max() < 0.5
+    with pytest.raises(Exception):
+        G(fill_mode='reflect')
+
+
+def test_create_dataset_inputs_with_augmentation(gpu):
+    from pseg_amd import synth
+    from ocr4all_pixel_classifier.lib.network import Network
+    from ocr4all_pixel_classifier.lib.dataset import Dataset, SingleData
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    from ocr4all_pixel_classifier.lib.trainer import AugmentationSettings
+    img, binary, mask = synth.synth_page(3, 96, 128, 3)
+    ds = Dataset([SingleData(image=img, binary=binary, mask=mask, original_shape=img.shape)], ColorMap({}))
+    net = Network("train", n_classes=3, exact=True)
+    gen = net.create_dataset_inputs(ds, data_augmentation=True, data_augmentation_settings=AugmentationSettings())
+    (x1, y1), (x2, y2) = next(gen), next(gen)
+    assert x1['input_1'].shape == (1, 96, 128, 1) and x1['input_2'].shape == (1, 96, 128, 1) and y1['logits'].shape == (1, 96, 128, 1)
+    assert x1['input_1'].max() <= 1.3 and x1['input_1'].min() >= -0.3             # / 255, cubic-spline overshoot kept (scipy too)
+    assert set(np.unique(y1['logits'])) <= {0.0, 1.0, 2.0}                          # order-0 warp keeps label values
+    assert not np.array_equal(x1['input_1'], x2['input_1'])                         # seed += 1 per sample
+    # mask and image moved together: the label map still agrees with the un-augmented one on most pixels
+    assert (y1['logits'][0, ..., 0] == mask).mean() > 0.9
+
+
+def test_float_page_training_entry_and_augmented_training(gpu, oracle_mod, tmp_path):
+    """pseg_train_forward_backward_f32 on an un-augmented page equals the uint8 entry (x / 255.0f either way; atomics order apart), and Network.train_dataset with data_augmentation=True learns."""
+    from pseg_amd import synth
+    from ocr4all_pixel_classifier.lib.trainer import Trainer, TrainSettings
+    from ocr4all_pixel_classifier.lib.dataset import Dataset, SingleData
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    from ocr4all_pixel_classifier.lib.metrics import Monitor
+    img, binary, mask = synth.synth_page(2, 96, 112, 3)
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=3, gain=1.0, bias_scale=0.02)
+    e = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_F32_EXACT)
+    e.set_weights(Wt)
+    e.train_init()
+    a = e.train_forward_backward(img, mask)
+    ga = {k: v.copy() for k, v in e.gradients().items()}
+    b = e.train_forward_backward_float(img.astype(np.float32), mask)
+    gb = e.gradients()
+    assert np.allclose(a, b, rtol=1e-6, atol=0)                       # same forward; reductions use float atomics
+    assert all(np.allclose(ga[k], gb[k], rtol=1e-4, atol=1e-6 * np.abs(ga[k]).max()) for k in ga)
+    e.close()
+    np.random.seed(0)
+    cm = ColorMap({})
+
+    def ds(seeds):
+        out = []
+        for s in seeds:
+            i, bi, m = synth.synth_page(s, 96, 96, 3)
+            out.append(SingleData(image=i, binary=bi, mask=m, original_shape=i.shape))
+        return Dataset(out, cm)
+    settings = TrainSettings(n_epoch=6, n_classes=3, l_rate=2e-3, train_data=ds([0, 1, 2, 3]), validation_data=ds([4]),
+                             display=1, output_dir=str(tmp_path), threads=1, monitor=Monitor.VAL_LOSS,
+                             data_augmentation=True)
+    hist = Trainer(settings).train()
+    assert len(hist["loss"]) == 6 and np.isfinite(hist["loss"]).all()
+    assert np.mean(hist["loss"][-2:]) < hist["loss"][0]

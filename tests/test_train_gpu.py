@@ -136,8 +136,6 @@ def test_trainer_api_end_to_end(gpu, oracle_mod, tmp_path):
     net = Network("Predict", n_classes=3, model=str(tmp_path / "model"), exact=True)
     lab = net.predict_single_data(settings.validation_data.data[0])[2]
     assert lab.shape == (96, 96)
-    with pytest.raises(Exception):                                   # augmentation is not built
-        next(tr.train_net.create_dataset_inputs(settings.train_data, data_augmentation=True))
     x, y = next(tr.train_net.create_dataset_inputs(settings.train_data, data_augmentation=False))
     assert x["input_1"].shape == (1, 96, 96, 1) and x["input_2"].shape == (1, 96, 96, 1) and y["logits"].shape == (1, 96, 96, 1)
     assert x["input_1"].dtype == np.float64 and x["input_1"].max() <= 1.0

@@ -220,6 +220,31 @@ int pseg_scale_image(int device, const void* src, int src_is_f64, int H, int W, 
 int pseg_affine_warp(int device, const float* src, int H, int W, const double m[4], const double off[2],
                      int order, float* dst);
 
+/* ---- evaluation reductions ------------------------------------------------------------ */
+
+/* Joint histogram behind fgpa / fgoverlap_per_class (lib/image_ops.py:8-55) and count_matches /
+ * total_accuracy (lib/evaluation.py:8-32): counts[b][m][p] = pixels with (binary != 0) == b, mask label m,
+ * predicted label p; (n_classes + 1) slots per axis, the last one collects labels outside [0, n_classes).
+ * pred / mask: n labels of pred_bytes / mask_bytes (1, 4 or 8; signed for 4 and 8) each; binary may be NULL
+ * (every pixel counts as ink).  counts: 2 * (n_classes+1)^2 int64.  Host pointers. */
+int pseg_eval_confusion(int device, const void* pred, int pred_bytes, const void* mask, int mask_bytes,
+                        const uint8_t* binary, int64_t n, int n_classes, int64_t* counts);
+
+/* cv2.connectedComponentsWithStats(binary, connectivity)'s label image (lib/evaluation.py:84-85): 0 = paper,
+ * components numbered 1.. in the order OpenCV's scan meets them (connectivity 4: raster order of the first
+ * pixel; 8: raster order of the first 2x2 block).  labels: int32 (H,W); *num_labels counts the background. */
+int pseg_cc_label(int device, const uint8_t* binary, int H, int W, int connectivity, int32_t* labels,
+                  int32_t* num_labels);
+
+/* Per-component tables for ConnectedComponentEval (lib/evaluation.py:73-117); every output may be NULL.
+ * stats: int32 [num_labels][5] = cv2's LEFT, TOP, WIDTH, HEIGHT, AREA; centroids: double [num_labels][2]
+ * (x, y); eq[l] = pixels of l with pred == mask; hist_pred / hist_mask: [num_labels][n_classes+1] class
+ * counts (last slot: out of range); order: the H*W pixel indices sorted by (label, raster position), so
+ * that `bbox(image)[component]` (lib/evaluation.py:104-106) is image.ravel()[order[o:o+area]]. */
+int pseg_cc_tables(int device, const int32_t* labels, int H, int W, int num_labels, const void* pred,
+                   int pred_bytes, const void* mask, int mask_bytes, int n_classes, int32_t* stats,
+                   double* centroids, int64_t* eq, int64_t* hist_pred, int64_t* hist_mask, int32_t* order);
+
 /* prepare_images (lib/dataset.py:131-150), all pixel work on the device in one call.
  * image, binary: uint8 (H0,W0) scan and binarisation (paper = 1 or 255).  (H1,W1) =
  * pseg_rescale_shape(H0, W0, target_line_height / line_height_px); (H2,W2) = the max_width stage

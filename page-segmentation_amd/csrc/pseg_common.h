@@ -156,6 +156,7 @@ struct ConvArgs {
 };
 int launch_conv_exact(const ConvArgs& a, hipStream_t st);
 int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st);   // 1 launched, 0 does not fit, < 0 error
+int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hipStream_t st);   // pseg_post.hip
 int upload_weights(Engine& e);
 int set_canvas(Engine& e, int H, int W, hipStream_t st);
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs, int64_t* d_labels,

@@ -18,13 +18,14 @@ namespace pseg {
 //         (cv2.connectedComponentsWithStats(binary, connectivity=4), lib/postprocess.py:10).
 // MODE 1: every pixel is foreground, neighbours connect when their class is equal
 //         (the per-class labelling of lib/postprocess.py:33 done for all classes at once).
+// MODE 2: as MODE 0 with the two upper diagonals as neighbours too (connectivity=8, lib/evaluation.py:73,84-85).
 template <int MODE>
 __device__ __forceinline__ bool is_fg(const uint8_t* bin, const int64_t* cls, int p) {
-    return MODE == 0 ? bin[p] != 0 : true;
+    return MODE != 1 ? bin[p] != 0 : true;
 }
 template <int MODE>
 __device__ __forceinline__ bool connects(const uint8_t* bin, const int64_t* cls, int p, int q) {
-    return MODE == 0 ? (bin[q] != 0) : (cls[p] == cls[q]);
+    return MODE != 1 ? (bin[q] != 0) : (cls[p] == cls[q]);
 }
 
 __device__ __forceinline__ int uf_find(const int* L, int x) {
@@ -84,7 +85,13 @@ __global__ __launch_bounds__(256) void ccl_cols_kernel(const uint8_t* bin, const
     if (link && (threadIdx.x & 63) == 0) uf_union(L, p, p - 1);    // run continues from the previous wave
     if (y == 0) return;
     const int q = p - W;
-    if (!(is_fg<MODE>(bin, cls, q) && connects<MODE>(bin, cls, p, q))) return;
+    if (!(is_fg<MODE>(bin, cls, q) && connects<MODE>(bin, cls, p, q))) {
+        if (MODE == 2) {       // the pixel above is paper: the diagonals are separate runs (above ink, they share its run)
+            if (x > 0 && !link && bin[q - 1] != 0) uf_union(L, p, q - 1);   // with a left link, p-1 joins q-1 vertically
+            if (x + 1 < W && bin[q + 1] != 0) uf_union(L, p, q + 1);
+        }
+        return;
+    }
     if (link) {
         const bool link_up = is_fg<MODE>(bin, cls, q - 1) && connects<MODE>(bin, cls, q, q - 1);
         const bool up_left = is_fg<MODE>(bin, cls, q - 1) && connects<MODE>(bin, cls, p - 1, q - 1);
@@ -108,6 +115,11 @@ static int ccl_run(const uint8_t* d_bin, const int64_t* d_cls, int* d_L, int H, 
     ccl_compress_kernel<<<grid, 256, 0, st>>>(d_L, n);
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
+}
+
+// roots (minimum linear index of the component, -1 on paper) of the ink components of `d_bin`
+int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hipStream_t st) {
+    return connectivity == 8 ? ccl_run<2>(d_bin, nullptr, d_L, H, W, st) : ccl_run<0>(d_bin, nullptr, d_L, H, W, st);
 }
 
 // ---------------------------------------------------------------------------------------------

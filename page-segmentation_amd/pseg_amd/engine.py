@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = (
     "pseg_otsu_char_height",
     "pseg_rescale_shape", "pseg_gaussian_kernel", "pseg_resize_nearest", "pseg_scale_image",
     "pseg_prepare_images", "pseg_affine_warp",
+    "pseg_eval_confusion", "pseg_cc_label", "pseg_cc_tables",
 )
 
 
@@ -87,6 +88,9 @@ def lib():
     L.pseg_prepare_images.argtypes = [i, vp, vp, i, i, i, i, vp, i, vp, i, i, i, vp, i, vp, i, vp, vp, vp, vp]
     L.pseg_affine_warp.argtypes = [i, vp, i, i, vp, vp, i, vp]
     L.pseg_cc_vote_device.argtypes = [i, vp, vp, i, i, i, vp]
+    L.pseg_eval_confusion.argtypes = [i, vp, i, vp, i, vp, i64, i, vp]
+    L.pseg_cc_label.argtypes = [i, vp, i, i, i, vp, c.POINTER(c.c_int32)]
+    L.pseg_cc_tables.argtypes = [i, vp, i, i, i, vp, i, vp, i, i, vp, vp, vp, vp, vp, vp]
     L.pseg_bbox_fill.argtypes = [i, vp, vp, i, i, i]
     L.pseg_masks.argtypes = [i, vp, vp, vp, i, i, i, vp, vp, vp, vp]
     L.pseg_masks_device.argtypes = [i, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp]
@@ -452,4 +456,71 @@ def affine_warp(plane, matrix, offset, order, device=0):
     o = np.ascontiguousarray(offset, dtype=np.float64).reshape(2)
     out = np.empty_like(a)
     _check(lib().pseg_affine_warp(int(device), _ptr(a), a.shape[0], a.shape[1], _ptr(m), _ptr(o), int(order), _ptr(out)))
+    return out
+
+
+def _labels_arg(a):
+    """A label map as a contiguous array of 1-, 4- or 8-byte integers (no copy for uint8 / int32 / int64)."""
+    a = np.asarray(a)
+    if a.dtype == np.bool_:
+        a = a.view(np.uint8)
+    if a.dtype not in (np.uint8, np.int32, np.int64):
+        a = a.astype(np.int64)
+    return np.ascontiguousarray(a)
+
+
+def eval_confusion(pred, mask, binary, n_classes, device=0):
+    """counts[b][m][p] (2, n_classes+1, n_classes+1) int64: the joint histogram of (binary != 0, mask label,
+    predicted label) behind fgpa / fgoverlap_per_class / count_matches / total_accuracy."""
+    p, m = _labels_arg(pred), _labels_arg(mask)
+    if p.shape != m.shape:
+        raise PsegError("pred %r and mask %r differ in shape" % (p.shape, m.shape))
+    b = None
+    if binary is not None:
+        b = np.ascontiguousarray(np.asarray(binary) != 0).view(np.uint8)
+        if b.shape != p.shape:
+            raise PsegError("binary %r and pred %r differ in shape" % (b.shape, p.shape))
+    k = int(n_classes) + 1
+    out = np.zeros((2, k, k), np.int64)
+    _check(lib().pseg_eval_confusion(int(device), _ptr(p), p.dtype.itemsize, _ptr(m), m.dtype.itemsize,
+                                     _ptr(b) if b is not None else None, ctypes.c_int64(p.size), int(n_classes), _ptr(out)))
+    return out
+
+
+def cc_label(binary, connectivity=4, device=0):
+    """(num_labels, labels int32) as cv2.connectedComponents(binary, connectivity=...)."""
+    b = np.ascontiguousarray(binary, dtype=np.uint8)
+    if b.ndim != 2:
+        raise PsegError("binary must be 2-dimensional")
+    labels = np.zeros(b.shape, np.int32)
+    n = ctypes.c_int32()
+    _check(lib().pseg_cc_label(int(device), _ptr(b), b.shape[0], b.shape[1], int(connectivity), _ptr(labels), ctypes.byref(n)))
+    return int(n.value), labels
+
+
+def cc_tables(labels, num_labels, pred=None, mask=None, n_classes=0, want_stats=True, want_order=False, device=0):
+    """dict with stats (N,5) int32 / centroids (N,2) float64 (cv2's), and with pred+mask: eq (N,), hist_pred,
+    hist_mask (N, n_classes+1) int64; order (H*W,) int32 when asked."""
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    n = int(num_labels)
+    out = {}
+    stats = cent = eq = hp = hm = order = None
+    if want_stats:
+        stats, cent = np.zeros((n, 5), np.int32), np.zeros((n, 2), np.float64)
+        out.update(stats=stats, centroids=cent)
+    p = m = None
+    if pred is not None and mask is not None:
+        p, m = _labels_arg(pred), _labels_arg(mask)
+        if p.shape != lab.shape or m.shape != lab.shape:
+            raise PsegError("labels, pred and mask differ in shape")
+        k = int(n_classes) + 1
+        eq, hp, hm = np.zeros(n, np.int64), np.zeros((n, k), np.int64), np.zeros((n, k), np.int64)
+        out.update(eq=eq, hist_pred=hp, hist_mask=hm)
+    if want_order:
+        order = np.zeros(lab.size, np.int32)
+        out["order"] = order
+    opt = lambda a: _ptr(a) if a is not None else None
+    _check(lib().pseg_cc_tables(int(device), _ptr(lab), lab.shape[0], lab.shape[1], n, opt(p), p.dtype.itemsize if p is not None else 0,
+                                opt(m), m.dtype.itemsize if m is not None else 0, int(n_classes), opt(stats), opt(cent), opt(eq),
+                                opt(hp), opt(hm), opt(order)))
     return out

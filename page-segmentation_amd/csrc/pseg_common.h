@@ -156,6 +156,11 @@ struct ConvArgs {
 };
 int launch_conv_exact(const ConvArgs& a, hipStream_t st);
 int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st);   // 1 launched, 0 does not fit, < 0 error
+// split form of UpSampling2D(2) -> Conv2D(k2) (pseg_upsplit.hip)
+struct UpSplit;
+int upsplit_create(UpSplit** out, const std::vector<float>& w, const std::vector<float>& bias, int Cin, int Cs0, int Cout, int CoS);
+void upsplit_free(UpSplit* u);
+int upsplit_launch(UpSplit* u, const uint16_t* src, int Hs, int Ws, uint16_t* dst, int relu, hipStream_t st);
 int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hipStream_t st);   // pseg_post.hip
 int upload_weights(Engine& e);
 int set_canvas(Engine& e, int H, int W, hipStream_t st);

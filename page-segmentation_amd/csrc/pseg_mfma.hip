@@ -1231,6 +1231,90 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const uint8_t* img, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// first layer, Cin = 1, wide output (unet 1 -> 64, res_unet 1 -> 32): the layer is a 128 (64) byte/px
+// WRITE stream with 9 MACs per output, so the kernel is organised around full-line stores.  A wave
+// owns 64 consecutive pixels of a row and walks down RB rows; lane = (pixel group pg, 8-channel
+// chunk c): it computes PPL pixels x 8 couts and stores one 16-byte chunk per pixel, so the lanes of a
+// pixel group write whole 128-byte lines.  The lane's KS*KS*8 weights stay in registers for the walk,
+// the KS-row input window slides down one row per step (bytes -> bf16(x/255) on load).  Packed
+// fp32 FMAs (two couts per instruction) in tap order over bf16-rounded operands: the same chain, hence
+// the same bits, as conv1_bf16_kernel and the bf16-mode oracle.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int KS, int COUT, int RB>
+__global__ __launch_bounds__(256) void conv1_rows_kernel(const uint8_t* __restrict__ img, int H, int W, int Hp, int Wp,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         uint16_t* __restrict__ dst, int relu) {
+    static_assert(COUT % 8 == 0 && (64 % (COUT / 8)) == 0, "couts in 8-channel chunks, a power of two of them");
+    constexpr int NCH = COUT / 8, PGS = 64 / NCH, PPL = 64 / PGS, P = KS / 2, NX = PPL + KS - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane % NCH, pg = lane / NCH;
+    const int x0 = blockIdx.x * 64 + pg * PPL;                 // first pixel of this lane
+    const int y0 = (blockIdx.y * 4 + wave) * RB;               // first row of this wave
+    if (y0 >= Hp) return;
+    f32x2 wv[KS * KS][4];
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wv[t][q] = *(const f32x2*)(w + t * COUT + 8 * c + 2 * q);
+    f32x2 bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = *(const f32x2*)(bias + 8 * c + 2 * q);
+    bool colok[NX];
+    unsigned coff[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int x = x0 + j - P;
+        colok[j] = x >= 0 && x < W;
+        coff[j] = colok[j] ? (unsigned)x : 0u;
+    }
+    auto load_row = [&](int y, float* r) {
+        const bool rowok = y >= 0 && y < H;                    // wave-uniform
+        const uint8_t* rp = img + (size_t)(rowok ? y : 0) * (size_t)W;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const float v = (float)rp[coff[j]] * 0.00392156886f;
+            r[j] = (rowok && colok[j]) ? __uint_as_float((uint32_t)d_f2bf(v) << 16) : 0.0f;
+        }
+    };
+    float win[KS][NX];
+#pragma unroll
+    for (int k = 0; k < KS - 1; ++k) load_row(y0 - P + k, win[k + 1]);      // rows y0-P .. y0+P-1 sit in slots 1..KS-1
+    for (int r = 0; r < RB; ++r) {
+        const int y = y0 + r;
+        if (y >= Hp) break;
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) win[k][j] = win[k + 1][j];
+        load_row(y + P, win[KS - 1]);
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const float xv = win[ky][i + kx];
+                    const f32x2 xx = f32x2{xv, xv};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_elementwise_fma(xx, wv[ky * KS + kx][q], acc[q]);
+                }
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a0 = acc[q][0] + bv[q][0], a1 = acc[q][1] + bv[q][1];
+                if (relu) { a0 = vmax(a0, 0.f); a1 = vmax(a1, 0.f); }
+                o[q] = pk_bf16(a0, a1);
+            }
+            const int x = x0 + i;
+            if (x < Wp) *(uint4*)(dst + ((size_t)y * Wp + x) * COUT + 8 * c) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // generic input staging for graphs whose first conv runs on the MFMA kernel: uint8 -> bf16(x/255)
 __global__ void preprocess_bf16_kernel(const uint8_t* img, int H, int W, int C, const float* lut,
                                        uint16_t* dst, int Hp, int Wp, int Cs) {
@@ -1318,7 +1402,7 @@ __global__ __launch_bounds__(256) void logits_bf16_kernel(const uint16_t* src0, 
 // =============================================================================================
 // host side: plans, packing, launches
 // =============================================================================================
-enum PlanKind { PLAN_GENERIC = 0, PLAN_CONV1 = 1, PLAN_LOGITS = 2 };
+enum PlanKind { PLAN_GENERIC = 0, PLAN_CONV1 = 1, PLAN_LOGITS = 2, PLAN_UPSPLIT = 3 };
 
 struct MfmaPlan {
     int kind = PLAN_GENERIC;
@@ -1348,6 +1432,7 @@ struct MfmaPlan {
     bool nw8_ok = false;        // an 8-wave kernel instance exists for this layer shape
     bool nw8_resident = false;  // ... and its whole weight set stays resident beside the 16-row tile
     int cmax = 4;
+    UpSplit* upsplit = nullptr;   // PLAN_UPSPLIT: GEMM + gather-sum form of upsample -> k2 conv
 };
 
 void mfma_free_op(Op& op) {
@@ -1357,6 +1442,7 @@ void mfma_free_op(Op& op) {
     (void)hipFree(p->d_bias); (void)hipFree(p->d_wf); (void)hipFree(p->d_lut);
     (void)hipFree(p->d_tail_wa); (void)hipFree(p->d_tail_wb); (void)hipFree(p->d_tail_bias);
     (void)hipFree(p->d_tc_wA1); (void)hipFree(p->d_tc_wA2); (void)hipFree(p->d_tc_beta);
+    upsplit_free(p->upsplit);
     delete p;
     op.plan = nullptr;
 }
@@ -1583,6 +1669,17 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     }
     if (op.type == OP_POOL) return PSEG_OK;
 
+    // upsample -> k2 conv of the deep decoder levels: GEMM over the source pixels + gather-sum (pseg_upsplit.hip).
+    // Measured at 2048x1536 (unet): 1024->512 216 -> ~75 us, 512->256 228 -> ~110 us, 256->128 246 -> ~185 us; at
+    // 128->64 the two extra passes over the full-resolution tensor cost more than the direct kernel (PSEG_UPSPLIT_MIN_CIN).
+    if (op.type == OP_CONV && k == 2 && op.up0 && !s1 && op.stride == 1 && !op.in_relu && op.add < 0 && op.pool_dst < 0 &&
+        op.tail_logits < 0 && op.fuse1 < 0 && !op.transposed && !getenv("PSEG_NO_UPSPLIT") && !getenv("PSEG_GENERIC")) {
+        const int min_cin = getenv("PSEG_UPSPLIT_MIN_CIN") ? atoi(getenv("PSEG_UPSPLIT_MIN_CIN")) : 256;
+        if (Cin >= min_cin) {
+            P->kind = PLAN_UPSPLIT;
+            return upsplit_create(&P->upsplit, w, bias, Cin, Cs0, Cout, e.tensors[op.dst].Cs);
+        }
+    }
     // ---- generic MFMA conv / deconv2 ------------------------------------------------------------
     const bool deconv = op.type == OP_DECONV2;
     const int KS = deconv ? 1 : k;
@@ -2012,6 +2109,13 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     const Tensor& d = e.tensors[op.dst];
     if (P->kind == PLAN_CONV1) {
         const uint8_t* img = e.cur_img;  // raw uint8 page (x/255 and pad-to-32 are fused)
+        if ((P->KS == 3 && (op.Cout == 64 || op.Cout == 32)) && !getenv("PSEG_CONV1_MFMA") && !getenv("PSEG_CONV1_VALU")) {
+            constexpr int RB = 16;
+            dim3 g(cdiv(e.Wp, 64), cdiv(e.Hp, 4 * RB));
+            if (op.Cout == 64) conv1_rows_kernel<3, 64, RB><<<g, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
+            else conv1_rows_kernel<3, 32, RB><<<g, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
+            return PSEG_OK;
+        }
         if (!getenv("PSEG_CONV1_VALU")) {
             dim3 g1(e.Wp / 32, cdiv(e.Hp, 16));
             uint16_t* o = (uint16_t*)d.d;
@@ -2031,6 +2135,10 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         else
             conv1_bf16_kernel<1, 32><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
         return PSEG_OK;
+    }
+    if (P->kind == PLAN_UPSPLIT) {
+        const Tensor& s0 = e.tensors[op.src0];
+        return upsplit_launch(P->upsplit, (const uint16_t*)s0.d, e.tH(s0), e.tW(s0), (uint16_t*)d.d, op.relu, st);
     }
     if (P->nw8_ok) {
         // 16-row tiles when they still fill the chip (one workgroup per CU); re-pack on a change

@@ -123,6 +123,11 @@ enum { PSEG_OPT_ADAM = 0, PSEG_OPT_ADAMAX = 1, PSEG_OPT_ADADELTA = 2, PSEG_OPT_A
        PSEG_OPT_RMSPROP = 4, PSEG_OPT_SGD = 5, PSEG_OPT_NADAM = 6 };
 int pseg_train_set_optimizer(pseg_engine* e, int optimizer);
 
+/* Dropout (unet: lib/model.py:167,172, rate 0.5) is live in pseg_train_forward_backward* and the identity in
+ * pseg_eval_step / pseg_predict*.  The mask of training forward number n (counted from this call) is a counter-based
+ * function of (seed, n, layer, element): reproducible, different every step.  Default seed 0x1234. */
+int pseg_train_set_dropout_seed(pseg_engine* e, uint32_t seed);
+
 /* Loss functions (lib/metrics.py:8-9,72-133; `Loss` enum).  metrics[0] of the step calls is the selected
  * loss; the three other metrics stay accuracy / jacard_coef / dice_coef.  Default: cross-entropy. */
 enum { PSEG_LOSS_CE = 0, PSEG_LOSS_JACCARD = 1, PSEG_LOSS_DICE = 2, PSEG_LOSS_HINGE = 3, PSEG_LOSS_FOCAL = 4,

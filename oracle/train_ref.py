@@ -81,6 +81,95 @@ def fcn_loss_and_grads(arch, Wt, image_u8, mask_u8, loss_kind="categorical_cross
     return float(loss.item()), acc, jac, dice, grads
 
 
+def dropout_keep(n, key, rate):
+    """The engine's counter-based Dropout mask (pseg_engine.hip: dropout_kernel) restated: element i is kept iff the
+    top 24 bits of a 32-bit mix of (i, key) are >= rate * 2^24."""
+    with np.errstate(over="ignore"):
+        h = np.arange(n, dtype=np.uint32) * np.uint32(0x9E3779B1) + np.uint32(key & 0xFFFFFFFF)
+        h ^= h >> np.uint32(16); h *= np.uint32(0x85EBCA6B); h ^= h >> np.uint32(13); h *= np.uint32(0xC2B2AE35); h ^= h >> np.uint32(16)
+    return (h >> np.uint32(8)) >= np.uint32(int(np.float32(rate) * np.float32(16777216.0)))
+
+
+def dropout_key(seed, step, op_index):
+    """Key of the Dropout behind op `op_index` in training forward number `step` (0-based) after
+    pseg_train_set_dropout_seed(seed)."""
+    base = ((seed * 0x632BE5AB + step * 0x9E3779B9) & 0xFFFFFFFF) | 1
+    return (base + 0x85EBCA77 * op_index) & 0xFFFFFFFF
+
+
+def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None):
+    """unet (lib/model.py:151-203) and res_unet (:237-307) in torch with the reference's cross-entropy (lib/metrics.py:8-9);
+    `drop` = (seed, step) enables unet's two Dropout(0.5) layers with the engine's masks (op indices 10 and 13 of the
+    engine's op list; masks are laid out over the (H/8, W/8, 512) and (H/16, W/16, 1024) canvases).
+    -> (loss, grads dict in Keras layouts, logits (H,W,C))."""
+    import torch
+    import torch.nn.functional as F
+    T = OrderedDict((k, torch.tensor(v, dtype=torch.float32, requires_grad=True)) for k, v in Wt.items())
+    H, W = image_u8.shape
+    ph, pw = (32 - H % 32) % 32, (32 - W % 32) % 32
+    names = iter(["conv2d"] + ["conv2d_%d" % i for i in range(1, 64)])
+
+    def conv(x, n, k, relu=False, stride=1, pre_relu=False):
+        if pre_relu:
+            x = F.relu(x)
+        Hin, Win = x.shape[2], x.shape[3]
+        th = max((-(-Hin // stride) - 1) * stride + k - Hin, 0)
+        tw = max((-(-Win // stride) - 1) * stride + k - Win, 0)
+        x = F.pad(x, (tw // 2, tw - tw // 2, th // 2, th - th // 2))           # TF SAME
+        y = F.conv2d(x, T[n + "/kernel"].permute(3, 2, 0, 1), T[n + "/bias"], stride=stride)
+        return F.relu(y) if relu else y
+
+    def dropped(x, op_index):
+        if drop is None:
+            return x
+        _, c, h, w = x.shape
+        keep = dropout_keep(h * w * c, dropout_key(drop[0], drop[1], op_index), 0.5).reshape(h, w, c)
+        m = torch.from_numpy(np.ascontiguousarray(keep.transpose(2, 0, 1)[None]).astype(np.float32))
+        return x * m * 2.0
+
+    x = torch.from_numpy(image_u8.astype(np.float32) / np.float32(255.0))[None, None]
+    x = F.pad(x, (0, pw, 0, ph))
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    if arch == "unet":
+        f = [64, 128, 256, 512, 1024]
+        t, skips = x, []
+        for l in range(5):
+            t = conv(t, next(names), 3, True)
+            t = conv(t, next(names), 3, True)
+            if l == 3: t = dropped(t, 10)
+            if l == 4: t = dropped(t, 13)
+            if l < 4:
+                skips.append(t)
+                t = F.max_pool2d(t, 2)
+        for l in (3, 2, 1, 0):
+            u = conv(up(t), next(names), 2, True)
+            t = conv(torch.cat([skips[l], u], 1), next(names), 3, True)
+            t = conv(t, next(names), 3, True)
+    elif arch == "res_unet":
+        def residual(t, stride):
+            n1, n2, n3 = next(names), next(names), next(names)
+            r = conv(t, n1, 3, stride=stride, pre_relu=True)
+            r = conv(r, n2, 3, pre_relu=True)
+            return conv(t, n3, 3, stride=stride) + r
+        n1, n2, n3 = next(names), next(names), next(names)
+        e1 = conv(conv(x, n1, 3), n2, 3, pre_relu=True) + conv(x, n3, 1)
+        e2 = residual(e1, 2); e3 = residual(e2, 2); e4 = residual(e3, 2); e5 = residual(e4, 2)
+        b0 = conv(e5, next(names), 3, pre_relu=True)
+        b1 = conv(b0, next(names), 3, pre_relu=True)
+        t = b1
+        for sk in (e4, e3, e2, e1):
+            t = residual(torch.cat([up(t), sk], 1), 1)
+    else:
+        raise ValueError(arch)
+    t = t[:, :, :H, :W]
+    z = F.conv2d(t, T["logits/kernel"].permute(3, 2, 0, 1), T["logits/bias"])[0].permute(1, 2, 0)
+    y = torch.from_numpy(mask_u8.astype(np.int64))
+    loss = F.cross_entropy(z.reshape(-1, z.shape[-1]), y.reshape(-1))
+    loss.backward()
+    grads = OrderedDict((k, (t_.grad.numpy().copy() if t_.grad is not None else np.zeros_like(Wt[k]))) for k, t_ in T.items())
+    return float(loss.item()), grads, z.detach().numpy()
+
+
 class KerasAdam:
     """TF 2.5 Keras Adam with per-tensor clip_by_norm applied first."""
 

@@ -76,6 +76,7 @@ struct Op {
     int fuse1 = -1;           // bf16 mode: OP_CONV that recomputes this first-layer op on its halo tile
     int tail_logits = -1;     // bf16 mode: OP_DECONV2 that also runs this OP_LOGITS (fused tail)
     int nw_hint = 4;          // bf16 mode: waves per workgroup the plan should be packed for (4 or 8)
+    float dropout = 0.0f;     // Dropout(rate) on this op's output: identity at inference, applied by the train step
     double flops_per_canvas_px = 0;  // algorithmic, true channels
     int timing_slot = -1;
 };
@@ -127,6 +128,7 @@ struct Engine {
     size_t lab_stage_bytes = 0, prob_stage_bytes = 0, logit_stage_bytes = 0;
     void* train = nullptr;   // TrainState (pseg_train.hip), f32 mode only
     void* batch = nullptr;   // BatchState (pseg_predict_batch): copy streams, events, two staging slots
+    uint32_t drop_key = 0;   // != 0 while a TRAINING forward runs: Dropout layers are live (key = seed / step mix)
     const float* cur_img_f32 = nullptr;   // float32 exact mode: float page (0..255 scale) instead of the uint8 one (augmented training samples)
     // timing
     bool timing = false;
@@ -161,6 +163,8 @@ struct UpSplit;
 int upsplit_create(UpSplit** out, const std::vector<float>& w, const std::vector<float>& bias, int Cin, int Cs0, int Cout, int CoS);
 void upsplit_free(UpSplit* u);
 int upsplit_launch(UpSplit* u, const uint16_t* src, int Hs, int Ws, uint16_t* dst, int relu, hipStream_t st);
+// Dropout mask of element i under `key`: keep iff hash(i, key) >= rate (inverted dropout, kept values * 1/(1-rate))
+void launch_dropout(float* x, size_t n, uint32_t key, float rate, hipStream_t st);
 int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hipStream_t st);   // pseg_post.hip
 int upload_weights(Engine& e);
 int set_canvas(Engine& e, int H, int W, hipStream_t st);

@@ -362,6 +362,21 @@ int set_canvas(Engine& e, int H, int W, hipStream_t st) {
     return PSEG_OK;
 }
 
+// inverted dropout with a counter-based mask: element i is kept iff the top 24 bits of a 32-bit mix of (i, key)
+// are >= rate * 2^24; the same call on a gradient tensor applies the same mask and scale (tests/test_train_arch_gpu.py
+// restates the mix in NumPy)
+__global__ void dropout_kernel(float* x, size_t n, uint32_t key, uint32_t thresh, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 0x9E3779B1u + key;
+        h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+        x[i] = (h >> 8) >= thresh ? x[i] * scale : 0.0f;
+    }
+}
+void launch_dropout(float* x, size_t n, uint32_t key, float rate, hipStream_t st) {
+    const uint32_t thresh = (uint32_t)(rate * 16777216.0f);
+    dropout_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(x, n, key, thresh, 1.0f / (1.0f - rate));
+}
+
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
                      int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st) {
     Tensor& in = e.tensors[e.input_tensor];
@@ -480,6 +495,10 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
             const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
             pool_exact_kernel<<<grid, 256, 0, st>>>((const float*)s0.d, e.tH(s0), e.tW(s0), s0.C,
                                                     (float*)e.tensors[op.dst].d);
+        }
+        if (e.drop_key && op.dropout > 0.0f) {   // training forward: Dropout on this op's output, in place
+            const Tensor& d = e.tensors[op.dst];
+            launch_dropout((float*)d.d, (size_t)e.tH(d) * e.tW(d) * d.C, e.drop_key + 0x85EBCA77u * (uint32_t)(&op - e.ops.data()), op.dropout, st);
         }
         PSEG_HIP(hipGetLastError());
         PSEG_TRY(time_end(e, op, st, ev0));

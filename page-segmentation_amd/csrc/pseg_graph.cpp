@@ -184,7 +184,7 @@ void build_fcn(Engine& e, bool skip) {
     b.logits(d5, skip ? c2 : -1);                      // concat [deconv5, conv2]  :85
 }
 
-// lib/model.py:151-203.  Dropout(0.5) is the identity at inference.
+// lib/model.py:151-203.  Dropout(0.5) is the identity at inference and live in the train step.
 void build_unet(Engine& e) {
     Builder b(e);
     int t = b.tensor("input", 0, e.in_ch);
@@ -194,6 +194,7 @@ void build_unet(Engine& e) {
     for (int l = 0; l < 5; ++l) {
         t = b.conv(t, -1, f[l], 3, true);
         t = b.conv(t, -1, f[l], 3, true);
+        if (l >= 3) e.ops.back().dropout = 0.5f;   // drop4 / drop5 (:167,172): every consumer sees the dropped tensor
         if (l < 4) {
             skips[l] = t;
             t = b.pool(t);

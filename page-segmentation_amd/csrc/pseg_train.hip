@@ -39,6 +39,11 @@ struct TrainState {
     std::vector<size_t> tbytes;
     float* d_wd = nullptr;       // scratch: transformed weights for dgrad
     size_t wd_bytes = 0;
+    float* d_tmp = nullptr;      // scratch: data gradient at the conv's input extent (upsampled / pre-activation sources)
+    float* d_tmp2 = nullptr;     // scratch: zero-dilated output gradient (stride-2 convs)
+    size_t tmp_bytes = 0, tmp2_bytes = 0;
+    uint32_t drop_seed = 0x1234u;
+    int64_t fwd_count = 0;       // training forwards so far: the Dropout mask changes every step
     float* d_logits = nullptr;
     float* d_dlogits = nullptr;
     uint8_t* d_mask = nullptr;
@@ -55,7 +60,7 @@ void train_free(Engine& e) {
     (void)hipFree(t->d_grad); (void)hipFree(t->d_m); (void)hipFree(t->d_v); (void)hipFree(t->d_norm);
     for (auto p : t->tgrad) (void)hipFree(p);
     (void)hipFree(t->d_wd); (void)hipFree(t->d_logits); (void)hipFree(t->d_dlogits);
-    (void)hipFree(t->d_mask); (void)hipFree(t->d_img);
+    (void)hipFree(t->d_mask); (void)hipFree(t->d_img); (void)hipFree(t->d_tmp); (void)hipFree(t->d_tmp2);
     delete t;
     e.train = nullptr;
 }
@@ -246,6 +251,10 @@ struct WgradArgs {
     int KW, pt, pl, mode, strip_rows;
     float* dW;
     float* dB;   // only written by blocks with tap 0 when non-null
+    // matrix-core kernel only: conv stride (X pixel = y * stride + ky - pt), X stored at half resolution and
+    // read through a nearest x2 upsample (Hx, Wx are then the upsampled extents, xpitch the stored row pitch),
+    // pre-activation ReLU on X (res_unet)
+    int stride = 1, xup = 0, in_relu = 0;
 };
 
 constexpr int WG_PC = 32;  // pixels per LDS chunk
@@ -357,7 +366,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
     const int ky = tap0 / a.KW, kx0 = tap0 % a.KW;
     const int itW = a.mode == 0 ? a.Wy : a.Wx, itH = a.mode == 0 ? a.Hy : a.Hx;
     const int r0 = blockIdx.y * a.strip_rows, r1 = min(r0 + a.strip_rows, itH);
-    const int tiles_ci = (a.XC + 15) >> 4, tiles_co = (a.Cout + 15) >> 4;
+    // channel blocks of TI x TJ tiles (blockIdx.z) for layers wider than one instance
+    const int nbo = (a.Cout + TJ * 16 - 1) / (TJ * 16);
+    const int xc0 = ((int)blockIdx.z / nbo) * TI * 16, yc0 = ((int)blockIdx.z % nbo) * TJ * 16;
+    const int XCb = min(a.XC - xc0, TI * 16), COb = min(a.Cout - yc0, TJ * 16);
+    const int tiles_ci = (XCb + 15) >> 4, tiles_co = (COb + 15) >> 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p16 = lane & 15, g = lane >> 4;
     wg_f32x4 acc[KXN][TI][TJ];
 #pragma unroll
@@ -369,26 +382,30 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
     float bacc[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) bacc[j] = 0.0f;
-    const bool want_b = a.dB != nullptr && tap0 == 0;
+    const bool want_b = a.dB != nullptr && tap0 == 0 && xc0 == 0;
 
     auto load = [&](int y, int xq, float (*xa)[TI], float* yb) {
         const int x = xq + g;
 #pragma unroll
         for (int k = 0; k < KXN; ++k) {
             int sy, sx;
-            if (a.mode == 0) { sy = y + ky - a.pt; sx = x + kx0 + k - a.pl; } else { sy = y; sx = x; }
+            if (a.mode == 0) { sy = y * a.stride + ky - a.pt; sx = x * a.stride + kx0 + k - a.pl; } else { sy = y; sx = x; }
             const bool okx = x < itW && sy >= 0 && sy < a.Hx && sx >= 0 && sx < a.Wx;
-            const float* xp = a.X + ((size_t)sy * a.xpitch + sx) * a.XC + p16;
+            const float* xp = a.X + ((size_t)(sy >> a.xup) * a.xpitch + (sx >> a.xup)) * a.XC + xc0 + p16;
 #pragma unroll
-            for (int i = 0; i < TI; ++i) xa[k][i] = (i < tiles_ci && okx && i * 16 + p16 < a.XC) ? xp[i * 16] : 0.0f;
+            for (int i = 0; i < TI; ++i) {
+                float v = (i < tiles_ci && okx && i * 16 + p16 < XCb) ? xp[i * 16] : 0.0f;
+                if (a.in_relu) v = v > 0.0f ? v : 0.0f;
+                xa[k][i] = v;
+            }
         }
         const int dy = a.mode == 0 ? y : 2 * y + (tap0 >> 1), dx = a.mode == 0 ? x : 2 * x + (tap0 & 1);
-        const size_t o = ((size_t)dy * a.ypitch + dx) * a.Cout + p16;
+        const size_t o = ((size_t)dy * a.ypitch + dx) * a.Cout + yc0 + p16;
         const bool oky = x < itW;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             float v = 0.0f;
-            if (j < tiles_co && oky && j * 16 + p16 < a.Cout) {
+            if (j < tiles_co && oky && j * 16 + p16 < COb) {
                 v = a.dY[o + j * 16];
                 if (a.maskY && !(a.maskY[o + j * 16] > 0.0f)) v = 0.0f;
             }
@@ -445,8 +462,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
                     {
                         const int e = threadIdx.x, row = e >> 4, col = e & 15;
                         const int ci = i * 16 + row, co = j * 16 + col;
-                        if (ci < a.XC && co < a.Cout)
-                            atomicAdd(&a.dW[((size_t)(tap0 + k) * a.Cin + a.ci0 + ci) * a.Cout + co], red[e]);
+                        if (ci < XCb && co < COb)
+                            atomicAdd(&a.dW[((size_t)(tap0 + k) * a.Cin + a.ci0 + xc0 + ci) * a.Cout + yc0 + co], red[e]);
                     }
                     __syncthreads();
                 }
@@ -456,7 +473,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
             float v = bacc[j];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (g == 0 && j < tiles_co && j * 16 + p16 < a.Cout) atomicAdd(&a.dB[j * 16 + p16], v);
+            if (g == 0 && j < tiles_co && j * 16 + p16 < COb) atomicAdd(&a.dB[yc0 + j * 16 + p16], v);
         }
     }
 }
@@ -478,12 +495,58 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
 #define PSEG_WG(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) { wgrad_mfma_kernel<TI_, TJ_, 1><<<g2, 256, 0, st>>>(a); PSEG_HIP(hipGetLastError()); return PSEG_OK; }
         PSEG_WG(1, 2) PSEG_WG(2, 2) PSEG_WG(2, 3) PSEG_WG(3, 3) PSEG_WG(3, 5) PSEG_WG(5, 3) PSEG_WG(5, 5)
 #undef PSEG_WG
+        return fail(PSEG_EUNSUPPORTED, "no weight-gradient instance for %d x %d channels", a.XC, a.Cout);
+    } else if (!getenv("PSEG_WGRAD_SCALAR")) {
+        // wide layers (unet / res_unet): 64 x 64 channel blocks on blockIdx.z
+        const dim3 g3(grid.y, grid.x, cdiv(a.XC, 64) * cdiv(a.Cout, 64));
+        wgrad_mfma_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
     } else {
         const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
+        if (a.stride != 1 || a.xup || a.in_relu || (XCp / 4) * (COp / 4) > 768)
+            return fail(PSEG_EUNSUPPORTED, "the scalar weight-gradient kernel does not cover this layer");
         wgrad_kernel<<<grid, 256, (size_t)WG_PC * (XCp + COp) * 4, st>>>(a);
     }
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
+}
+
+// dst[i] += src[i] (masked by maskX[i] > 0 when given): residual addend gradients, pre-activation ReLU dgrad
+__global__ void accum_kernel(float* dst, const float* src, const float* maskY, const float* maskX, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = src[i];
+        if (maskY && !(maskY[i] > 0.0f)) v = 0.0f;
+        if (maskX && !(maskX[i] > 0.0f)) v = 0.0f;
+        dst[i] += v;
+    }
+}
+// gradient of a nearest x2 upsample: dst[Y][X][c] += sum of the 2x2 block of src (2H x 2W x C), masked by maskX
+__global__ void upsample_bwd_kernel(float* dst, const float* src, const float* maskX, int H, int W, int C) {
+    const size_t n = (size_t)H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int x = (int)(p % W), y = (int)(p / W);
+        const float* q = src + ((size_t)(2 * y) * (2 * W) + 2 * x) * C + c;
+        float v = (q[0] + q[C]) + (q[(size_t)2 * W * C] + q[(size_t)2 * W * C + C]);
+        if (maskX && !(maskX[i] > 0.0f)) v = 0.0f;
+        dst[i] += v;
+    }
+}
+// zero-dilated copy of a (ReLU-masked) gradient for the data gradient of a stride-2 conv: dst (2H x 2W x C), dst(2y, 2x) = src(y, x)
+__global__ void dilate2_kernel(float* dst, const float* src, const float* maskY, int H, int W, int C) {
+    const size_t n = (size_t)4 * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int x = (int)(p % (2 * W)), y = (int)(p / (2 * W));
+        float v = 0.0f;
+        if (!(x & 1) && !(y & 1)) {
+            const size_t o = ((size_t)(y >> 1) * W + (x >> 1)) * C + c;
+            v = src[o];
+            if (maskY && !(maskY[o] > 0.0f)) v = 0.0f;
+        }
+        dst[i] = v;
+    }
 }
 
 // dB[co] += sum over pixels of dY' (dY masked by Y > 0 for ReLU layers)
@@ -607,7 +670,6 @@ static int producer_of(const Engine& e, int tensor) {
 
 static int train_init(Engine& e, float b1, float b2, float eps, float clipnorm, float clipvalue) {
     if (e.mode != PSEG_MODE_F32_EXACT) return fail(PSEG_EUNSUPPORTED, "training runs on the float32 engine (mode F32_EXACT)");
-    if (e.arch != PSEG_ARCH_FCN_SKIP && e.arch != PSEG_ARCH_FCN) return fail(PSEG_EUNSUPPORTED, "training is built for fcn / fcn_skip only so far");
     if (e.n_classes > 16) return fail(PSEG_EUNSUPPORTED, "training supports at most 16 classes");
     train_free(e);
     auto* t = new TrainState();
@@ -658,7 +720,12 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     else PSEG_HIP(hipMemcpyAsync(t->d_img, img, npx * e.in_ch, hipMemcpyHostToDevice, st));
     PSEG_HIP(hipMemcpyAsync(t->d_mask, mask, npx, hipMemcpyHostToDevice, st));
     e.cur_img_f32 = img_f32 ? (const float*)t->d_img : nullptr;
+    // Dropout layers are live in a training forward (Keras fit), the identity in an evaluation step
+    const uint32_t drop_key = backward ? (t->drop_seed * 0x632BE5ABu + (uint32_t)t->fwd_count * 0x9E3779B9u) | 1u : 0u;
+    if (backward) ++t->fwd_count;
+    e.drop_key = drop_key;
     const int rc_fwd = run_exact(e, t->d_img, t->d_logits, nullptr, nullptr, nullptr, st);
+    e.drop_key = 0;
     e.cur_img_f32 = nullptr;
     PSEG_TRY(rc_fwd);
     float* acc = t->d_grad + t->nparam;
@@ -697,46 +764,88 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
         const int C0 = s0.C, C1 = s1 ? s1->C : 0;
         float* gw = op.kparam >= 0 ? t->d_grad + t->off[op.kparam] : nullptr;
         float* gb = op.bparam >= 0 ? t->d_grad + t->off[op.bparam] : nullptr;
+        if (op.dropout > 0.0f && drop_key) {   // same mask and scale as the forward, on the gradient of the dropped tensor
+            const Tensor& d = e.tensors[op.dst];
+            launch_dropout(t->tgrad[op.dst], (size_t)e.tH(d) * e.tW(d) * d.C, drop_key + 0x85EBCA77u * (uint32_t)oi, op.dropout, st);
+        }
         if (op.type == OP_LOGITS || op.type == OP_CONV) {
-            if (op.stride != 1 || op.up0 || op.up1 || op.in_relu || op.add >= 0)
-                return fail(PSEG_EUNSUPPORTED, "backward of layer %s is not built", op.layer.c_str());
+            if (op.stride != 1 && op.stride != 2) return fail(PSEG_EUNSUPPORTED, "backward of layer %s (stride %d) is not built", op.layer.c_str(), op.stride);
             const bool lg = op.type == OP_LOGITS;
             const float* dY = lg ? t->d_dlogits : t->tgrad[op.dst];
             const float* Y = lg ? nullptr : (const float*)e.tensors[op.dst].d;
+            const float* maskY = (op.relu && Y) ? Y : nullptr;
             const int Hy = lg ? H : e.tH(e.tensors[op.dst]), Wy = lg ? W : e.tW(e.tensors[op.dst]);
-            const int Hx = e.tH(s0), Wx = e.tW(s0);
-            const int k = op.k, pt = lg ? 0 : (k - 1) / 2, pl = pt;   // stride-1 SAME, odd kernels (flip-symmetric)
+            // extent of the conv's input: both concat sources share it (a half-resolution source is read through up0 / up1)
+            const int Hx = e.tH(s0) << op.up0, Wx = e.tW(s0) << op.up0;
+            const int k = op.k, st_ = op.stride;
+            int pt = 0, pl = 0;
+            if (!lg) {   // TF SAME: pad_total = max((out-1)*s + k - in, 0), before = total / 2 (as run_exact)
+                pt = std::max((Hy - 1) * st_ + k - Hx, 0) / 2;
+                pl = std::max((Wy - 1) * st_ + k - Wx, 0) / 2;
+            }
+            // residual addend (Add() after the bias): its gradient is the layer's output gradient
+            if (op.add >= 0) {
+                const Tensor& ad = e.tensors[op.add];
+                const size_t n = (size_t)e.tH(ad) * e.tW(ad) * ad.C;
+                accum_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(t->tgrad[op.add], dY, maskY, nullptr, n);
+            }
             // ---- wgrad + bias grad ----
             for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
                 const Tensor& sx = sidx == 0 ? s0 : *s1;
+                const int up = sidx == 0 ? op.up0 : op.up1;
                 WgradArgs a{};
-                a.X = (const float*)sx.d; a.XC = sx.C; a.ci0 = sidx == 0 ? 0 : C0; a.Hx = Hx; a.Wx = Wx; a.xpitch = Wx;
-                a.dY = dY; a.maskY = (op.relu && Y) ? Y : nullptr;
+                a.X = (const float*)sx.d; a.XC = sx.C; a.ci0 = sidx == 0 ? 0 : C0; a.Hx = Hx; a.Wx = Wx; a.xpitch = Wx >> up;
+                a.xup = up; a.stride = st_; a.in_relu = op.in_relu;
+                a.dY = dY; a.maskY = maskY;
                 a.Hy = Hy; a.Wy = Wy; a.ypitch = Wy; a.Cout = op.Cout; a.Cin = op.Cin;
                 a.KW = k; a.pt = pt; a.pl = pl; a.mode = 0;
                 a.strip_rows = std::max(1, cdiv(Hy * k * k, strips_target));
                 a.dW = gw; a.dB = sidx == 0 ? gb : nullptr;
-                const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
-                if ((XCp / 4) * (COp / 4) > 768) return fail(PSEG_EUNSUPPORTED, "wgrad tile count too large for %s", op.layer.c_str());
                 dim3 grid(cdiv(Hy, a.strip_rows), k * k);
                 PSEG_TRY(launch_wgrad(a, grid, st));
             }
             // ---- dgrad into the source gradients (skipped for the network input) ----
+            // = a stride-1 convolution of the (ReLU-masked, for stride 2 zero-dilated) output gradient with the flipped
+            // kernel at the conv's input extent.  Plain sources accumulate in place; an upsampled source gets the sum of
+            // its 2x2 blocks, a pre-activation source the X > 0 mask -- both through a scratch tensor.
+            const float* dYd = dY;
+            const float* maskd = maskY;
+            if (st_ == 2) {
+                const size_t bytes = (size_t)Hx * Wx * op.Cout * 4;
+                PSEG_TRY(ensure_buf((void**)&t->d_tmp2, &t->tmp2_bytes, bytes));
+                const size_t n = bytes / 4;
+                dilate2_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(t->d_tmp2, dY, maskY, Hy, Wy, op.Cout);
+                dYd = t->d_tmp2;
+                maskd = nullptr;
+            }
             for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
                 const int src = sidx == 0 ? op.src0 : op.src1;
                 if (src == e.input_tensor) continue;
+                const int up = sidx == 0 ? op.up0 : op.up1;
                 const int c0 = sidx == 0 ? 0 : C0, nc = sidx == 0 ? C0 : C1;
+                const bool direct = !up && !op.in_relu;
                 PSEG_TRY(ensure_wd((size_t)k * k * op.Cout * nc));
                 wd_conv_kernel<<<64, 256, 0, st>>>(op.d_w, k, k, op.Cin, op.Cout, c0, nc, t->d_wd);
+                if (!direct) PSEG_TRY(ensure_buf((void**)&t->d_tmp, &t->tmp_bytes, (size_t)Hx * Wx * nc * 4));
                 ConvArgs a{};
-                a.src0 = dY; a.C0 = op.Cout; a.Hin = Hy; a.Win = Wy;
+                a.src0 = dYd; a.C0 = op.Cout; a.Hin = st_ == 2 ? Hx : Hy; a.Win = st_ == 2 ? Wx : Wy;
                 a.w = t->d_wd; a.bias = nullptr; a.KH = a.KW = k; a.stride = 1;
                 a.pt = k - 1 - pt; a.pl = k - 1 - pl;
                 a.Hout = lg ? H : Hx; a.Wout = lg ? W : Wx; a.Cout = nc;
-                a.mask = (op.relu && Y) ? Y : nullptr;
-                a.dst = t->tgrad[src]; a.add = t->tgrad[src];
+                a.mask = maskd;
+                a.dst = direct ? t->tgrad[src] : t->d_tmp;
+                a.add = direct ? t->tgrad[src] : nullptr;
                 a.dst_pitch = Wx;
                 PSEG_TRY(launch_conv_exact(a, st));
+                if (!direct) {
+                    const Tensor& sx = e.tensors[src];
+                    const float* maskX = op.in_relu ? (const float*)sx.d : nullptr;
+                    const size_t n = (size_t)e.tH(sx) * e.tW(sx) * nc;
+                    const int g = (int)std::min<size_t>((n + 255) / 256, 8192);
+                    if (up) upsample_bwd_kernel<<<g, 256, 0, st>>>(t->tgrad[src], t->d_tmp, maskX, e.tH(sx), e.tW(sx), nc);
+                    else accum_kernel<<<g, 256, 0, st>>>(t->tgrad[src], t->d_tmp, nullptr, maskX, n);
+                }
+                PSEG_HIP(hipGetLastError());
             }
         } else if (op.type == OP_DECONV2) {
             const float* dY = t->tgrad[op.dst];
@@ -924,6 +1033,14 @@ int pseg_train_set_optimizer(pseg_engine* h, int optimizer) {
     t->step = 0;
     t->m_schedule = 1.0;
     t->state_init = false;
+    return PSEG_OK;
+}
+
+int pseg_train_set_dropout_seed(pseg_engine* h, uint32_t seed) {
+    if (!h || !h->e.train) return fail(PSEG_EINVAL, "pseg_train_init has not been called");
+    TrainState* t = (TrainState*)h->e.train;
+    t->drop_seed = seed;
+    t->fwd_count = 0;
     return PSEG_OK;
 }
 

@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = (
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
     "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_get_activation", "pseg_flops_per_pixel",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
-    "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_set_loss", "pseg_train_forward_backward", "pseg_train_forward_backward_f32", "pseg_train_grad_buffer", "pseg_train_metrics",
+    "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_set_loss", "pseg_train_set_dropout_seed", "pseg_train_forward_backward", "pseg_train_forward_backward_f32", "pseg_train_grad_buffer", "pseg_train_metrics",
     "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
     "pseg_cc_vote", "pseg_cc_vote_device", "pseg_bbox_fill", "pseg_masks", "pseg_masks_device",
     "pseg_otsu_char_height",
@@ -72,6 +72,7 @@ def lib():
     L.pseg_train_init.argtypes = [vp, f, f, f, f, f]
     L.pseg_train_set_optimizer.argtypes = [vp, i]
     L.pseg_train_set_loss.argtypes = [vp, i]
+    L.pseg_train_set_dropout_seed.argtypes = [vp, c.c_uint32]
     L.pseg_train_forward_backward.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
     L.pseg_train_forward_backward_f32.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
     L.pseg_train_grad_buffer.argtypes = [vp, c.POINTER(vp), c.POINTER(i64)]
@@ -263,6 +264,10 @@ class Engine:
         m = (ctypes.c_float * 4)()
         _check(lib().pseg_train_forward_backward(self._h, _ptr(img), _ptr(msk), img.shape[0], img.shape[1], m))
         return tuple(float(v) for v in m)
+
+    def train_set_dropout_seed(self, seed):
+        """Seed of the Dropout masks (unet); also restarts the step counter the masks depend on."""
+        _check(lib().pseg_train_set_dropout_seed(self._h, int(seed) & 0xFFFFFFFF))
 
     def train_forward_backward_float(self, image, mask):
         """As train_forward_backward with a float32 page on the 0..255 scale (augmented sample)."""

@@ -1,0 +1,69 @@
+"""Train step of unet and res_unet (float32 engine) against torch autograd (oracle/train_ref.py:graph_loss_and_grads):
+loss within 1e-4 relative (north_star), every gradient tensor within 2e-3 of its scale; unet's Dropout layers with
+the engine's counter-based masks restated in NumPy."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample(seed, H, W, C):
+    from pseg_amd import synth
+    img, _, mask = synth.synth_page(seed, max(H, 96), max(W, 96), C)
+    return np.ascontiguousarray(img[:H, :W]), np.ascontiguousarray(mask[:H, :W])
+
+
+def _compare(g, g_o):
+    assert list(g.keys()) == list(g_o.keys())
+    for k in g_o:
+        scale = np.abs(g_o[k]).max() + 1e-12
+        err = np.abs(g[k] - g_o[k]).max()
+        assert err <= 2e-3 * scale + 1e-9, "%s: max err %g vs scale %g" % (k, err, scale)
+
+
+@pytest.mark.parametrize("arch,C,shape", [("res_unet", 3, (64, 96)), ("res_unet", 4, (40, 50)), ("unet", 3, (32, 64))])
+def test_gradients_match_autograd(gpu, oracle_mod, arch, C, shape):
+    from oracle.train_ref import graph_loss_and_grads
+    Wt = oracle_mod.init_weights(arch, C, seed=11, gain=1.2, bias_scale=0.05)
+    img, mask = _sample(2, shape[0], shape[1], C)
+    eng = gpu.Engine(arch, C, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    eng.train_init(clipnorm=1.0)
+    if arch == "unet":
+        eng.train_set_dropout_seed(77)
+        for step in range(2):                                    # the mask changes with the step
+            loss_o, g_o, _ = graph_loss_and_grads(arch, Wt, img, mask, drop=(77, step))
+            loss = eng.train_forward_backward(img, mask)[0]
+            assert abs(loss - loss_o) <= 1e-4 * abs(loss_o), (step, loss, loss_o)
+            _compare(eng.gradients(), g_o)
+        # evaluation: Dropout is the identity
+        loss_e, _, _ = graph_loss_and_grads(arch, Wt, img, mask)
+        assert abs(eng.eval_step(img, mask)[0] - loss_e) <= 1e-4 * abs(loss_e)
+    else:
+        loss_o, g_o, _ = graph_loss_and_grads(arch, Wt, img, mask)
+        loss = eng.train_forward_backward(img, mask)[0]
+        assert abs(loss - loss_o) <= 1e-4 * abs(loss_o)
+        _compare(eng.gradients(), g_o)
+        assert eng.eval_step(img, mask)[0] == pytest.approx(loss, rel=1e-6)
+    eng.close()
+
+
+@pytest.mark.parametrize("arch", ["unet", "res_unet"])
+def test_training_reduces_the_loss(gpu, oracle_mod, arch):
+    Wt = oracle_mod.init_weights(arch, 3, seed=5, gain=1.0, bias_scale=0.02)
+    pages = [_sample(s, 64, 64, 3) for s in (0, 1)]
+    eng = gpu.Engine(arch, 3, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    eng.train_init(clipnorm=1.0)
+    first = np.mean([eng.eval_step(*p)[0] for p in pages])
+    for step in range(30):
+        eng.train_forward_backward(*pages[step % 2])
+        eng.train_apply(1e-3)
+    last = np.mean([eng.eval_step(*p)[0] for p in pages])
+    assert np.isfinite(last) and last < 0.8 * first
+    # the bf16 predict engine accepts the trained weights
+    eb = gpu.Engine(arch, 3, mode=gpu.MODE_BF16)
+    eb.set_weights(eng.get_weights())
+    assert eb.predict(pages[0][0], want_logits=False, want_probs=False)[2].shape == (64, 64)
+    eb.close()
+    eng.close()

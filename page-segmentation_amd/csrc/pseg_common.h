@@ -128,6 +128,7 @@ struct Engine {
     size_t lab_stage_bytes = 0, prob_stage_bytes = 0, logit_stage_bytes = 0;
     void* train = nullptr;   // TrainState (pseg_train.hip), f32 mode only
     void* batch = nullptr;   // BatchState (pseg_predict_batch): copy streams, events, two staging slots
+    int relaxed_f32 = 0;     // != 0 during a train / eval step: wide float32 layers may run channel-blocked on the matrix cores
     uint32_t drop_key = 0;   // != 0 while a TRAINING forward runs: Dropout layers are live (key = seed / step mix)
     const float* cur_img_f32 = nullptr;   // float32 exact mode: float page (0..255 scale) instead of the uint8 one (augmented training samples)
     // timing
@@ -155,6 +156,7 @@ struct ConvArgs {
     int dst_pitch;       // pixels per output row (0: Wout) -- crop / canvas-pitched outputs
     int out_sy, out_sx, out_oy, out_ox;   // MFMA kernel only: output pixel (y*sy + oy, x*sx + ox); 0 strides = 1
     int deconv4;         // MFMA kernel only: Conv2DTranspose k2 s2 as one GEMM, n = ab*Cout + co -> (2y + a, 2x + b)
+    int relaxed;         // MFMA kernel only: the caller accepts a channel-blocked summation order (train step) for layers whose all-channel tile does not fit LDS
 };
 int launch_conv_exact(const ConvArgs& a, hipStream_t st);
 int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st);   // 1 launched, 0 does not fit, < 0 error

@@ -411,6 +411,7 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
             a.in_relu = op.in_relu;
             a.relu = op.relu;
             a.Cout = op.Cout;
+            a.relaxed = e.relaxed_f32;
             if (op.type == OP_LOGITS) {
                 // crop (lib/model.py:29-42) folded into the output extent
                 a.Hout = e.H;
@@ -470,6 +471,7 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
                 c.dst = (float*)e.tensors[op.dst].d;
                 c.dst_pitch = 2 * c.Win;
                 c.deconv4 = 1;
+                c.relaxed = e.relaxed_f32;
                 const int rc = launch_conv_exact_mfma(c, st);
                 if (rc < 0) return rc;
                 done = rc == 1;

@@ -38,7 +38,7 @@ constexpr int XTW = 32;   // output tile width (two 16-pixel MFMA column tiles)
 //               taps into one MFMA instead of wasting three quarters of it).
 // Both orders are the oracle's chain order; the padded / trailing k feed w = 0 against a finite x.
 template <int MT, int NT, bool FLAT>
-__global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp, int THH, int TWH) {
+__global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp, int THH, int TWH, int CB) {
     extern __shared__ __attribute__((aligned(16))) float xt[];   // [THH][TWH][Cp]
     constexpr int RW = MT / 2;            // output rows per wave
     constexpr int TH = 4 * RW;            // output rows per workgroup
@@ -52,7 +52,18 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
     const int co_base = blockIdx.y * (NT * 16);
     const int Ntot = a.deconv4 ? 4 * a.Cout : a.Cout;
 
-    // ---- stage the halo tile: all input channels, zeros outside the image and in the channel pad
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Channel blocks: CB == Cin (one block, the oracle's chain order) unless the caller allowed a relaxed order
+    // (train step): then the chain runs (block, ky, kx, ci) over tiles of CB channels that fit LDS.
+    for (int cb = 0; cb < Cin; cb += CB) {
+    const int cn = min(CB, Cin - cb);
+    if (cb) __syncthreads();                         // every wave is done reading the previous block's tile
+    // ---- stage the halo tile: the block's input channels, zeros outside the image and in the channel pad
     const int npx = THH * TWH;
     for (int p = wave; p < npx; p += 4) {            // one pixel per wave trip, lanes over channels
         const int r = p / TWH, c = p - r * TWH;
@@ -62,9 +73,10 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
         const float* s0 = a.src0 + ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0;
         const float* s1 = a.src1 ? a.src1 + ((size_t)(iy >> a.up1) * (a.Win >> a.up1) + (ix >> a.up1)) * a.C1 : nullptr;
         const float* mk = a.mask ? a.mask + ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0 : nullptr;
-        for (int ch = lane; ch < Cp; ch += 64) {
+        for (int cl = lane; cl < Cp; cl += 64) {
+            const int ch = cb + cl;
             float v = 0.0f;
-            if (in && ch < Cin) {
+            if (in && cl < cn) {
                 if (ch < a.C0) {
                     v = s0[ch];
                     if (a.in_relu) v = v > 0.0f ? v : 0.0f;
@@ -74,16 +86,10 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
                     if (a.in_relu) v = v > 0.0f ? v : 0.0f;
                 }
             }
-            d[ch] = v;
+            d[cl] = v;
         }
     }
     __syncthreads();
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int pixoff[MT];   // float offset of this lane's pixel at tap (0,0), channel 0
 #pragma unroll
@@ -106,16 +112,16 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
         _Pragma("unroll") for (int m = 0; m < MT; ++m)                                           \
             acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(WF[t], XF[m], acc[m][t], 0, 0, 0);
     if constexpr (!FLAT) {
-        const int nks = (Cin + 3) >> 2;        // k-steps per tap
+        const int nks = (cn + 3) >> 2;         // k-steps per tap
         for (int ky = 0; ky < a.KH; ++ky)
             for (int kx = 0; kx < a.KW; ++kx) {
-                const float* wt = a.w + (size_t)((ky * a.KW + kx) * Cin) * a.Cout;
+                const float* wt = a.w + (size_t)((ky * a.KW + kx) * Cin + cb) * a.Cout;
                 const int toff = (ky * TWH + kx) * Cp + g;
                 auto load = [&](float* xf, float* wf, int s) {
                     const int ci = 4 * s + g;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) xf[m] = xt[pixoff[m] + toff + 4 * s];
-                    const bool okc = ci < Cin;
+                    const bool okc = ci < cn;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) wf[t] = (okc && wcol[t] >= 0) ? wt[(size_t)ci * a.Cout + wcol[t]] : 0.0f;
                 };
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
         }
         if (s < nks) { PSEG_XMMA(xa, wa) }
     }
+    }   // channel blocks
 #undef PSEG_XMMA
 
     // ---- epilogue: acc + bias (+ add), ReLU; lane owns n = 4g..4g+3 of pixel p16 in every tile
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
 }
 
 template <int MT, int NT, bool FLAT>
-static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, dim3 grid, size_t lds, hipStream_t st) {
+static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, int CB, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     PSEG_HIP(hipGetDevice(&dev));
@@ -204,7 +211,7 @@ static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, dim3 grid, siz
         PSEG_HIP(hipFuncSetAttribute((const void*)conv_exact_mfma_kernel<MT, NT, FLAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev & 63] = true;
     }
-    conv_exact_mfma_kernel<MT, NT, FLAT><<<grid, 256, lds, st>>>(a, Cp, THH, TWH);
+    conv_exact_mfma_kernel<MT, NT, FLAT><<<grid, 256, lds, st>>>(a, Cp, THH, TWH, CB);
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
 }
@@ -227,8 +234,17 @@ int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st) {
     // the only resident workgroup stages its tile or stores its results)
     auto lds_of = [&](int mt) { return (size_t)((4 * (mt / 2) - 1) * a.stride + a.KH) * TWH * Cp * 4; };
     const size_t l4 = lds_of(4), l2 = lds_of(2);
+    int CB = Cin;
     if (l4 <= budget && (160 * 1024 / l4 >= 2 || l2 > budget || 160 * 1024 / l2 < 2 || getenv("PSEG_EXACT_MT4"))) MT = 4;
     else if (l2 <= budget) MT = 2;
+    if (!MT && a.relaxed && !flat) {
+        // the caller tolerates another summation order (train step): blocks of channels whose 4-row tile fits twice per CU
+        const size_t px2 = (size_t)((4 - 1) * a.stride + a.KH) * TWH;
+        CB = (int)(72 * 1024 / (px2 * 4)) / 4 * 4 - 4;
+        if (CB < 16) return 0;
+        Cp = CB + 2;                               // CB is a multiple of 4: stride 2 (mod 4)
+        MT = 2;
+    }
     if (!MT) return 0;
     THH = (4 * (MT / 2) - 1) * a.stride + a.KH;
     const size_t lds = (size_t)THH * TWH * Cp * 4;
@@ -238,8 +254,8 @@ int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st) {
     dim3 grid(cdiv(a.Wout, XTW) * cdiv(a.Hout, TH), cdiv(ntall, NT));
 #define PSEG_XM(MT_, NT_)                                                                        \
     if (MT == MT_ && NT == NT_) {                                                                \
-        if (flat) PSEG_TRY((launch_xm<MT_, NT_, true>(a, Cp, THH, TWH, grid, lds, st)));         \
-        else PSEG_TRY((launch_xm<MT_, NT_, false>(a, Cp, THH, TWH, grid, lds, st)));             \
+        if (flat) PSEG_TRY((launch_xm<MT_, NT_, true>(a, Cp, THH, TWH, CB, grid, lds, st)));         \
+        else PSEG_TRY((launch_xm<MT_, NT_, false>(a, Cp, THH, TWH, CB, grid, lds, st)));             \
         return 1;                                                                                \
     }
     PSEG_XM(4, 1) PSEG_XM(4, 2) PSEG_XM(4, 3) PSEG_XM(4, 4) PSEG_XM(4, 5)

@@ -303,7 +303,9 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
         // the trip (a few VALU ops) instead of being hoisted and kept live across the whole tile loop,
         // which had cost the persistent variant its second wave per SIMD
         asm volatile("" : "+v"(tid), "+v"(lane), "+v"(p16), "+v"(g));
+#if !PSEG_DIAG   // (the trace build's extra uses of `wave` make this constraint unsatisfiable for the backend)
         asm volatile("" : "+s"(wave));
+#endif
     }
     if (c_persist && !first_tile) {
         set_tile(tile);

@@ -724,8 +724,10 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     const uint32_t drop_key = backward ? (t->drop_seed * 0x632BE5ABu + (uint32_t)t->fwd_count * 0x9E3779B9u) | 1u : 0u;
     if (backward) ++t->fwd_count;
     e.drop_key = drop_key;
+    e.relaxed_f32 = getenv("PSEG_TRAIN_STRICT") ? 0 : 1;   // wide layers: channel-blocked matrix-core kernel (summation order differs from predict)
     const int rc_fwd = run_exact(e, t->d_img, t->d_logits, nullptr, nullptr, nullptr, st);
     e.drop_key = 0;
+    e.relaxed_f32 = 0;
     e.cur_img_f32 = nullptr;
     PSEG_TRY(rc_fwd);
     float* acc = t->d_grad + t->nparam;
@@ -833,6 +835,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.pt = k - 1 - pt; a.pl = k - 1 - pl;
                 a.Hout = lg ? H : Hx; a.Wout = lg ? W : Wx; a.Cout = nc;
                 a.mask = maskd;
+                a.relaxed = getenv("PSEG_TRAIN_STRICT") ? 0 : 1;
                 a.dst = direct ? t->tgrad[src] : t->d_tmp;
                 a.add = direct ? t->tgrad[src] : nullptr;
                 a.dst_pitch = Wx;
@@ -878,6 +881,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 c.Hin = 2 * Hx; c.Win = 2 * Wx; c.Hout = Hx; c.Wout = Wx;
                 c.w = t->d_wd; c.KH = c.KW = 2; c.stride = 2; c.Cout = nc;
                 c.add = t->tgrad[src]; c.dst = t->tgrad[src];
+                c.relaxed = 1;
                 const int rc = launch_conv_exact_mfma(c, st);
                 if (rc < 0) return rc;
                 if (rc == 0) {

@@ -125,25 +125,56 @@ int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hi
 // ---------------------------------------------------------------------------------------------
 // majority vote (lib/postprocess.py:9-26)
 // ---------------------------------------------------------------------------------------------
-// hist[root * ncls + class] += 1 with the adds of one wave to one counter merged into a single
-// atomic (neighbouring pixels almost always share root and class).
-__global__ void vote_count_kernel(const int* L, const int64_t* pred, int* hist, int n, int ncls) {
+// hist[root * ncls + class] += 1.  The histogram is as large as the page (one row of ncls counters per possible
+// root), so every counter update that reaches memory is a scattered read-modify-write: the kernel's cost is the
+// NUMBER of global atomics.  A workgroup therefore owns a 32 x 32 pixel tile (a glyph spans one to four tiles
+// instead of thirty row segments), merges its pixels' (root, class) keys in an LDS hash table and flushes one atomic
+// per distinct key.  Only the rows of roots are ever touched: vote_zero_kernel clears exactly those instead of a
+// page-sized memset.
+constexpr int VT = 32, VSLOTS = 2048;
+__global__ __launch_bounds__(256) void vote_count_kernel(const int* L, const int64_t* pred, int* hist, int H, int W, int ncls) {
+    __shared__ int keys[VSLOTS];
+    __shared__ int vals[VSLOTS];
+    for (int i = threadIdx.x; i < VSLOTS; i += 256) { keys[i] = -1; vals[i] = 0; }
+    __syncthreads();
+    const int tiles_x = (W + VT - 1) / VT;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y = ty * VT + (threadIdx.x >> 3), x0 = tx * VT + (threadIdx.x & 7) * 4;
+    int key = -1, cnt = 0;                        // run of equal keys inside this thread's four pixels
+    auto put = [&](int k, int c) {
+        unsigned slot = ((unsigned)k * 0x9E3779B1u) >> (32 - 11);
+        while (true) {
+            const int old = atomicCAS(&keys[slot], -1, k);
+            if (old == -1 || old == k) { atomicAdd(&vals[slot], c); return; }
+            slot = (slot + 1) & (VSLOTS - 1);
+        }
+    };
+    if (y < H)
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j;
+            int k = -1;
+            if (x < W) {
+                const size_t p = (size_t)y * W + x;
+                const int r = L[p];
+                const int64_t c = pred[p];
+                if (r >= 0 && c >= 0 && c < ncls) k = r * ncls + (int)c;
+            }
+            if (k == key) { ++cnt; continue; }
+            if (key >= 0) put(key, cnt);
+            key = k; cnt = 1;
+        }
+    if (key >= 0) put(key, cnt);
+    __syncthreads();
+    for (int i = threadIdx.x; i < VSLOTS; i += 256)
+        if (keys[i] >= 0) atomicAdd(&hist[keys[i]], vals[i]);
+}
+
+// clears the histogram rows of the roots (the only rows vote_count_kernel adds to and vote_winner_kernel reads)
+__global__ void vote_zero_kernel(const int* L, int* hist, int n, int ncls) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    int key = -1;
-    if (p < n) {
-        const int r = L[p];
-        const int64_t c = pred[p];
-        if (r >= 0 && c >= 0 && c < ncls) key = r * ncls + (int)c;
-    }
-    unsigned long long todo = __ballot(key >= 0);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lkey = __shfl(key, leader);
-        const unsigned long long same = __ballot(key == lkey);
-        if (lane == leader) atomicAdd(&hist[lkey], (int)__popcll(same));
-        todo &= ~same;
-    }
+    if (p >= n || L[p] != p) return;
+    int* h = hist + (size_t)p * ncls;
+    for (int c = 0; c < ncls; ++c) h[c] = 0;
 }
 
 // The root pixel of every component reduces its histogram: np.argmax(bins[1:]) = lowest class
@@ -192,9 +223,9 @@ static int cc_vote_device(int64_t* d_pred, const uint8_t* d_bin, int H, int W, i
     if (!d_L || !d_hist) return fail(PSEG_ENOMEM, "hipMalloc(vote workspace) failed");
     int rc = ccl_run<0>(d_bin, nullptr, d_L, H, W, st);
     if (rc == PSEG_OK) {
-        (void)hipMemsetAsync(d_hist, 0, (size_t)n * ncls * 4, st);
         const int grid = cdiv(n, 256);
-        vote_count_kernel<<<grid, 256, 0, st>>>(d_L, d_pred, d_hist, n, ncls);
+        vote_zero_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, n, ncls);
+        vote_count_kernel<<<cdiv(W, VT) * cdiv(H, VT), 256, 0, st>>>(d_L, d_pred, d_hist, H, W, ncls);
         vote_winner_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, n, ncls);
         vote_apply_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, d_pred, n, ncls);
         if (hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "vote kernel launch failed");

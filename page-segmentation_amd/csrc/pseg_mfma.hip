@@ -97,6 +97,7 @@ struct MConv {
     const uint16_t* tail_wb;   // [64][8] bf16: logits weights for the skip channels
     const float* tail_bias;    // [16] logits bias (zero padded)
     float* out_logits; float* out_probs; int64_t* out_labels; uint8_t* out_labels_u8;
+    float* skip_logits; int skip_CP;   // FL_SKIPLOG: [pixel][skip_CP] f32 logits contribution of this layer's output (it is not stored itself)
     unsigned long long* trace;  // PSEG_TRACE: per-workgroup s_memtime stamps (diagnostic builds only)
     int dbg;   // ablation bits (PSEG_DBG): 1 skip input staging, 2 skip MFMAs, 4 skip epilogue, 8 skip weight DMA
 };
@@ -173,7 +174,7 @@ constexpr int STAGE_SLOTS = 12;  // 16-byte loads a lane keeps in flight while s
 // "read it from the argument block" (generic fallback).  With ~50 runtime geometry fields the
 // compiler hoists and spills scalars by the hundred; with constants the prologue collapses.
 enum { MODE_CONV = 0, MODE_DECONV = 1, MODE_TAIL = 2 };
-enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16, FL_FUSE1 = 32, FL_PERSIST = 64, FL_LOGITS = 128 };
+enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16, FL_FUSE1 = 32, FL_PERSIST = 64, FL_LOGITS = 128, FL_SKIPLOG = 256 };
 #ifndef PSEG_DIAG
 #define PSEG_DIAG 0   // 1: compile the in-kernel trace stamps / ablation switches (diagnostic builds)
 #endif
@@ -826,6 +827,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     // equals pooling the stored bf16 tensor.
     const int CsO = a.nch_out * 8;
     constexpr unsigned OOBS = 0xfffffff0u;
+    constexpr bool c_skiplog = FIXED && (FL_ & FL_SKIPLOG) != 0 && NT == 2;
+    uint2 pks[2][c_skiplog ? MT : 1];
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, a.dst_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(c_pool ? a.pool_dst : a.dst), 0, c_pool ? a.pool_bytes : 0u, 0x00020000);
     unsigned pixoff[MT];   // byte offset of this lane's pixel in dst, or OOBS
@@ -865,7 +868,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             }
             const uint2 pk = make_uint2(pk_bf16(v[m][0], v[m][1]),
                                         pk_bf16(v[m][2], v[m][3]));
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
+            if constexpr (c_skiplog) pks[t < 2 ? t : 0][m] = pk;     // consumed by the logits MFMA below instead of memory
+            else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
         }
         if (c_pool) {
             const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
@@ -885,6 +889,21 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
                                             pk_bf16(q[2], q[3]));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rp, o, 0, 0);
             }
+        }
+    }
+    if constexpr (c_skiplog) {
+        // The skip connection into the logits layer (fcn_skip: conv2 -> logits): this layer's bf16-rounded output is
+        // only ever multiplied by the logits kernel, so that product is taken here -- the two accumulator tiles of a
+        // pixel are the B operand (k = 8g+j <-> cout 4g+j for j < 4, 16+4g+(j-4) otherwise) -- and 4 (8) floats per
+        // pixel leave the kernel instead of the 64-byte tensor row.
+        const bf16x8 wq = *(const bf16x8*)(a.tail_wa + lane * 8);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int y = oy0 + wave * (MT / 2) + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+            f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, __builtin_bit_cast(bf16x8, make_uint4(pks[0][m].x, pks[0][m].y, pks[1][m].x, pks[1][m].y)), z, 0, 0, 0);
+            if (y < a.Hout && x < a.Wout && 4 * g < a.skip_CP)
+                *(float4*)(a.skip_logits + ((size_t)y * a.Wout + x) * a.skip_CP + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
         }
     }
     } while (0);
@@ -923,6 +942,7 @@ struct TailC {
     const uint16_t* wA1;           // [tile][k-step][64][8]
     const uint16_t* wA2;           // [ab][64][8]
     const float* beta;             // [NTL*16]
+    const float* S;                // skip-logits buffer [full-res canvas pixel][CP] written by the skip producer, or null
     float* out_logits; float* out_probs; int64_t* out_labels; uint8_t* out_labels_u8;
 };
 
@@ -978,6 +998,15 @@ __global__ __launch_bounds__(256) void tail_composed_kernel(TailC a) {
                 const int t = ab * CP / 16;
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, __builtin_bit_cast(bf16x8, sb[ab][s]), acc[t], 0, 0, 0);
             }
+    }
+    if (a.S) {   // skip contribution precomputed by the producer of the skip tensor: this lane's four classes of its sub-pixel
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const int row0 = 16 * t + 4 * g, ab = row0 / CP, c0 = row0 - ab * CP;
+            const size_t px = (size_t)(2 * hy + (ab >> 1)) * (2 * a.Wh) + 2 * hx + (ab & 1);
+            const float4 sv = *(const float4*)(a.S + px * CP + c0);
+            acc[t][0] += sv.x; acc[t][1] += sv.y; acc[t][2] += sv.z; acc[t][3] += sv.w;
+        }
     }
     // ---- per pixel: classes live in CP/4 lane groups (xor 16 / 32 partners) ----
     const int C = a.C;
@@ -1434,6 +1463,9 @@ struct MfmaPlan {
     bool nw8_ok = false;        // an 8-wave kernel instance exists for this layer shape
     bool nw8_resident = false;  // ... and its whole weight set stays resident beside the 16-row tile
     int cmax = 4;
+    float* d_skiplog = nullptr;    // skip-logits buffer [canvas pixel][skip_CP] (op.skiplog >= 0), grown with the canvas
+    size_t skiplog_bytes = 0;
+    int skip_CP = 0;
     UpSplit* upsplit = nullptr;   // PLAN_UPSPLIT: GEMM + gather-sum form of upsample -> k2 conv
 };
 
@@ -1445,6 +1477,7 @@ void mfma_free_op(Op& op) {
     (void)hipFree(p->d_tail_wa); (void)hipFree(p->d_tail_wb); (void)hipFree(p->d_tail_bias);
     (void)hipFree(p->d_tc_wA1); (void)hipFree(p->d_tc_wA2); (void)hipFree(p->d_tc_beta);
     upsplit_free(p->upsplit);
+    (void)hipFree(p->d_skiplog);
     delete p;
     op.plan = nullptr;
 }
@@ -1518,6 +1551,27 @@ int mfma_plan_graph(Engine& e) {
             op.fused_away = true;
         }
     }
+    // skip connection into a composed tail (fcn_skip: conv2 -> logits): when the full-resolution conv output has no
+    // other reader than its fused pool and the logits layer, the conv stores its logits contribution (4 or 8 floats
+    // per pixel) instead of the tensor, and the tail adds it: 64 + 64 B/px of HBM traffic become 16 + 16 (32 + 32).
+    if (!getenv("PSEG_NO_SKIPLOG") && !getenv("PSEG_NO_TAIL_COMPOSE") && !getenv("PSEG_NO_TAIL_FUSION") && !getenv("PSEG_GENERIC") &&
+        !getenv("PSEG_NO_CONV1_FUSION") && e.n_classes <= 8)
+        for (auto& dc : e.ops) {
+            if (dc.type != OP_DECONV2 || dc.tail_logits < 0 || dc.relu) continue;
+            Op& lg = e.ops[dc.tail_logits];
+            if (lg.src1 < 0) continue;
+            const int pi = producer_of(e, lg.src1);
+            if (pi < 0) continue;
+            Op& cv = e.ops[pi];
+            if (cv.type != OP_CONV || cv.pool_dst < 0 || cv.fuse1 < 0 || cv.Cout > 32 || cv.relu || cv.add >= 0 || cv.tail_logits >= 0) continue;
+            int users = 0;
+            for (auto& o : e.ops) users += ((o.src0 == cv.dst) + (o.src1 == cv.dst) + (o.add == cv.dst)) * (o.fused_away && o.type == OP_POOL ? 0 : 1);
+            if (users != 1) continue;                                   // the logits layer only
+            const int nks0 = cdiv((e.tensors[dc.src0].Cs + (dc.src1 >= 0 ? e.tensors[dc.src1].Cs : 0)) / 8, 4);
+            if (nks0 != 3) continue;                                    // the composed-tail instances that take the buffer
+            cv.skiplog = dc.tail_logits;
+            e.tensors[cv.dst].fused = true;
+        }
     return PSEG_OK;
 }
 
@@ -1857,6 +1911,25 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         else { const int ab = n / P->CoP, co = n % P->CoP; if (ab < 4 && co < Cout) bb[n] = bias[co]; }
     }
     PSEG_TRY(upload(&P->d_bias, bb));
+    if (!deconv && op.skiplog >= 0) {
+        // skip-logits fusion: the logits kernel rows of this layer's channels (they follow the deconv channels in the
+        // concat, Keras (1,1,Cdec+Cout,C): w[(Cdec + co)*C + c]) as ONE A fragment: lane l = (class = l & 15, g = l >> 4),
+        // element j <-> cout co = j < 4 ? 4g + j : 16 + 4g + (j - 4)
+        const Op& lg = e.ops[op.skiplog];
+        const std::vector<float>& lw = e.params[lg.kparam].host;
+        const int C = lg.Cout, Cdec = lg.Cin - Cout;
+        std::vector<uint16_t> wq(64 * 8, 0);
+        for (int l = 0; l < 64; ++l) {
+            const int cls = l & 15, gg = l >> 4;
+            if (cls >= C) continue;
+            for (int j = 0; j < 8; ++j) {
+                const int co = j < 4 ? 4 * gg + j : 16 + 4 * gg + (j - 4);
+                if (co < Cout) wq[l * 8 + j] = f2bf(lw[(size_t)(Cdec + co) * C + cls]);
+            }
+        }
+        PSEG_TRY(upload(&P->d_tail_wa, wq));
+        P->skip_CP = C <= 4 ? 4 : 8;
+    }
     if (!deconv && op.tail_logits >= 0) {
         // conv + logits fusion: logits kernel (Keras (1,1,64,C): w[co*C + c]) in the fragment order of the two
         // epilogue MFMAs: lane l = (class = l & 15, g = l >> 4), MFMA q, element j <-> cout
@@ -1908,9 +1981,12 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         PSEG_TRY(upload(&P->d_tail_wb, wbk));
         PSEG_TRY(upload(&P->d_tail_bias, tb));
         // ---- composed tail: M_ab = Wl_dec . Wd[ab] (from the bf16-rounded kernels, float64 products) ----
-        const int nks0 = cdiv((Cs0 + Cs1) / 8, 4), nkss = Cskip > 0 ? cdiv(round_up(Cskip, 8) / 8, 4) : 0;
+        bool skip_in_buffer = false;     // the skip producer stores its logits contribution (op.skiplog): no skip GEMM here
+        if (lg.src1 >= 0) { const int sp = producer_of(e, lg.src1); skip_in_buffer = sp >= 0 && e.ops[sp].skiplog >= 0; }
+        const int nks0 = cdiv((Cs0 + Cs1) / 8, 4), nkss = (Cskip > 0 && !skip_in_buffer) ? cdiv(round_up(Cskip, 8) / 8, 4) : 0;
         const int CP = C <= 4 ? 4 : (C <= 8 ? 8 : 16);
-        const bool shapes_ok = (nks0 == 3 && nkss == 1) || (nks0 == 1 && nkss == 0);
+        const bool shapes_ok = (nks0 == 3 && nkss == 1) || (nks0 == 1 && nkss == 0) || (nks0 == 3 && skip_in_buffer);
+        if (skip_in_buffer && (op.relu || !shapes_ok || CP > 8)) return fail(PSEG_EUNSUPPORTED, "skip-logits fusion was planned for a tail that cannot be composed");
         if (!op.relu && !getenv("PSEG_NO_TAIL_COMPOSE") && shapes_ok) {
             const int NTL = CP / 4;
             std::vector<double> M((size_t)4 * C * Cin, 0.0);       // [ab][cls][ci]
@@ -1983,9 +2059,9 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     const int mode = a.tail ? MODE_TAIL : (a.deconv ? MODE_DECONV : MODE_CONV);
     const int fl = (a.pool_dst ? FL_POOL : 0) | (a.add ? FL_ADD : 0) | (a.in_relu ? FL_INRELU : 0) |
                    (a.up0 ? FL_UP0 : 0) | (a.up1 ? FL_UP1 : 0) | (a.f1_img ? FL_FUSE1 : 0) | (a.ntiles > 0 ? FL_PERSIST : 0) |
-                   ((!a.deconv && a.tail_wa) ? FL_LOGITS : 0);
+                   ((!a.deconv && a.tail_wa && !a.skip_logits) ? FL_LOGITS : 0) | (a.skip_logits ? FL_SKIPLOG : 0);
     const int sg = a.sigma, st_ = a.stride, ks = P.KS;
-    if (a.f1_img && !(P.MT == 8 && P.NT == 2 && ks == 5 && sg == 3 && mode == MODE_CONV && (fl & ~FL_PERSIST) == (FL_POOL | FL_FUSE1)))
+    if (a.f1_img && !(P.MT == 8 && P.NT == 2 && ks == 5 && sg == 3 && mode == MODE_CONV && (fl & ~(FL_PERSIST | FL_SKIPLOG)) == (FL_POOL | FL_FUSE1)))
         return fail(PSEG_EUNSUPPORTED, "first-layer fusion has no kernel instance for this shape");
 #define PSEG_TRY_INST8(MT_, NT_, KS_, ST_, SG_, MODE_, FL_)                                         \
     if (P.NW == 8 && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == (FL_)) \
@@ -2004,6 +2080,8 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
 #define PSEG_TRY_INST(MT_, NT_, KS_, ST_, SG_, MODE_, FL_)                                          \
     if (!getenv("PSEG_GENERIC") && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == (FL_)) \
         return launch_inst<MT_, NT_, KS_, ST_, SG_, MODE_, (FL_)>(a, P, grid, st);
+    PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL | FL_FUSE1 | FL_PERSIST | FL_SKIPLOG)   // conv1 + conv2 fused, persistent, skip logits instead of the tensor
+    PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL | FL_FUSE1 | FL_SKIPLOG)
     PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL | FL_FUSE1 | FL_PERSIST)   // conv1 + conv2 fused, persistent
     PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL | FL_FUSE1)   // conv1 + conv2 fused
     PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL)      // conv2 (dense tile, resident weights)
@@ -2034,6 +2112,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, FL_LOGITS)
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_INRELU | FL_ADD | FL_LOGITS)   // res_unet: last block + logits + argmax
     if (fl & FL_LOGITS) return fail(PSEG_EUNSUPPORTED, "conv + logits fusion has no kernel instance for this shape");
+    if (fl & FL_SKIPLOG) return fail(PSEG_EUNSUPPORTED, "skip-logits fusion has no kernel instance for this shape");
     PSEG_TRY_INST(4, 4, 2, 1, 6, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv
     PSEG_TRY_INST(4, 4, 3, 2, 6, MODE_CONV, 0)            // res_unet encoder: stride-2 shortcut conv
     PSEG_TRY_INST(4, 4, 3, 2, 6, MODE_CONV, FL_INRELU)    // res_unet encoder: stride-2 first conv of the block
@@ -2199,6 +2278,19 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         a.out_labels = e.cur_labels;
         a.out_labels_u8 = e.cur_labels_u8;
     }
+    if (op.skiplog >= 0) {
+        const size_t need = (size_t)a.Hout * a.Wout * P->skip_CP * 4;
+        if (need > P->skiplog_bytes) {
+            PSEG_HIP(hipStreamSynchronize(st));
+            (void)hipFree(P->d_skiplog);
+            P->d_skiplog = nullptr; P->skiplog_bytes = 0;
+            PSEG_HIP(hipMalloc((void**)&P->d_skiplog, need));
+            P->skiplog_bytes = need;
+        }
+        a.skip_logits = P->d_skiplog;
+        a.skip_CP = P->skip_CP;
+        a.tail_wa = P->d_tail_wa;
+    }
     if (op.fuse1 >= 0) {
         const Op& c1 = e.ops[op.fuse1];
         auto* P1 = (MfmaPlan*)c1.plan;
@@ -2254,12 +2346,23 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
             t.Hh = e.tH(s0); t.Wh = e.tW(s0);
             t.H0 = e.H; t.W0 = e.W; t.C = lg.Cout;
             t.wA1 = P->d_tc_wA1; t.wA2 = P->d_tc_wA2; t.beta = P->d_tc_beta;
+            if (lg.src1 >= 0) {
+                const int sp = producer_of(e, lg.src1);
+                if (sp >= 0 && e.ops[sp].skiplog >= 0) {
+                    auto* PS = (MfmaPlan*)e.ops[sp].plan;
+                    if (!PS || !PS->d_skiplog || PS->skip_CP != P->tc_CP) return fail(PSEG_EINVAL, "skip-logits buffer missing for the composed tail");
+                    t.S = PS->d_skiplog;
+                    t.skip = nullptr;
+                }
+            }
             t.out_logits = e.cur_logits; t.out_probs = e.cur_probs; t.out_labels = e.cur_labels; t.out_labels_u8 = e.cur_labels_u8;
             if (t.Wh % 16) return fail(PSEG_EINVAL, "composed tail needs a canvas width multiple of 32");
             const int waves = t.Hh * (t.Wh / 16);
             const dim3 grid(cdiv(waves, 4));
             const int key = P->tc_CP * 100 + P->tc_nks0 * 10 + P->tc_nkss;
             switch (key) {
+                case 430: tail_composed_kernel<4, 3, 0><<<grid, 256, 0, st>>>(t); break;   // skip logits from the producer's buffer
+                case 830: tail_composed_kernel<8, 3, 0><<<grid, 256, 0, st>>>(t); break;
                 case 431: tail_composed_kernel<4, 3, 1><<<grid, 256, 0, st>>>(t); break;
                 case 831: tail_composed_kernel<8, 3, 1><<<grid, 256, 0, st>>>(t); break;
                 case 1631: tail_composed_kernel<16, 3, 1><<<grid, 256, 0, st>>>(t); break;

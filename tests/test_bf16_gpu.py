@@ -48,7 +48,7 @@ def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, arch, C, shape):
         assert g.shape == a.shape, name
         err = np.abs(g - a).max()
         assert err <= TOL * max(1.0, np.abs(a).max()), "%s: max err %g (max |a| %g)" % (name, err, np.abs(a).max())
-    assert checked >= len(acts) - 3
+    assert checked >= len(acts) - 4      # logits + at most three tensors that live only inside fused kernels
     assert np.abs(logit - z_o).max() <= TOL * max(1.0, np.abs(z_o).max())
     bad, total = _check_labels(pred, logit, z_o)
     assert np.array_equal(pred, np.argmax(logit, -1))
@@ -137,6 +137,7 @@ def test_bf16_conv1_fusion_is_bit_identical_to_unfused(gpu, oracle_mod, monkeypa
     stand-alone first-layer kernel: logits of the fused and unfused engines are identical."""
     rng = np.random.default_rng(33)
     Wt = oracle_mod.init_weights("fcn_skip", 3, seed=8, gain=1.5, bias_scale=0.05)
+    monkeypatch.setenv("PSEG_NO_SKIPLOG", "1")        # keep conv2's tensor in memory: it is compared below
     outs = []
     for fuse in (True, False):
         if not fuse:
@@ -155,3 +156,28 @@ def test_bf16_conv1_fusion_is_bit_identical_to_unfused(gpu, oracle_mod, monkeypa
         outs.append(res)
     for (zf, lf, cf), (zu, lu, cu) in zip(*outs):
         assert np.array_equal(cf, cu) and np.array_equal(zf, zu) and np.array_equal(lf, lu)
+
+
+@pytest.mark.parametrize("C,shape", [(3, (70, 50)), (6, (160, 224)), (3, (33, 1)), (8, (96, 130))])
+def test_bf16_skip_logits_fusion_agrees_with_the_stored_skip_tensor(gpu, oracle_mod, monkeypatch, C, shape):
+    """fcn_skip: conv2 hands the logits layer its contribution (4 / 8 floats per pixel, taken from the same bf16-rounded
+    values) instead of storing its 30-channel full-resolution tensor.  Same products, another float32 summation
+    order: logits agree to float32 noise, labels except at exact near-ties; the tensor is reported as fused."""
+    Wt = oracle_mod.init_weights("fcn_skip", C, seed=9, gain=1.5, bias_scale=0.05)
+    img = np.random.default_rng(shape[0]).integers(0, 256, size=shape, dtype=np.uint8)
+    eng = gpu.Engine("fcn_skip", C, mode=gpu.MODE_BF16)
+    eng.set_weights(Wt)
+    z1, p1, l1 = eng.predict(img)
+    with pytest.raises(gpu.PsegError, match="fused"):
+        eng.activation("conv2d_1")
+    assert eng.activation("max_pooling2d").shape[2] == 30          # the pooled tensor is still written
+    eng.close()
+    monkeypatch.setenv("PSEG_NO_SKIPLOG", "1")
+    eng = gpu.Engine("fcn_skip", C, mode=gpu.MODE_BF16)
+    eng.set_weights(Wt)
+    z0, p0, l0 = eng.predict(img)
+    assert eng.activation("conv2d_1").shape[2] == 30
+    eng.close()
+    assert np.abs(z1 - z0).max() <= 2e-6 * max(1.0, np.abs(z0).max())
+    assert np.abs(p1 - p0).max() <= 1e-5
+    assert _check_labels(l1, z1, z0)[0] == 0 and np.array_equal(l1, np.argmax(z1, -1))

@@ -125,10 +125,10 @@ def main():
         peak = PEAK_TFLOPS[args.mode]
         total_ms = sum(s[1] / s[2] for s in slots)
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
-        # runs, gfx950 correction applied) recorded under profiles/ -- see profiles/r01_traffic.json
+        # runs, gfx950 correction applied) recorded under profiles/ -- see profiles/r01e_traffic.json
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01e_traffic.json")) as f:
                 tr = json.load(f).get(name)
             if tr and (H, W, C, args.arch, args.mode) == (2048, 1536, 3, "fcn_skip", "bf16"):
                 traffic = tr["hbm_read_bytes"] + tr["hbm_write_bytes"]
@@ -136,7 +136,7 @@ def main():
             traffic = None
         roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01e_traffic.json)",
                 "avg_ms": round(avg_ms, 5), "launches": int(n),
                 "flop_per_launch": flops,
                 "whole_net_frac": round(eng.flops_per_pixel() * H * W / (total_ms * 1e-3) / 1e12 / peak, 5),

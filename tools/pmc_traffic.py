@@ -9,6 +9,8 @@ import csv, glob, json, os, sys, collections
 LAYER_OF = [  # kernel-name fragment -> layer key used by bench.py's timing slots (fcn_skip, 2048x1536)
     ("conv_mfma_kernel<8, 2, 5, 1, 3, 0, 33", "conv2d_1"),
     ("conv_mfma_kernel<8, 2, 5, 1, 3, 0, 97", "conv2d_1"),
+    ("conv_mfma_kernel<8, 2, 5, 1, 3, 0, 353", "conv2d_1"),
+    ("conv_mfma_kernel<8, 2, 5, 1, 3, 0, 289", "conv2d_1"),
     ("tail_composed_kernel", "conv2d_transpose_4"),
 ]
 

@@ -1551,6 +1551,15 @@ int mfma_plan_graph(Engine& e) {
             op.fused_away = true;
         }
     }
+    // conv outputs nothing reads but their fused pool (fcn_skip: conv4; fcn: conv2, conv4, conv6) are not written: the
+    // launch gives the output buffer descriptor zero length, which makes the hardware drop the stores
+    if (!getenv("PSEG_NO_POOL_ONLY"))
+        for (auto& cv : e.ops) {
+            if (cv.type != OP_CONV || cv.pool_dst < 0 || cv.add >= 0) continue;
+            int users = 0;
+            for (auto& o : e.ops) users += ((o.src0 == cv.dst) + (o.src1 == cv.dst) + (o.add == cv.dst)) * (o.fused_away && o.type == OP_POOL ? 0 : 1);
+            if (users == 0) { cv.pool_only = true; e.tensors[cv.dst].fused = true; }
+        }
     // skip connection into a composed tail (fcn_skip: conv2 -> logits): when the full-resolution conv output has no
     // other reader than its fused pool and the logits layer, the conv stores its logits contribution (4 or 8 floats
     // per pixel) instead of the tensor, and the tail adds it: 64 + 64 B/px of HBM traffic become 16 + 16 (32 + 32).
@@ -2184,7 +2193,7 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     const Tensor& d = e.tensors[op.dst];
     a.dst = (uint16_t*)d.d;
     a.nch_out = d.Cs / 8;
-    a.dst_bytes = (unsigned)((size_t)e.tH(d) * e.tW(d) * d.Cs * 2);
+    a.dst_bytes = op.pool_only ? 0u : (unsigned)((size_t)e.tH(d) * e.tW(d) * d.Cs * 2);
     a.CoP = P.CoP;
     a.nb_loop = 1;
     a.nb_total = P.nblocks_n;

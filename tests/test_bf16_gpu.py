@@ -26,15 +26,25 @@ def _check_labels(pred, logit, logit_o):
     ("fcn_skip", 3, (64, 96)), ("fcn_skip", 3, (70, 50)), ("fcn_skip", 6, (160, 96)), ("fcn_skip", 3, (33, 1)),
     ("fcn_skip", 3, (256, 320)), ("fcn", 3, (96, 64)), ("unet", 3, (64, 96)), ("res_unet", 3, (70, 50)),
 ])
-def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, arch, C, shape):
+def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, monkeypatch, arch, C, shape):
     rng = np.random.default_rng(11)
     H, W = shape
     img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
     Wt = oracle_mod.init_weights(arch, C, seed=42, gain=1.5, bias_scale=0.05)
     z_o, acts = oracle_mod.forward(arch, Wt, img, "bf16", return_acts=True)
+    # the default engine: final outputs
     eng = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
     eng.set_weights(Wt)
     logit, prob, pred = eng.predict(img)
+    eng.close()
+    # an engine that keeps the tensors the default one never writes (pool-only conv outputs, the skip into the
+    # logits layer): intermediate activations layer by layer
+    monkeypatch.setenv("PSEG_NO_POOL_ONLY", "1")
+    monkeypatch.setenv("PSEG_NO_SKIPLOG", "1")
+    eng = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
+    eng.set_weights(Wt)
+    logit_k, _, pred_k = eng.predict(img)
+    assert np.abs(logit_k - logit).max() <= 2e-6 * max(1.0, np.abs(logit).max())
     checked = 0
     for name, a in acts.items():
         if name == "logits":
@@ -48,7 +58,7 @@ def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, arch, C, shape):
         assert g.shape == a.shape, name
         err = np.abs(g - a).max()
         assert err <= TOL * max(1.0, np.abs(a).max()), "%s: max err %g (max |a| %g)" % (name, err, np.abs(a).max())
-    assert checked >= len(acts) - 4      # logits + at most three tensors that live only inside fused kernels
+    assert checked >= len(acts) - 3      # logits + at most two tensors that live only inside fused kernels
     assert np.abs(logit - z_o).max() <= TOL * max(1.0, np.abs(z_o).max())
     bad, total = _check_labels(pred, logit, z_o)
     assert np.array_equal(pred, np.argmax(logit, -1))

@@ -56,11 +56,11 @@ def test_training_reduces_the_loss(gpu, oracle_mod, arch):
     eng.set_weights(Wt)
     eng.train_init(clipnorm=1.0)
     first = np.mean([eng.eval_step(*p)[0] for p in pages])
-    for step in range(30):
+    for step in range(60):                                       # Adam at 1e-3 is spiky on res_unet during the first 30 steps
         eng.train_forward_backward(*pages[step % 2])
         eng.train_apply(1e-3)
     last = np.mean([eng.eval_step(*p)[0] for p in pages])
-    assert np.isfinite(last) and last < 0.8 * first
+    assert np.isfinite(last) and last < 0.5 * first
     # the bf16 predict engine accepts the trained weights
     eb = gpu.Engine(arch, 3, mode=gpu.MODE_BF16)
     eb.set_weights(eng.get_weights())

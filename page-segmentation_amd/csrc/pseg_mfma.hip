@@ -97,6 +97,7 @@ struct MConv {
     const uint16_t* tail_wb;   // [64][8] bf16: logits weights for the skip channels
     const float* tail_bias;    // [16] logits bias (zero padded)
     float* out_logits; float* out_probs; int64_t* out_labels; uint8_t* out_labels_u8;
+    int xq, xr;          // XCD-aware tile order: tiles / 8 and tiles % 8 (xq < 0: off)
     float* skip_logits; int skip_CP;   // FL_SKIPLOG: [pixel][skip_CP] f32 logits contribution of this layer's output (it is not stored itself)
     unsigned long long* trace;  // PSEG_TRACE: per-workgroup s_memtime stamps (diagnostic builds only)
     int dbg;   // ablation bits (PSEG_DBG): 1 skip input staging, 2 skip MFMAs, 4 skip epilogue, 8 skip weight DMA
@@ -216,7 +217,17 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     int p16 = lane & 15, g = lane >> 4;
     const int tiles_x = (a.Wout + TW - 1) / TW;
     int oy0, ox0, iy0, ix0;
+    // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with its own
+    // L2.  Workgroup b therefore takes tile number (b / 8) of band (b % 8), bands being contiguous runs of tiles (a
+    // bijection on [0, tiles) for any tile count): the tiles whose halos overlap sit in one XCD's L2 instead of being
+    // fetched from HBM by several.  xq < 0: plain order.
+    auto xcd_tile = [&](int t) {
+        if (a.xq < 0) return t;
+        const int x = t & 7, j = t >> 3;
+        return x * a.xq + min(x, a.xr) + j;
+    };
     auto set_tile = [&](int t) {
+        t = xcd_tile(t);
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
         oy0 = ty * TH; ox0 = tx * TW;
         iy0 = oy0 * c_stride - a.pt; ix0 = ox0 * c_stride - a.pl;
@@ -384,7 +395,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
                 // k-loop and epilogue instead of opening the next trip
                 const int nt = tile + (int)gridDim.x;
                 if (nt < a.ntiles) {
-                    const int nty = nt / tiles_x, ntx = nt - nty * tiles_x;
+                    const int ntt = xcd_tile(nt);
+                    const int nty = ntt / tiles_x, ntx = ntt - nty * tiles_x;
                     load_u8(nty * TH, ntx * TW);
                 }
             }
@@ -2180,6 +2192,7 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.bytes0 = (unsigned)((size_t)e.tH(s0) * e.tW(s0) * s0.Cs * 2);
     a.bytes1 = s1 ? (unsigned)((size_t)e.tH(*s1) * e.tW(*s1) * s1->Cs * 2) : 0u;
     a.sigma = P.PS2 / 16;
+    a.xq = -1; a.xr = 0;      // plain tile order unless the launcher sets the XCD bands
     a.up0 = op.up0;
     a.up1 = op.up1;
     a.Hin = e.tH(s0) << op.up0;
@@ -2313,6 +2326,8 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         a.lds_f1_off = P->lds_f1_off;
     }
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, P->NW * (P->MT / 2)), P->nblocks_n);
+    a.xq = getenv("PSEG_NO_XCD") ? -1 : (int)grid.x / 8;
+    a.xr = (int)grid.x % 8;
     // persistent instance (PSEG_NO_PERSIST=1 disables): resident weights (NB == 1), single channel block, two
     // workgroups per CU walking 12 tiles each: the 38 KB weight set and the k-chunk table are staged once per
     // workgroup instead of once per tile.  Worth 1-3 % on the fused conv1+conv2 kernel (the DMA it saves was
@@ -2400,6 +2415,8 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
         if (P->nblk == 1 && P->nblocks_n == 2 && !getenv("PSEG_GENERIC") && (a.sigma == 10 || a.sigma == 6)) a.nb_loop = 2;
     }
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n / a.nb_loop);
+    a.xq = getenv("PSEG_NO_XCD") ? -1 : (int)grid.x / 8;
+    a.xr = (int)grid.x % 8;
     return launch_generic_any(a, *P, grid, st, op.layer.c_str());
 }
 

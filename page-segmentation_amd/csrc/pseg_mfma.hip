@@ -256,7 +256,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     // and destination of piece (wave + 4j) are base + j * 4 KiB.
     // N blocks: normally one per workgroup (blockIdx.y); the fused tail walks all of its N blocks in
     // one workgroup (nb_loop > 1, single channel block) so the input tile is staged once.
-    constexpr int NBL = (FIXED && MODE_ == MODE_TAIL) ? 2 : 1;   // compile-time: other instances keep a flat body
+    // (also deconv4 of fcn_skip, sigma 14: its two N blocks re-read a 41 MB tensor that no longer sits in L2 by the time the second runs)
+    constexpr int NBL = (FIXED && (MODE_ == MODE_TAIL || (MODE_ == MODE_DECONV && SG_ == 14))) ? 2 : 1;   // compile-time: other instances keep a flat body
 #pragma unroll 1
     for (int nbi = 0; nbi < NBL; ++nbi) {
     const int nb = blockIdx.y * NBL + nbi;
@@ -2414,6 +2415,7 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
         // the specialised tail instances walk both N blocks in one workgroup (NBL = 2 in the kernel)
         if (P->nblk == 1 && P->nblocks_n == 2 && !getenv("PSEG_GENERIC") && (a.sigma == 10 || a.sigma == 6)) a.nb_loop = 2;
     }
+    if (op.tail_logits < 0 && P->nblk == 1 && P->nblocks_n == 2 && !getenv("PSEG_GENERIC") && a.sigma == 14 && P->NT == 4) a.nb_loop = 2;   // deconv4 (fcn_skip)
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n / a.nb_loop);
     a.xq = getenv("PSEG_NO_XCD") ? -1 : (int)grid.x / 8;
     a.xr = (int)grid.x % 8;

@@ -31,6 +31,7 @@ int fail(int code, const char* fmt, ...);
         if (_rc != PSEG_OK) return _rc;                                                        \
     } while (0)
 
+constexpr int PSEG_MAXC = 64;   // classes the train-step metric slots and the wide bf16 logits kernel are sized for
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

@@ -1717,8 +1717,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     }
     if (op.type == OP_LOGITS) {
         P->kind = PLAN_LOGITS;
-        P->cmax = Cout <= 4 ? 4 : (Cout <= 8 ? 8 : 16);
-        if (Cout > 16) return fail(PSEG_EUNSUPPORTED, "bf16 mode supports at most 16 classes (got %d)", Cout);
+        P->cmax = Cout <= 4 ? 4 : (Cout <= 8 ? 8 : (Cout <= 16 ? 16 : (Cout <= 32 ? 32 : 64)));
+        if (Cout > PSEG_MAXC) return fail(PSEG_EUNSUPPORTED, "bf16 mode supports at most %d classes (got %d)", PSEG_MAXC, Cout);
         std::vector<float> wf((size_t)(Cs0 + Cs1) * P->cmax, 0.0f), bb(P->cmax, 0.0f);
         for (int ci = 0; ci < Cin; ++ci) {
             const int cs = ci < C0 ? ci : Cs0 + (ci - C0);
@@ -1726,6 +1726,10 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         }
         for (int c = 0; c < Cout; ++c) bb[c] = bias[c];
         PSEG_TRY(upload(&P->d_wf, wf));
+        if (P->cmax > 16) {   // more classes than one MFMA tile has rows: the one-pixel-per-thread kernel (logits_bf16_kernel<32 / 64>)
+            PSEG_TRY(upload(&P->d_bias, bb));
+            return PSEG_OK;
+        }
         // MFMA form: A fragments [k-step][lane = (class, g)][8 channels of chunk 4s + g], bias padded to 16
         const int nks = cdiv((Cs0 + Cs1) / 8, 4);
         std::vector<uint16_t> wa((size_t)nks * 64 * 8, 0);
@@ -2440,7 +2444,7 @@ int mfma_launch_logits(Engine& e, Op& op, float* d_logits, float* d_probs, int64
     const uint16_t* p0 = (const uint16_t*)s0.d;
     const uint16_t* p1 = s1 ? (const uint16_t*)s1->d : nullptr;
     const int n0 = s0.Cs / 8, n1 = s1 ? s1->Cs / 8 : 0;
-    if (!getenv("PSEG_LOGITS_VALU")) {
+    if (!getenv("PSEG_LOGITS_VALU") && P->cmax <= 16) {
         const int waves = e.H * cdiv(e.W, 16);
         logits_mfma_kernel<<<cdiv(waves, 4), 256, 0, st>>>(p0, n0, p1, n1, e.Wp, e.H, e.W, op.Cout, P->d_wpk, P->d_bias,
                                                           d_logits, d_probs, d_labels, d_labels_u8);
@@ -2451,7 +2455,9 @@ int mfma_launch_logits(Engine& e, Op& op, float* d_logits, float* d_probs, int64
                                                               op.Cout, d_logits, d_probs, d_labels, d_labels_u8)
     if (P->cmax == 4) LG(4);
     else if (P->cmax == 8) LG(8);
-    else LG(16);
+    else if (P->cmax == 16) LG(16);
+    else if (P->cmax == 32) LG(32);
+    else LG(64);
 #undef LG
     return PSEG_OK;
 }

@@ -71,8 +71,8 @@ void train_free(Engine& e) {
 // acc layout: [0] sum loss, [1] count correct, [2..2+C) intersection_c, [2+C..2+2C) sum_c
 __global__ void ce_metrics_kernel(const float* logits, const uint8_t* labels, int n, int C, float inv_n,
                                   float* dlogits, float* acc) {
-    __shared__ float sh[2 + 2 * 16];
-    if (threadIdx.x < 2 + 2 * 16) sh[threadIdx.x] = 0.0f;
+    __shared__ float sh[2 + 2 * PSEG_MAXC];
+    if (threadIdx.x < 2 + 2 * PSEG_MAXC) sh[threadIdx.x] = 0.0f;
     __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) {
@@ -109,7 +109,7 @@ __global__ void ce_metrics_kernel(const float* logits, const uint8_t* labels, in
 //   categorical_hinge on the raw logits: mean_px max(0, max(0, max_{c != y} z_c) - z_y + 1)
 //   categorical_focal on the raw logits clipped to [1e-7, 1 - 1e-7] ("y_pred" is what the model outputs):
 //            100 * mean over (pixel, class) of -1_c * 0.25 (1 - z_c)^2 log z_c
-// acc[2 + 2*16] accumulates the hinge / focal loss sum.
+// acc[2 + 2*PSEG_MAXC] accumulates the hinge / focal loss sum.
 __global__ void loss_grad_kernel(int kind, const float* logits, const uint8_t* labels, int n, int C, float inv_n,
                                  const float* acc, float* dlogits, float* alt_sum) {
     __shared__ float sh;
@@ -123,7 +123,7 @@ __global__ void loss_grad_kernel(int kind, const float* logits, const uint8_t* l
         if (kind == PSEG_LOSS_DICE || kind == PSEG_LOSS_JACCARD || kind == PSEG_LOSS_DICE_CE) {
             float m = z[0];
             for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
-            float s = 0.0f, pr[16], dp[16], dot = 0.0f;
+            float s = 0.0f, pr[PSEG_MAXC], dp[PSEG_MAXC], dot = 0.0f;
             for (int c = 0; c < C; ++c) { pr[c] = expf(z[c] - m); s += pr[c]; }
             const float scale = (kind == PSEG_LOSS_DICE_CE ? 0.5f : 1.0f) / (float)C;
             for (int c = 0; c < C; ++c) {
@@ -670,7 +670,7 @@ static int producer_of(const Engine& e, int tensor) {
 
 static int train_init(Engine& e, float b1, float b2, float eps, float clipnorm, float clipvalue) {
     if (e.mode != PSEG_MODE_F32_EXACT) return fail(PSEG_EUNSUPPORTED, "training runs on the float32 engine (mode F32_EXACT)");
-    if (e.n_classes > 16) return fail(PSEG_EUNSUPPORTED, "training supports at most 16 classes");
+    if (e.n_classes > PSEG_MAXC) return fail(PSEG_EUNSUPPORTED, "training supports at most %d classes", PSEG_MAXC);
     train_free(e);
     auto* t = new TrainState();
     e.train = t;
@@ -682,7 +682,7 @@ static int train_init(Engine& e, float b1, float b2, float eps, float clipnorm, 
         o = (o + 3) & ~(int64_t)3;
     }
     t->nparam = o;
-    t->nflat = o + 2 + 2 * 16 + 1;   // + the hinge / focal loss sum
+    t->nflat = o + 2 + 2 * PSEG_MAXC + 1;   // + the hinge / focal loss sum
     PSEG_HIP(hipMalloc((void**)&t->d_grad, (size_t)t->nflat * 4));
     PSEG_HIP(hipMalloc((void**)&t->d_m, (size_t)t->nparam * 4));
     PSEG_HIP(hipMalloc((void**)&t->d_v, (size_t)t->nparam * 4));
@@ -737,7 +737,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     ce_metrics_kernel<<<cdiv((int)npx, 256), 256, 0, st>>>(t->d_logits, t->d_mask, (int)npx, C, 1.0f / (float)npx, t->d_dlogits, acc);
     if (t->loss_kind != PSEG_LOSS_CE)
         loss_grad_kernel<<<cdiv((int)npx, 256), 256, 0, st>>>(t->loss_kind, t->d_logits, t->d_mask, (int)npx, C, 1.0f / (float)npx,
-                                                            acc, t->d_dlogits, acc + 2 + 2 * 16);
+                                                            acc, t->d_dlogits, acc + 2 + 2 * PSEG_MAXC);
     PSEG_HIP(hipGetLastError());
     if (!backward) return PSEG_OK;
 
@@ -904,7 +904,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
 static int train_metrics(Engine& e, float out[4]) {
     TrainState* t = TS(e);
     const int C = e.n_classes;
-    std::vector<float> acc(2 + 2 * 16 + 1);
+    std::vector<float> acc(2 + 2 * PSEG_MAXC + 1);
     PSEG_HIP(hipStreamSynchronize(e.stream));
     PSEG_HIP(hipMemcpy(acc.data(), t->d_grad + t->nparam, acc.size() * 4, hipMemcpyDeviceToHost));
     const double n = (double)t->H * t->W;
@@ -927,9 +927,9 @@ static int train_metrics(Engine& e, float out[4]) {
         }
         out[0] = (float)(l / C * (t->loss_kind == PSEG_LOSS_DICE_CE ? 0.5 : 1.0));
     } else if (t->loss_kind == PSEG_LOSS_HINGE) {
-        out[0] = (float)(acc[2 + 2 * 16] / n);
+        out[0] = (float)(acc[2 + 2 * PSEG_MAXC] / n);
     } else if (t->loss_kind == PSEG_LOSS_FOCAL) {
-        out[0] = (float)(acc[2 + 2 * 16] / n);
+        out[0] = (float)(acc[2 + 2 * PSEG_MAXC] / n);
     }
     return PSEG_OK;
 }
@@ -1053,7 +1053,7 @@ int pseg_train_set_loss(pseg_engine* h, int loss) {
     if (loss < PSEG_LOSS_CE || loss > PSEG_LOSS_DICE_CE) return fail(PSEG_EINVAL, "unknown loss id %d", loss);
     TrainState* t = TS(h->e);
     if (!t) return fail(PSEG_EINVAL, "pseg_train_init has not been called");
-    if (h->e.n_classes > 16) return fail(PSEG_EUNSUPPORTED, "losses other than cross-entropy support at most 16 classes");
+    if (h->e.n_classes > PSEG_MAXC) return fail(PSEG_EUNSUPPORTED, "losses other than cross-entropy support at most %d classes", PSEG_MAXC);
     t->loss_kind = loss;
     return PSEG_OK;
 }

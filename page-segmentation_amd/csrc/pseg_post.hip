@@ -100,19 +100,151 @@ __global__ __launch_bounds__(256) void ccl_cols_kernel(const uint8_t* bin, const
     uf_union(L, p, q);
 }
 
-__global__ void ccl_compress_kernel(int* L, int n) {
+// path compression; with `hist`, the vote's per-root counters (ncls per root) are cleared on the way
+__global__ void ccl_compress_kernel(int* L, int n, int* hist = nullptr, int ncls = 0) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n && L[p] >= 0) L[p] = uf_find(L, p);
+    if (p >= n || L[p] < 0) return;
+    const int r = uf_find(L, p);
+    L[p] = r;
+    if (hist && r == p)
+        for (int c = 0; c < ncls; ++c) hist[(size_t)p * ncls + c] = 0;
+}
+
+// ---- tile-local labelling (default) -------------------------------------------------------------------------
+// A workgroup labels a 16 x 64 pixel tile entirely in LDS -- the same run-based row pass (one wave = one 64-pixel tile
+// row), column unions and path compression as above, on LDS atomics -- and writes each pixel the GLOBAL index of its
+// tile-local root (the raster-first pixel of the component's part inside the tile).  Only pixels on tile borders then
+// need global unions (8 % of the page), followed by the global compress pass.  Roots are still the component's minimum
+// linear index: the raster-first pixel of a component is the raster-first pixel of its tile part, hence a local root.
+constexpr int CT_H = 16, CT_W = 64;
+
+__device__ __forceinline__ int lds_find(const int* lab, int x) {
+    int r = __hip_atomic_load(&lab[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (r != x) { x = r; r = __hip_atomic_load(&lab[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    return x;
+}
+__device__ __forceinline__ void lds_union(int* lab, int a, int b) {
+    while (true) {
+        a = lds_find(lab, a);
+        b = lds_find(lab, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&lab[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* bin, const int64_t* cls, int* L, int H, int W) {
+    __shared__ int lab[CT_H * CT_W];
+    const int tiles_x = (W + CT_W - 1) / CT_W;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = tx * CT_W + lane;
+    // rows wave, wave + 4, ...: row pass (ballot of run starts)
+    bool fgr[CT_H / 4], linkr[CT_H / 4];
+#pragma unroll
+    for (int j = 0; j < CT_H / 4; ++j) {
+        const int r = wave + 4 * j, y = ty * CT_H + r;
+        bool fg = false, link = false;
+        if (y < H && x < W) {
+            const int p = y * W + x;
+            fg = is_fg<MODE>(bin, cls, p);
+            link = fg && lane > 0 && is_fg<MODE>(bin, cls, p - 1) && connects<MODE>(bin, cls, p, p - 1);
+        }
+        const unsigned long long brk = __ballot(!link);
+        const unsigned long long upto = brk & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const int s = 63 - __clzll((long long)upto);             // lane 0 never links: upto != 0
+        lab[r * CT_W + lane] = fg ? r * CT_W + s : -1;
+        fgr[j] = fg; linkr[j] = link;
+    }
+    __syncthreads();
+    // column pass inside the tile (unions only where an overlap of two runs begins)
+#pragma unroll
+    for (int j = 0; j < CT_H / 4; ++j) {
+        const int r = wave + 4 * j, y = ty * CT_H + r;
+        if (!fgr[j] || r == 0) continue;
+        const int p = y * W + x, q = p - W;
+        const int li = r * CT_W + lane;
+        if (!(is_fg<MODE>(bin, cls, q) && connects<MODE>(bin, cls, p, q))) {
+            if (MODE == 2) {
+                if (lane > 0 && !linkr[j] && bin[q - 1] != 0) lds_union(lab, li, li - CT_W - 1);
+                if (lane + 1 < CT_W && x + 1 < W && bin[q + 1] != 0) lds_union(lab, li, li - CT_W + 1);
+            }
+            continue;
+        }
+        if (linkr[j]) {
+            const bool link_up = is_fg<MODE>(bin, cls, q - 1) && connects<MODE>(bin, cls, q, q - 1);
+            const bool up_left = is_fg<MODE>(bin, cls, q - 1) && connects<MODE>(bin, cls, p - 1, q - 1);
+            if (link_up && up_left) continue;
+        }
+        lds_union(lab, li, li - CT_W);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CT_H / 4; ++j) {
+        const int r = wave + 4 * j, y = ty * CT_H + r;
+        if (y >= H || x >= W) continue;
+        int g = -1;
+        if (fgr[j]) {
+            const int root = lds_find(lab, r * CT_W + lane);
+            g = (ty * CT_H + root / CT_W) * W + tx * CT_W + (root % CT_W);
+        }
+        L[y * W + x] = g;
+    }
+}
+
+// unions across tile borders.  Threads exist only for border pixels: the first row of every tile row band but the
+// first (nby * W pixels, joined with the row above) and the first column of every tile column but the first (nbx * H
+// pixels, joined with the pixel to the left; MODE 2 also the two diagonals that cross that vertical border).
+template <int MODE>
+__global__ __launch_bounds__(256) void ccl_border_kernel(const uint8_t* bin, const int64_t* cls, int* L, int H, int W, int nby, int nbx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nby * W) {                                    // horizontal borders
+        const int y = (t / W + 1) * CT_H, x = t % W;
+        const int p = y * W + x, q = p - W;
+        if (!is_fg<MODE>(bin, cls, p)) return;
+        if (is_fg<MODE>(bin, cls, q) && connects<MODE>(bin, cls, p, q)) {
+            // as inside a tile: skip where the left neighbours already join the same two runs (not across a vertical border:
+            // the left link of such a pixel is itself a border union that may not have happened yet -- but it will)
+            uf_union(L, p, q);
+        } else if (MODE == 2) {
+            if (x > 0 && bin[q - 1] != 0) uf_union(L, p, q - 1);
+            if (x + 1 < W && bin[q + 1] != 0) uf_union(L, p, q + 1);
+        }
+        return;
+    }
+    const int u = t - nby * W;
+    if (u >= nbx * H) return;                             // vertical borders
+    const int x = (u / H + 1) * CT_W, y = u % H;
+    const int p = y * W + x;
+    if (!is_fg<MODE>(bin, cls, p)) return;
+    if (is_fg<MODE>(bin, cls, p - 1) && connects<MODE>(bin, cls, p, p - 1)) uf_union(L, p, p - 1);
+    if (MODE == 2) {
+        // up-left diagonal of p (needed when the pixel above p is paper) and, seen from the other side, the up-right
+        // diagonal of the pixel below-left of p (needed when the pixel above THAT one, i.e. left of p, is paper);
+        // rows on a horizontal border are covered by the branch above for the first, here for the second
+        if (y > 0 && (y % CT_H) != 0 && bin[p - W] == 0 && bin[p - W - 1] != 0) uf_union(L, p, p - W - 1);
+        if (y + 1 < H && ((y + 1) % CT_H) != 0 && bin[p - 1] == 0 && bin[p + W - 1] != 0) uf_union(L, p, p + W - 1);
+    }
 }
 
 template <int MODE>
 static int ccl_run(const uint8_t* d_bin, const int64_t* d_cls, int* d_L, int H, int W,
-                   hipStream_t st) {
+                   hipStream_t st, int* d_hist = nullptr, int ncls = 0) {
     const int n = H * W;
     const int grid = cdiv(n, 256);
-    ccl_rows_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
-    ccl_cols_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
-    ccl_compress_kernel<<<grid, 256, 0, st>>>(d_L, n);
+    if (getenv("PSEG_CCL_GLOBAL")) {
+        ccl_rows_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
+        ccl_cols_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
+    } else {
+        ccl_tile_kernel<MODE><<<cdiv(W, CT_W) * cdiv(H, CT_H), 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
+        const int nby = (H - 1) / CT_H, nbx = (W - 1) / CT_W;
+        if (nby * W + nbx * H > 0)
+            ccl_border_kernel<MODE><<<cdiv(nby * W + nbx * H, 256), 256, 0, st>>>(d_bin, d_cls, d_L, H, W, nby, nbx);
+    }
+    ccl_compress_kernel<<<grid, 256, 0, st>>>(d_L, n, d_hist, ncls);
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
 }
@@ -129,8 +261,8 @@ int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hi
 // root), so every counter update that reaches memory is a scattered read-modify-write: the kernel's cost is the
 // NUMBER of global atomics.  A workgroup therefore owns a 32 x 32 pixel tile (a glyph spans one to four tiles
 // instead of thirty row segments), merges its pixels' (root, class) keys in an LDS hash table and flushes one atomic
-// per distinct key.  Only the rows of roots are ever touched: vote_zero_kernel clears exactly those instead of a
-// page-sized memset.
+// per distinct key.  Only the rows of roots are ever touched: the labelling's compress pass clears exactly those
+// instead of a page-sized memset.
 constexpr int VT = 32, VSLOTS = 2048;
 __global__ __launch_bounds__(256) void vote_count_kernel(const int* L, const int64_t* pred, int* hist, int H, int W, int ncls) {
     __shared__ int keys[VSLOTS];
@@ -169,31 +301,20 @@ __global__ __launch_bounds__(256) void vote_count_kernel(const int* L, const int
         if (keys[i] >= 0) atomicAdd(&hist[keys[i]], vals[i]);
 }
 
-// clears the histogram rows of the roots (the only rows vote_count_kernel adds to and vote_winner_kernel reads)
-__global__ void vote_zero_kernel(const int* L, int* hist, int n, int ncls) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n || L[p] != p) return;
-    int* h = hist + (size_t)p * ncls;
-    for (int c = 0; c < ncls; ++c) h[c] = 0;
-}
-
-// The root pixel of every component reduces its histogram: np.argmax(bins[1:]) = lowest class
-// among the most frequent (lib/postprocess.py:22-23).  The winner overwrites slot 0.
-__global__ void vote_winner_kernel(const int* L, int* hist, int n, int ncls) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n || L[p] != p) return;
-    int* h = hist + (size_t)p * ncls;
-    int best = 0, bv = h[0];
-    for (int c = 1; c < ncls; ++c)
-        if (h[c] > bv) { bv = h[c]; best = c; }
-    h[0] = best;
-}
-
+// Every ink pixel reads its component's counters (a few cache lines per component) and takes
+// np.argmax(bins) = the lowest class among the most frequent (lib/postprocess.py:22-23).
 __global__ void vote_apply_kernel(const int* L, const int* hist, int64_t* pred, int n, int ncls) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int r = L[p];
-    if (r >= 0) pred[p] = hist[(size_t)r * ncls];
+    if (r < 0) return;
+    const int* h = hist + (size_t)r * ncls;
+    int best = 0, bv = h[0];
+    for (int c = 1; c < ncls; ++c) {
+        const int v = h[c];
+        if (v > bv) { bv = v; best = c; }
+    }
+    pred[p] = best;
 }
 
 static int cc_vote_device(int64_t* d_pred, const uint8_t* d_bin, int H, int W, int ncls,
@@ -221,12 +342,10 @@ static int cc_vote_device(int64_t* d_pred, const uint8_t* d_bin, int H, int W, i
     int* d_L = (int*)need(0, (size_t)n * 4);
     int* d_hist = (int*)need(1, (size_t)n * ncls * 4);
     if (!d_L || !d_hist) return fail(PSEG_ENOMEM, "hipMalloc(vote workspace) failed");
-    int rc = ccl_run<0>(d_bin, nullptr, d_L, H, W, st);
+    int rc = ccl_run<0>(d_bin, nullptr, d_L, H, W, st, d_hist, ncls);     // the compress pass clears the roots' counters
     if (rc == PSEG_OK) {
         const int grid = cdiv(n, 256);
-        vote_zero_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, n, ncls);
         vote_count_kernel<<<cdiv(W, VT) * cdiv(H, VT), 256, 0, st>>>(d_L, d_pred, d_hist, H, W, ncls);
-        vote_winner_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, n, ncls);
         vote_apply_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, d_pred, n, ncls);
         if (hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "vote kernel launch failed");
     }

@@ -2143,10 +2143,12 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 3, 2, 6, MODE_CONV, 0)            // res_unet encoder: stride-2 shortcut conv
     PSEG_TRY_INST(4, 4, 3, 2, 6, MODE_CONV, FL_INRELU)    // res_unet encoder: stride-2 first conv of the block
     PSEG_TRY_INST(4, 5, 1, 1, 10, MODE_DECONV, 0)         // deconv2
-    PSEG_TRY_INST(4, 4, 1, 1, 14, MODE_DECONV, 0)         // deconv4 (fcn_skip), two N blocks
+    if (a.nb_loop == 2) { PSEG_TRY_INST(4, 4, 1, 1, 14, MODE_DECONV, 0) }   // deconv4 (fcn_skip): this instance walks two N blocks per workgroup (NBL = 2)
     PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_DECONV, 0)          // deconv4 (fcn)
-    PSEG_TRY_INST(4, 4, 1, 1, 10, MODE_TAIL, 0)           // deconv5 + logits (fcn_skip)
-    PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_TAIL, 0)            // deconv5 + logits (fcn)
+    if (a.nb_loop == 2) {                                 // the tail instances walk two N blocks per workgroup too
+        PSEG_TRY_INST(4, 4, 1, 1, 10, MODE_TAIL, 0)       // deconv5 + logits (fcn_skip)
+        PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_TAIL, 0)        // deconv5 + logits (fcn)
+    }
 #undef PSEG_TRY_INST
     if (getenv("PSEG_LOG_GENERIC"))
         fprintf(stderr, "[pseg] generic instance: MT %d NT %d KS %d stride %d sigma %d mode %d flags %d\n", P.MT, P.NT, ks, P.stride, sg, mode, fl);

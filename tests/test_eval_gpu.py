@@ -125,3 +125,26 @@ def test_full_page_counts_consistency(gpu):
     first = np.full(n, lab.size, np.int64)                              # numbering = raster order of first pixels
     np.minimum.at(first, lab.ravel(), np.arange(lab.size))
     assert (np.diff(first[1:]) > 0).all()
+
+
+def test_cc_label_random_shapes_and_densities(gpu):
+    """Tile-local labelling + border unions (16 x 64 tiles): shapes around the tile sizes and ink densities from
+    isolated specks to percolating blobs, both connectivities, against the scipy restatement (same numbering)."""
+    rng = np.random.default_rng(123)
+    shapes = [(15, 63), (16, 64), (17, 65), (31, 129), (48, 200), (100, 64), (33, 300), (130, 70)]
+    for (H, W) in shapes:
+        for dens in (0.05, 0.35, 0.5, 0.62, 0.9):
+            b = (rng.random((H, W)) < dens).astype(np.uint8)
+            for conn in (4, 8):
+                n, lab = gpu.cc_label(b, conn)
+                wn, wl, _, _ = O.connected_components_with_stats(b, conn)
+                assert n == wn and np.array_equal(lab, wl), (H, W, dens, conn)
+    # long thin structures crossing many tiles: a spiral and a comb
+    b = np.zeros((70, 200), np.uint8)
+    b[::2, :] = 1
+    b[1::4, -1] = 1
+    b[3::4, 0] = 1                                             # one serpentine component
+    for conn in (4, 8):
+        n, lab = gpu.cc_label(b, conn)
+        wn, wl, _, _ = O.connected_components_with_stats(b, conn)
+        assert n == wn == 2 and np.array_equal(lab, wl)

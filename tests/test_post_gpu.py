@@ -90,3 +90,16 @@ def test_post_process_call_sequences(gpu, oracle_mod):
     for k in rng.integers(0, len(cases), 25):
         pred, binary, C, want = cases[int(k)]
         assert np.array_equal(gpu.cc_vote(pred.copy(), binary, C), want)
+
+
+def test_cc_vote_random_shapes_densities_and_class_counts(gpu, oracle_mod):
+    """The vote's tile-merged counters (32 x 32 tiles, LDS hash table) and the tile-local labelling (16 x 64) on shapes
+    around the tile sizes, densities from specks to one percolating component, 2 .. 40 classes, noisy predictions."""
+    rng = np.random.default_rng(99)
+    for (H, W) in [(31, 33), (32, 32), (33, 65), (64, 129), (100, 100), (17, 300)]:
+        for dens, C in [(0.1, 2), (0.45, 3), (0.6, 7), (0.95, 40)]:
+            binary = (rng.random((H, W)) < dens).astype(np.uint8)
+            pred = rng.integers(0, C, size=(H, W)).astype(np.int64)          # every pixel its own class: many keys per tile
+            want = oracle_mod.vote_connected_component_class(pred, binary)
+            got = gpu.cc_vote(pred.copy(), binary, C)
+            assert np.array_equal(got, want), (H, W, dens, C)

@@ -1,6 +1,7 @@
-"""Loss / Monitor enums (reference: lib/metrics.py:115-141).  The loss and metric arithmetic
-itself (mean sparse softmax cross-entropy, accuracy, jaccard, dice; lib/metrics.py:8-17,60-85)
-belongs to the engine's train step (a later SURVEY 8 row)."""
+"""Loss / Monitor enums (reference: lib/metrics.py:115-141).  The loss and metric arithmetic itself (the six
+losses of lib/metrics.py:8-112, accuracy, jaccard, dice) runs in the engine's train step (pseg_train_set_loss,
+pseg_train_forward_backward); a Loss member called like the reference's (`loss_func()`) yields the name the
+engine is configured with."""
 import enum
 
 

@@ -110,7 +110,7 @@ int pseg_timing_get(pseg_engine* e, int slot, char* name, size_t name_cap, doubl
 
 /* ---- Train: lib/network.py:90-104,167-246 (compile + fit), lib/metrics.py:8-17,60-85 ------- */
 
-/* Training state of a PSEG_MODE_F32_EXACT engine (fcn / fcn_skip): Keras-formulation Adam
+/* Training state of a PSEG_MODE_F32_EXACT engine (all four graphs, up to 64 classes): Keras-formulation Adam
  * (lib/architecture.py:83; beta1 .9, beta2 .999, eps 1e-7 are Keras' defaults) with per-tensor
  * clip-by-norm (`clipnorm`, lib/network.py:97; <= 0 disables) and optional clip-by-value. */
 int pseg_train_init(pseg_engine* e, float beta1, float beta2, float eps, float clipnorm,

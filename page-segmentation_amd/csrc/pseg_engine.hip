@@ -358,6 +358,7 @@ int set_canvas(Engine& e, int H, int W, hipStream_t st) {
     for (auto& op : e.ops) {
         if (op.fuse1 >= 0) e.slots[op.timing_slot].flops += e.ops[op.fuse1].flops_per_canvas_px * px;
         if (op.tail_logits >= 0) e.slots[op.timing_slot].flops += e.ops[op.tail_logits].flops_per_canvas_px * px;
+        if (op.into_tail >= 0) e.slots[e.ops[op.into_tail].timing_slot].flops += op.flops_per_canvas_px * px;
     }
     return PSEG_OK;
 }

@@ -1074,6 +1074,164 @@ __global__ __launch_bounds__(256) void tail_composed_kernel(TailC a) {
 
 
 // ---------------------------------------------------------------------------------------------
+// Composed tail with the preceding transposed conv inside (fcn_skip: deconv4 -> [concat conv3] -> deconv5 o logits).
+// deconv4 (k2 s2, ReLU) maps a quarter-resolution pixel q to four half-resolution pixels; its 30-channel output is
+// read by nothing but this tail, so it is recomputed here and never stored: a wave takes 16 half-resolution pixels
+// of ONE sub-pixel parity (hx = x0 + 2 p16 + b, a = hy & 1), so that they share one weight matrix Wd4[ab] and the
+// GEMM d4[co][pixel] = Wd4[ab] . [deconv3 ; conv5](q) is four k-steps of two MFMAs.  +bias, ReLU and the bf16
+// rounding happen in registers; the two accumulator tiles are then the B operand of the composed deconv5 o logits
+// GEMM (k = 8g+j <-> channel 4g+j / 16+4g+(j-4)), followed by conv3's 40 channels from memory and the skip logits
+// conv2 left in the S buffer.  No LDS.  Reads per full-resolution pixel: 16 (S) + 20 (conv3) + ~7 (quarter-res) bytes.
+// ---------------------------------------------------------------------------------------------
+struct Tail2 {
+    const uint16_t* q0; const uint16_t* q1; int nq0, nq1;   // quarter-resolution sources of the inner deconv (chunks per pixel)
+    const uint16_t* c3; int nc3;                            // half-resolution concat source of the outer deconv
+    const float* S;                                         // skip logits [full-res canvas pixel][CP]
+    int Hh, Wh, H0, W0, C;
+    const uint16_t* wQ;            // inner deconv A fragments [ab][tile 2][k-step 4][64][8]
+    const float* biasQ;            // [32]
+    const uint16_t* wD;            // composed kernel, inner-deconv channels [tile][64][8]
+    const uint16_t* wC;            // composed kernel, c3 channels [tile][k-step 2][64][8]
+    const float* beta;
+    float* out_logits; float* out_probs; int64_t* out_labels; uint8_t* out_labels_u8;
+};
+
+constexpr int T2_ITER = 4;   // 16-pixel tiles a wave walks with one set of weight fragments in registers
+
+template <int CP>
+__global__ __launch_bounds__(256) void tail_fused2_kernel(Tail2 a) {
+    constexpr int NTL = CP / 4;
+    const int lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tiles_x = (a.Wh + 31) >> 5, groups_x = (tiles_x + T2_ITER - 1) / T2_ITER;
+    const int b = wv & 1, tl = wv >> 1;
+    const int hy = tl / groups_x;
+    if (hy >= a.Hh) return;
+    const int xt0 = (tl - hy * groups_x) * T2_ITER;
+    const int ab = (hy & 1) * 2 + b;
+    // the weight fragments of this wave's sub-pixel stay in registers for all of its tiles (they were 11 of the 18
+    // loads per tile: the kernel is bound by load issue, not by the 11 MFMAs)
+    bf16x8 wq[4][2], wd[NTL], wc[NTL][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wq[s][t] = *(const bf16x8*)(a.wQ + ((size_t)((ab * 2 + t) * 4 + s) * 64 + lane) * 8);
+    float4 bq[2], bt[NTL];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bq[t] = *(const float4*)(a.biasQ + t * 16 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        wd[t] = *(const bf16x8*)(a.wD + ((size_t)t * 64 + lane) * 8);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wc[t][s] = *(const bf16x8*)(a.wC + ((size_t)(t * 2 + s) * 64 + lane) * 8);
+        bt[t] = *(const float4*)(a.beta + t * 16 + 4 * g);
+    }
+    const int C = a.C;
+#pragma unroll 1
+    for (int it = 0; it < T2_ITER; ++it) {
+        const int x0 = (xt0 + it) * 32;
+        if (x0 >= a.Wh) break;
+        const int hxr = x0 + 2 * p16 + b;
+        const bool inx = hxr < a.Wh;
+        const int hx = inx ? hxr : a.Wh - 1;                 // clamp: loads stay in bounds, stores are masked
+        const size_t qpx = (size_t)(hy >> 1) * (a.Wh >> 1) + (hx >> 1);
+        const size_t hpx = (size_t)hy * a.Wh + hx;
+        // ---- all loads first ----
+        uint4 xq[4], xc[2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ch = 4 * s + g;
+            xq[s] = make_uint4(0, 0, 0, 0);
+            if (ch < a.nq0) xq[s] = *(const uint4*)(a.q0 + (qpx * a.nq0 + ch) * 8);
+            else if (ch < a.nq0 + a.nq1) xq[s] = *(const uint4*)(a.q1 + (qpx * a.nq1 + (ch - a.nq0)) * 8);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ch = 4 * s + g;
+            xc[s] = ch < a.nc3 ? *(const uint4*)(a.c3 + (hpx * a.nc3 + ch) * 8) : make_uint4(0, 0, 0, 0);
+        }
+        f32x4 acc[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const int row0 = 16 * t + 4 * g, abo = row0 / CP, c0 = row0 - abo * CP;
+            const size_t px = (size_t)(2 * hy + (abo >> 1)) * (2 * a.Wh) + 2 * hx + (abo & 1);
+            const float4 sv = *(const float4*)(a.S + px * CP + c0);
+            acc[t] = f32x4{bt[t].x + sv.x, bt[t].y + sv.y, bt[t].z + sv.z, bt[t].w + sv.w};
+        }
+        // ---- inner deconv: d4[co][pixel] for this wave's sub-pixel ----
+        f32x4 d4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                d4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[s][t], __builtin_bit_cast(bf16x8, xq[s]), d4[t], 0, 0, 0);
+        uint32_t pk[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            pk[t][0] = pk_bf16(vmax(d4[t][0] + bq[t].x, 0.f), vmax(d4[t][1] + bq[t].y, 0.f));
+            pk[t][1] = pk_bf16(vmax(d4[t][2] + bq[t].z, 0.f), vmax(d4[t][3] + bq[t].w, 0.f));
+        }
+        const uint4 xd = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+        // ---- composed deconv5 o logits ----
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[t], __builtin_bit_cast(bf16x8, xd), acc[t], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t][s], __builtin_bit_cast(bf16x8, xc[s]), acc[t], 0, 0, 0);
+        }
+        // ---- per pixel: classes live in CP/4 lane groups (as tail_composed_kernel) ----
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const int row0 = 16 * t + 4 * g;
+            const int abo = row0 / CP, c0 = row0 - abo * CP;
+            const int y = 2 * hy + (abo >> 1), x = 2 * hx + (abo & 1);
+            const bool inb = inx && y < a.H0 && x < a.W0;
+            float bv = -3.4e38f;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool take = (c0 + r < C) & (acc[t][r] > bv);
+                bv = take ? acc[t][r] : bv;
+                bi = take ? c0 + r : bi;
+            }
+            if constexpr (CP > 4) {
+#pragma unroll
+                for (int sh = 16; sh < 4 * CP; sh <<= 1) {
+                    const float ov = __shfl_xor(bv, sh);
+                    const int oi = __shfl_xor(bi, sh);
+                    const bool take = (ov > bv) | ((ov == bv) & (oi < bi));
+                    bv = take ? ov : bv;
+                    bi = take ? oi : bi;
+                }
+            }
+            const size_t p = (size_t)y * a.W0 + x;
+            if (inb && c0 == 0) {
+                if (a.out_labels_u8) a.out_labels_u8[p] = (uint8_t)bi;
+                if (a.out_labels) a.out_labels[p] = bi;
+            }
+            if (a.out_logits && inb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < C) a.out_logits[p * C + c0 + r] = acc[t][r];
+            if (a.out_probs) {
+                float ex[4], sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ex[r] = (c0 + r < C) ? expf(acc[t][r] - bv) : 0.f; sum += ex[r]; }
+                if constexpr (CP > 4) {
+#pragma unroll
+                    for (int sh = 16; sh < 4 * CP; sh <<= 1) sum += __shfl_xor(sum, sh);
+                }
+                if (inb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c0 + r < C) a.out_probs[p * C + c0 + r] = ex[r] / sum;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stand-alone logits layer (1x1 conv -> softmax / argmax) for graphs whose tail does not fuse
 // (unet, res_unet): one MFMA GEMM per 16 pixels, rows = classes, K = channels; every B fragment is
 // one coalesced 16-byte load per lane (no LDS).  HBM-bound: reads the last activation once.
@@ -1476,6 +1634,11 @@ struct MfmaPlan {
     bool nw8_ok = false;        // an 8-wave kernel instance exists for this layer shape
     bool nw8_resident = false;  // ... and its whole weight set stays resident beside the 16-row tile
     int cmax = 4;
+    uint16_t* d_q_w = nullptr;     // into_tail deconv: A fragments [ab][2][4][64][8] and bias[32] for tail_fused2_kernel
+    float* d_q_bias = nullptr;
+    uint16_t* d_t2_wD = nullptr;   // composed tail with the inner deconv: composed kernel fragments
+    uint16_t* d_t2_wC = nullptr;
+    bool tail2 = false;
     float* d_skiplog = nullptr;    // skip-logits buffer [canvas pixel][skip_CP] (op.skiplog >= 0), grown with the canvas
     size_t skiplog_bytes = 0;
     int skip_CP = 0;
@@ -1491,6 +1654,7 @@ void mfma_free_op(Op& op) {
     (void)hipFree(p->d_tc_wA1); (void)hipFree(p->d_tc_wA2); (void)hipFree(p->d_tc_beta);
     upsplit_free(p->upsplit);
     (void)hipFree(p->d_skiplog);
+    (void)hipFree(p->d_q_w); (void)hipFree(p->d_q_bias); (void)hipFree(p->d_t2_wD); (void)hipFree(p->d_t2_wC);
     delete p;
     op.plan = nullptr;
 }
@@ -1593,6 +1757,20 @@ int mfma_plan_graph(Engine& e) {
             if (nks0 != 3) continue;                                    // the composed-tail instances that take the buffer
             cv.skiplog = dc.tail_logits;
             e.tensors[cv.dst].fused = true;
+            // ... and the transposed conv in front of that tail (fcn_skip: deconv4, ReLU), whose output nothing else reads,
+            // is computed inside the tail kernel (tail_fused2_kernel) instead of being stored and read back
+            if (getenv("PSEG_NO_TAIL2") || dc.src1 < 0 || e.tensors[dc.src1].Cs > 64) continue;
+            const int di = producer_of(e, dc.src0);
+            if (di < 0) continue;
+            Op& dq = e.ops[di];
+            if (dq.type != OP_DECONV2 || !dq.relu || dq.Cout > 32 || dq.tail_logits >= 0 || dq.into_tail >= 0) continue;
+            if ((e.tensors[dq.src0].Cs + (dq.src1 >= 0 ? e.tensors[dq.src1].Cs : 0)) / 8 > 16) continue;
+            int du = 0;
+            for (auto& o : e.ops) du += (o.src0 == dq.dst) + (o.src1 == dq.dst) + (o.add == dq.dst);
+            if (du != 1) continue;
+            dq.into_tail = (int)(&dc - e.ops.data());
+            dq.fused_away = true;
+            e.tensors[dq.dst].fused = true;
         }
     return PSEG_OK;
 }
@@ -1937,6 +2115,28 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         else { const int ab = n / P->CoP, co = n % P->CoP; if (ab < 4 && co < Cout) bb[n] = bias[co]; }
     }
     PSEG_TRY(upload(&P->d_bias, bb));
+    if (deconv && op.into_tail >= 0) {
+        // this transposed conv runs inside the composed tail: A fragments [ab][cout tile 2][k-step 4][lane = (cout & 15, g)][8],
+        // element j <-> storage channel (4s + g) * 8 + j of the concatenated quarter-resolution sources
+        std::vector<uint16_t> wq((size_t)4 * 2 * 4 * 64 * 8, 0);
+        for (int ab = 0; ab < 4; ++ab)
+            for (int t = 0; t < 2; ++t)
+                for (int sidx = 0; sidx < 4; ++sidx)
+                    for (int l = 0; l < 64; ++l) {
+                        const int co = t * 16 + (l & 15), chunk = 4 * sidx + (l >> 4);
+                        if (co >= Cout) continue;
+                        for (int j = 0; j < 8; ++j) {
+                            const int cs = chunk * 8 + j;
+                            if (cs >= Cs0 + Cs1) continue;
+                            const int ci = true_ci(cs);
+                            if (ci >= 0) wq[((((size_t)ab * 2 + t) * 4 + sidx) * 64 + l) * 8 + j] = f2bf(w[((size_t)ab * Cin + ci) * Cout + co]);
+                        }
+                    }
+        std::vector<float> bq(32, 0.0f);
+        for (int c = 0; c < Cout; ++c) bq[c] = bias[c];
+        PSEG_TRY(upload(&P->d_q_w, wq));
+        PSEG_TRY(upload(&P->d_q_bias, bq));
+    }
     if (!deconv && op.skiplog >= 0) {
         // skip-logits fusion: the logits kernel rows of this layer's channels (they follow the deconv channels in the
         // concat, Keras (1,1,Cdec+Cout,C): w[(Cdec + co)*C + c]) as ONE A fragment: lane l = (class = l & 15, g = l >> 4),
@@ -2061,6 +2261,29 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
             PSEG_TRY(upload(&P->d_tc_wA2, a2));
             PSEG_TRY(upload(&P->d_tc_beta, beta));
             P->tc_CP = CP; P->tc_nks0 = nks0; P->tc_nkss = nkss;
+            const int dqi = producer_of(e, op.src0);
+            if (dqi >= 0 && e.ops[dqi].into_tail >= 0 && skip_in_buffer && s1) {
+                // the same composed kernel M in the operand order of tail_fused2_kernel: the inner deconv's channels arrive as
+                // two accumulator tiles (lane group g, element j <-> channel j < 4 ? 4g + j : 16 + 4g + (j - 4)), the concat
+                // source as storage chunks 4s + g
+                std::vector<uint16_t> wd((size_t)NTL * 64 * 8, 0), wc((size_t)NTL * 2 * 64 * 8, 0);
+                for (int t = 0; t < NTL; ++t)
+                    for (int l = 0; l < 64; ++l) {
+                        const int row = 16 * t + (l & 15), ab = row / CP, cls = row % CP, gg = l >> 4;
+                        if (cls >= C) continue;
+                        for (int j = 0; j < 8; ++j) {
+                            const int ch = j < 4 ? 4 * gg + j : 16 + 4 * gg + (j - 4);
+                            if (ch < C0) wd[((size_t)t * 64 + l) * 8 + j] = f2bf((float)M[((size_t)ab * C + cls) * Cin + ch]);
+                            for (int sidx = 0; sidx < 2; ++sidx) {
+                                const int cc = (4 * sidx + gg) * 8 + j;
+                                if (cc < C1) wc[(((size_t)t * 2 + sidx) * 64 + l) * 8 + j] = f2bf((float)M[((size_t)ab * C + cls) * Cin + C0 + cc]);
+                            }
+                        }
+                    }
+                PSEG_TRY(upload(&P->d_t2_wD, wd));
+                PSEG_TRY(upload(&P->d_t2_wC, wc));
+                P->tail2 = true;
+            }
         }
     }
     return PSEG_OK;
@@ -2388,6 +2611,25 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
             }
             t.out_logits = e.cur_logits; t.out_probs = e.cur_probs; t.out_labels = e.cur_labels; t.out_labels_u8 = e.cur_labels_u8;
             if (t.Wh % 16) return fail(PSEG_EINVAL, "composed tail needs a canvas width multiple of 32");
+            if (P->tail2) {
+                const Op& dq = e.ops[producer_of(e, op.src0)];
+                auto* PQ = (MfmaPlan*)dq.plan;
+                if (!PQ || !PQ->d_q_w || !t.S || (P->tc_CP != 4 && P->tc_CP != 8)) return fail(PSEG_EINVAL, "fused inner deconv: plan data missing");
+                Tail2 u{};
+                const Tensor& q0 = e.tensors[dq.src0];
+                u.q0 = (const uint16_t*)q0.d; u.nq0 = q0.Cs / 8;
+                u.q1 = dq.src1 >= 0 ? (const uint16_t*)e.tensors[dq.src1].d : nullptr;
+                u.nq1 = dq.src1 >= 0 ? e.tensors[dq.src1].Cs / 8 : 0;
+                u.c3 = t.src1; u.nc3 = t.nch1;
+                u.S = t.S; u.Hh = t.Hh; u.Wh = t.Wh; u.H0 = t.H0; u.W0 = t.W0; u.C = t.C;
+                u.wQ = PQ->d_q_w; u.biasQ = PQ->d_q_bias; u.wD = P->d_t2_wD; u.wC = P->d_t2_wC; u.beta = P->d_tc_beta;
+                u.out_logits = t.out_logits; u.out_probs = t.out_probs; u.out_labels = t.out_labels; u.out_labels_u8 = t.out_labels_u8;
+                const int nwaves = t.Hh * cdiv((t.Wh + 31) / 32, T2_ITER) * 2;
+                if (P->tc_CP == 4) tail_fused2_kernel<4><<<cdiv(nwaves, 4), 256, 0, st>>>(u);
+                else tail_fused2_kernel<8><<<cdiv(nwaves, 4), 256, 0, st>>>(u);
+                PSEG_HIP(hipGetLastError());
+                return PSEG_OK;
+            }
             const int waves = t.Hh * (t.Wh / 16);
             const dim3 grid(cdiv(waves, 4));
             const int key = P->tc_CP * 100 + P->tc_nks0 * 10 + P->tc_nkss;

@@ -12,6 +12,7 @@ LAYER_OF = [  # kernel-name fragment -> layer key used by bench.py's timing slot
     ("conv_mfma_kernel<8, 2, 5, 1, 3, 0, 353", "conv2d_1"),
     ("conv_mfma_kernel<8, 2, 5, 1, 3, 0, 289", "conv2d_1"),
     ("tail_composed_kernel", "conv2d_transpose_4"),
+    ("tail_fused2_kernel", "conv2d_transpose_4"),
 ]
 
 

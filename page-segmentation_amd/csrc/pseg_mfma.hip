@@ -1958,9 +1958,9 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     // (the fused conv1+conv2 kernel was also tried with 8-row tiles -- 136 registers, 42 KB, three workgroups per
     // CU: 182 vs 164 us; the halo recompute of conv1 grows from 1.41x to 1.69x and the weights stream twice as often)
     if (getenv("PSEG_MT")) P->MT = atoi(getenv("PSEG_MT")) == 8 && NT <= 2 ? 8 : 4;
-    // the 1/8-resolution k5 layers (conv7, deconv1) have 192 eight-row tiles on a 2048x1536 page for 256 CUs: four-row
-    // tiles (one row per wave) give 384 workgroups, two per CU on half the chip, whose phases overlap
-    if (!deconv && KS == 5 && NT == 5 && op.stride == 1 && e.tensors[op.dst].s >= 3 && !s1 && getenv("PSEG_MT2")) P->MT = 2;
+    // (the 1/8-resolution k5 layers -- conv7, deconv1: 192 eight-row tiles for 256 CUs on a 2048x1536 page -- were tried
+    // with four-row tiles (384 workgroups: 28.0 -> 26.3 and 33.3 -> 31.0 us) and with two N blocks of 3 + 2 cout tiles
+    // (no change): two workgroups sharing a CU gain little over one here, not worth the extra instances)
     P->KS = KS;
     P->stride = deconv ? 1 : op.stride;
     // 8-wave workgroups (16-row tiles, the whole CU's LDS) exist for the k5 stride-1 mid-layer shapes
@@ -2347,7 +2347,6 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, 0)            // conv5
     PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, FL_POOL)      // conv6
     PSEG_TRY_INST(4, 5, 5, 1, 6, MODE_CONV, 0)            // conv7, deconv1
-    PSEG_TRY_INST(2, 5, 5, 1, 6, MODE_CONV, 0)            // conv7, deconv1 with four-row tiles (PSEG_MT2)
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, 0)            // unet: k3 convs (64..1024 channels, 32-channel blocks)
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, FL_POOL)      // unet: k3 conv + fused pool
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, 0)            // unet: dense tile, three workgroups per CU

@@ -141,6 +141,12 @@ def main():
                 "flop_per_launch": flops,
                 "whole_net_frac": round(eng.flops_per_pixel() * H * W / (total_ms * 1e-3) / 1e12 / peak, 5),
                 "per_kernel_ms": {s[0]: round(s[1] / s[2], 5) for s in slots}}
+        # the 3x3 conv stack on its own (north_star names it for unet): layers whose kernel is 3x3, without the
+        # Cin = 1 first layer (a write stream, not MFMA work)
+        ksize = {n.split("/")[0]: sh[0] for n, sh in eng.weight_specs() if n.endswith("kernel")}
+        k3 = [s for s in slots if ksize.get(s[0]) == 3 and s[3] > 1e10]
+        if k3:
+            roof["conv3x3_stack_frac"] = round(sum(s[3] for s in k3) / (sum(s[1] / s[2] for s in k3) * 1e-3) / 1e12 / peak, 5)
 
     # ---- CPU baseline: the oracle (port of the reference semantics) on this host ---------------
     cpu = None

@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) void tail_fused2_kernel(Tail2 a) {
         for (int t = 0; t < NTL; ++t) {
             const int row0 = 16 * t + 4 * g, abo = row0 / CP, c0 = row0 - abo * CP;
             const size_t px = (size_t)(2 * hy + (abo >> 1)) * (2 * a.Wh) + 2 * hx + (abo & 1);
-            const float4 sv = *(const float4*)(a.S + px * CP + c0);
+            const float4 sv = a.S ? *(const float4*)(a.S + px * CP + c0) : make_float4(0.f, 0.f, 0.f, 0.f);   // fcn: no skip
             acc[t] = f32x4{bt[t].x + sv.x, bt[t].y + sv.y, bt[t].z + sv.z, bt[t].w + sv.w};
         }
         // ---- inner deconv: d4[co][pixel] for this wave's sub-pixel ----
@@ -1772,6 +1772,23 @@ int mfma_plan_graph(Engine& e) {
             dq.fused_away = true;
             e.tensors[dq.dst].fused = true;
         }
+    // the same inner-deconv fusion for a tail without skips (fcn: deconv4 -> deconv5 o logits)
+    if (!getenv("PSEG_NO_TAIL2") && !getenv("PSEG_NO_TAIL_COMPOSE") && !getenv("PSEG_NO_TAIL_FUSION") && !getenv("PSEG_GENERIC") && e.n_classes <= 8)
+        for (auto& dc : e.ops) {
+            if (dc.type != OP_DECONV2 || dc.tail_logits < 0 || dc.relu || dc.src1 >= 0 || e.ops[dc.tail_logits].src1 >= 0) continue;
+            if (e.tensors[dc.src0].Cs != 32) continue;
+            const int di = producer_of(e, dc.src0);
+            if (di < 0) continue;
+            Op& dq = e.ops[di];
+            if (dq.type != OP_DECONV2 || !dq.relu || dq.Cout > 32 || dq.tail_logits >= 0 || dq.into_tail >= 0) continue;
+            if ((e.tensors[dq.src0].Cs + (dq.src1 >= 0 ? e.tensors[dq.src1].Cs : 0)) / 8 > 16) continue;
+            int du = 0;
+            for (auto& o : e.ops) du += (o.src0 == dq.dst) + (o.src1 == dq.dst) + (o.add == dq.dst);
+            if (du != 1) continue;
+            dq.into_tail = (int)(&dc - e.ops.data());
+            dq.fused_away = true;
+            e.tensors[dq.dst].fused = true;
+        }
     return PSEG_OK;
 }
 
@@ -2262,7 +2279,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
             PSEG_TRY(upload(&P->d_tc_beta, beta));
             P->tc_CP = CP; P->tc_nks0 = nks0; P->tc_nkss = nkss;
             const int dqi = producer_of(e, op.src0);
-            if (dqi >= 0 && e.ops[dqi].into_tail >= 0 && skip_in_buffer && s1) {
+            if (dqi >= 0 && e.ops[dqi].into_tail >= 0 && ((skip_in_buffer && s1) || (lg.src1 < 0 && !s1))) {
                 // the same composed kernel M in the operand order of tail_fused2_kernel: the inner deconv's channels arrive as
                 // two accumulator tiles (lane group g, element j <-> channel j < 4 ? 4g + j : 16 + 4g + (j - 4)), the concat
                 // source as storage chunks 4s + g
@@ -2613,7 +2630,7 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
             if (P->tail2) {
                 const Op& dq = e.ops[producer_of(e, op.src0)];
                 auto* PQ = (MfmaPlan*)dq.plan;
-                if (!PQ || !PQ->d_q_w || !t.S || (P->tc_CP != 4 && P->tc_CP != 8)) return fail(PSEG_EINVAL, "fused inner deconv: plan data missing");
+                if (!PQ || !PQ->d_q_w || (!t.S && lg.src1 >= 0) || (P->tc_CP != 4 && P->tc_CP != 8)) return fail(PSEG_EINVAL, "fused inner deconv: plan data missing");
                 Tail2 u{};
                 const Tensor& q0 = e.tensors[dq.src0];
                 u.q0 = (const uint16_t*)q0.d; u.nq0 = q0.Cs / 8;

@@ -221,3 +221,29 @@ def test_bf16_inner_deconv_inside_the_tail(gpu, oracle_mod, monkeypatch, arch, C
     assert np.abs(z1 - z0).max() <= 2e-3 * max(1.0, np.abs(z0).max())
     assert np.mean(np.abs(z1 - z0) > 1e-5 * max(1.0, np.abs(z0).max())) < 0.02
     assert _check_labels(l1, z1, z0)[0] == 0 and np.array_equal(l1, np.argmax(z1, -1))
+
+
+def test_bf16_fused_paths_random_page_sizes(gpu, oracle_mod, monkeypatch):
+    """The default fcn_skip engine (skip logits from conv2, deconv4 inside the tail, pool-only stores dropped, XCD tile
+    order) against an engine with all of that switched off, on page sizes that exercise every tile edge."""
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 1), (1, 65), (31, 33), (32, 32), (33, 31), (47, 129), (64, 64), (65, 97), (100, 7), (129, 200), (200, 45)]
+    for C in (3, 6):
+        Wt = oracle_mod.init_weights("fcn_skip", C, seed=C, gain=1.5, bias_scale=0.05)
+        imgs = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in shapes]
+        fused = gpu.Engine("fcn_skip", C, mode=gpu.MODE_BF16)
+        fused.set_weights(Wt)
+        outs = [fused.predict(im, want_probs=False) for im in imgs]
+        fused.close()
+        for k in ("PSEG_NO_TAIL2", "PSEG_NO_SKIPLOG", "PSEG_NO_POOL_ONLY", "PSEG_NO_XCD"):
+            monkeypatch.setenv(k, "1")
+        plain = gpu.Engine("fcn_skip", C, mode=gpu.MODE_BF16)
+        plain.set_weights(Wt)
+        for im, (z1, _, l1) in zip(imgs, outs):
+            z0, _, l0 = plain.predict(im, want_probs=False)
+            assert z1.shape == z0.shape == im.shape + (C,)
+            assert np.abs(z1 - z0).max() <= 2e-3 * max(1.0, np.abs(z0).max()), im.shape
+            assert _check_labels(l1, z1, z0)[0] == 0 and np.array_equal(l1, np.argmax(z1, -1)), im.shape
+        plain.close()
+        for k in ("PSEG_NO_TAIL2", "PSEG_NO_SKIPLOG", "PSEG_NO_POOL_ONLY", "PSEG_NO_XCD"):
+            monkeypatch.delenv(k)

@@ -90,10 +90,44 @@ int pseg_predict_device(pseg_engine* e, const uint8_t* d_img, int H, int W, floa
 int pseg_predict_batch(pseg_engine* e, int n_pages, const uint8_t* const* imgs, const int* H,
                        const int* W, int64_t* const* labels, uint8_t* const* labels_u8);
 
+/* Label-exact throughput mode (lib/network.py:259: argmax of the float32 logits).  A bf16 engine's label map differs
+ * from the float32 engine's only at near-ties of the two largest logits.  pseg_predict_margin_device runs the graph
+ * and also writes the margin map (float32 (H,W): top-1 minus top-2 logit; labels_u8 optional).
+ * pseg_predict_exact_labels_device returns the float32 engine's label map: bf16 pass + margin, then the 64x64 blocks
+ * that hold a pixel with margin < tau are re-evaluated, with their receptive-field halo, by a float32 companion
+ * engine (bit-exact referee, same weights).  tau = 4 x the bf16 path's measured logit error on a calibration crop
+ * and doubles whenever a refereed block shows a flipped pixel above it; pages whose flagged blocks cover most of the
+ * area go through the float32 engine whole.  Synchronises `stream` internally (the flag map is read by the host).
+ * d_labels (int64) and d_margin are optional outputs.  pseg_label_exact_stats: {tau, calibration logit error,
+ * flagged pixel fraction, refereed block fraction, refereed area (with halos) / page area, tau escalations,
+ * whole-page fallback (0/1), labels changed by the referee} of the last call. */
+int pseg_predict_margin_device(pseg_engine* e, const uint8_t* d_img, int H, int W, uint8_t* d_labels_u8,
+                               float* d_margin, void* stream);
+int pseg_predict_exact_labels_device(pseg_engine* e, const uint8_t* d_img, int H, int W, uint8_t* d_labels_u8,
+                                     int64_t* d_labels, float* d_margin, void* stream);
+/* Host-buffer form (Network.predict_single_data's `pred`, lib/network.py:259): either output may be NULL, not both. */
+int pseg_predict_exact_labels(pseg_engine* e, const uint8_t* img, int H, int W, int64_t* labels, uint8_t* labels_u8);
+int pseg_label_exact_stats(const pseg_engine* e, double out[8]);
+
+/* Page-locked host memory for the host-buffer entries ("uint8 page in pinned host memory -> label
+ * map in host memory").  Pages and label maps that live in buffers from pseg_host_alloc, or in caller memory
+ * registered with pseg_host_register, move by DMA straight between the caller's buffer and HBM, overlapped with
+ * compute; any other (pageable) buffer is staged through the engine's two-slot pinned ring by the calling thread.
+ * The reference keeps pages in NumPy arrays (lib/dataset.py:18-29); the Python shim offers pinned_empty(). */
+int pseg_host_alloc(void** p, size_t bytes);
+int pseg_host_free(void* p);
+int pseg_host_register(void* p, size_t bytes);
+int pseg_host_unregister(void* p);
+
 /* Copy an intermediate activation to the host as float32 NHWC (true channel count) --
  * layer-by-layer parity tests.  `layer` is the Keras layer name.  dims[3] = {H,W,C} of the
  * padded canvas at that layer.  Valid after a predict call. */
 int pseg_get_activation(pseg_engine* e, const char* layer, float* out, int64_t cap, int dims[3]);
+
+/* The engine's own hipStream_t (what NULL stream arguments mean; the train step always runs on it): lets a caller
+ * order its own work -- e.g. the data-parallel gradient all-reduce -- against the engine's kernels without
+ * synchronising the device. */
+void* pseg_engine_stream(pseg_engine* e);
 
 /* Algorithmic forward FLOPs per canvas pixel (2 per MAC, true channel counts): the figure
  * SURVEY.md 8(d) quotes (113 700 for fcn_skip C=3). */
@@ -168,11 +202,17 @@ int pseg_eval_step(pseg_engine* e, const uint8_t* img, const uint8_t* mask, int 
  * `binary` (non-zero = ink); each takes its most frequent class in pred (ties -> lowest).
  * pred int64 (H,W) is updated in place, as the reference does. Host pointers. */
 int pseg_cc_vote(int device, int64_t* pred, const uint8_t* binary, int H, int W, int n_classes);
-/* Device variant: asynchronous on `stream`.  The label / histogram workspace is cached per calling thread
- * and device and reused by the next call in stream order: issue the calls of one thread on one stream (or
- * synchronise between streams). */
+/* Device variant: asynchronous on `stream`.  The label / histogram workspace is cached per device; calls from
+ * different streams or threads are ordered against each other by an event (pseg_release_workspace frees it). */
 int pseg_cc_vote_device(int device, int64_t* d_pred, const uint8_t* d_binary, int H, int W,
                         int n_classes, void* stream);
+
+/* The same vote on the compact uint8 label map pseg_predict_device emits (n_classes <= 256): 4 instead of 25
+ * algorithmic bytes per pixel; widen to int64 only at the host boundary. */
+int pseg_cc_vote_device_u8(int device, uint8_t* d_pred, const uint8_t* d_binary, int H, int W,
+                           int n_classes, void* stream);
+/* Frees the device workspace the vote entries cache per device (waits for its last user). */
+int pseg_release_workspace(int device);
 
 /* add_bounding_boxes (lib/postprocess.py:29-42): every 4-connected component of each class
  * paints its bounding box; higher classes overwrite lower. out may alias nothing. */
@@ -186,6 +226,12 @@ int pseg_masks(int device, const int64_t* pred, const uint8_t* binary, const uin
 int pseg_masks_device(int device, const int64_t* d_pred, const uint8_t* d_binary,
                       const uint8_t* d_lut, int n_lut, int H, int W, uint8_t* d_color,
                       uint8_t* d_overlay, uint8_t* d_inverted, uint8_t* d_fg_color, void* stream);
+
+/* generate_output_masks on the compact uint8 label map (14 instead of 21 algorithmic bytes per pixel); d_pred and
+ * d_binary must be 4-byte aligned. */
+int pseg_masks_device_u8(int device, const uint8_t* d_pred, const uint8_t* d_binary,
+                         const uint8_t* d_lut, int n_lut, int H, int W, uint8_t* d_color,
+                         uint8_t* d_overlay, uint8_t* d_inverted, uint8_t* d_fg_color, void* stream);
 
 /* compute_char_height (lib/image_ops.py:58-82) minus the file read: Otsu threshold, invert
  * unless `inverse`, 4-connected components, keep glyph-shaped ones, upper median of heights.

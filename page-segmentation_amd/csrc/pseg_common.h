@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,33 @@ int fail(int code, const char* fmt, ...);
         int _rc = (expr);                                                                      \
         if (_rc != PSEG_OK) return _rc;                                                        \
     } while (0)
+
+// Developer knobs (PSEG_* environment variables: ablation switches, alternative kernel choices).  A release build
+// snapshots the PSEG_* part of the environment when an engine is created (pseg_create) and answers every knob query
+// from that snapshot -- a kernel launch costs no getenv(), and a stray change of the environment cannot alter a
+// running engine; each call site caches its answer per snapshot generation.  The diagnostic build (libpseg_diag.so:
+// tools/trace_layers.py flips knobs between launches) reads the environment every time.
+#ifndef PSEG_DIAG
+#define PSEG_DIAG 0
+#endif
+unsigned knob_generation();                 // current snapshot number (>= 1)
+const char* knob_lookup(const char* name);  // value in the current snapshot, or nullptr
+void knobs_refresh();                       // take a new snapshot (pseg_create)
+#if PSEG_DIAG
+#define PSEG_KNOB(name) getenv(name)
+#else
+#define PSEG_KNOB(name)                                                                                   \
+    ([]() -> const char* {                                                                                \
+        static unsigned gen_ = 0;                                                                         \
+        static const char* v_ = nullptr;                                                                  \
+        const unsigned g_ = ::pseg::knob_generation();                                                    \
+        if (__atomic_load_n(&gen_, __ATOMIC_ACQUIRE) != g_) {                                             \
+            __atomic_store_n(&v_, ::pseg::knob_lookup(name), __ATOMIC_RELAXED);                           \
+            __atomic_store_n(&gen_, g_, __ATOMIC_RELEASE);                                                \
+        }                                                                                                 \
+        return __atomic_load_n(&v_, __ATOMIC_RELAXED);                                                    \
+    }())
+#endif
 
 constexpr int PSEG_MAXC = 64;   // classes the train-step metric slots and the wide bf16 logits kernel are sized for
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -117,12 +145,15 @@ struct Engine {
     // canvas
     int H = 0, W = 0, Hp = 0, Wp = 0;
     bool weights_dirty = true;
+    bool exact_dirty = true;       // label-exact mode: the float32 companion's weights / the calibrated threshold are stale
     float* d_lut = nullptr;        // 256-entry u/255 table (f32)
     const uint8_t* cur_img = nullptr;  // bf16 mode: the uint8 page of the running predict call
     float* cur_logits = nullptr;       // bf16 mode: output pointers of the running predict call
     float* cur_probs = nullptr;
     int64_t* cur_labels = nullptr;
     uint8_t* cur_labels_u8 = nullptr;
+    float* cur_margin = nullptr;       // bf16 mode: top-1 minus top-2 logit map requested by the running call (label-exact mode)
+    bool margin_done = false;          // ... and whether the tail kernel of the graph wrote it (else it is derived from the logits)
     float* d_logits_tmp = nullptr; // H*W*C f32 when the caller does not want logits
     size_t logits_tmp_bytes = 0;
     uint8_t* d_img_stage = nullptr;
@@ -132,6 +163,7 @@ struct Engine {
     float* d_logit_stage = nullptr;
     size_t lab_stage_bytes = 0, prob_stage_bytes = 0, logit_stage_bytes = 0;
     void* train = nullptr;   // TrainState (pseg_train.hip), f32 mode only
+    void* exact = nullptr;   // ExactState (pseg_exactlabels.hip): float32 companion engine, margin / flag buffers of the label-exact mode
     void* batch = nullptr;   // BatchState (pseg_predict_batch): copy streams, events, two staging slots
     int relaxed_f32 = 0;     // != 0 during a train / eval step: wide float32 layers may run channel-blocked on the matrix cores
     uint32_t drop_key = 0;   // != 0 while a TRAINING forward runs: Dropout layers are live (key = seed / step mix)
@@ -174,6 +206,12 @@ int upsplit_launch(UpSplit* u, const uint16_t* src, int Hs, int Ws, uint16_t* ds
 void launch_dropout(float* x, size_t n, uint32_t key, float rate, hipStream_t st);
 int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hipStream_t st);   // pseg_post.hip
 int upload_weights(Engine& e);
+// one page through the engine's graph, device buffers, asynchronous on `st` (every output optional)
+int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* d_logits, float* d_probs, int64_t* d_labels,
+                   uint8_t* d_labels_u8, hipStream_t st, float* d_margin);
+void launch_margin_from_logits(const float* d_logits, size_t n, int C, float* d_margin, hipStream_t st);
+bool mfma_tail_emits_margin(const Engine& e);   // the bf16 graph's tail kernel writes the margin map itself
+void exact_free(Engine& e);                     // label-exact mode state (pseg_exactlabels.hip)
 int set_canvas(Engine& e, int H, int W, hipStream_t st);
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs, int64_t* d_labels,
               uint8_t* d_labels_u8, hipStream_t st);

@@ -7,6 +7,8 @@
 // This mode is the parity referee; the throughput mode lives in pseg_mfma.hip.
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "pseg_common.h"
 
@@ -17,6 +19,44 @@ int build_graph(Engine& e);
 std::string& last_error() {
     thread_local std::string msg;
     return msg;
+}
+
+// ---- knob snapshots (see pseg_common.h) -------------------------------------------------------------------------
+namespace {
+std::mutex g_knob_mu;
+std::vector<std::map<std::string, std::string>*> g_knob_snaps;   // every snapshot stays alive: call sites may hold pointers into it
+unsigned g_knob_gen = 0;
+extern "C" char** environ;
+void knobs_snapshot_locked() {
+    auto* m = new std::map<std::string, std::string>();
+    for (char** ep = environ; ep && *ep; ++ep) {
+        if (strncmp(*ep, "PSEG_", 5) != 0) continue;
+        const char* eq = strchr(*ep, '=');
+        if (eq) (*m)[std::string(*ep, eq - *ep)] = std::string(eq + 1);
+    }
+    g_knob_snaps.push_back(m);
+    __atomic_store_n(&g_knob_gen, g_knob_gen + 1, __ATOMIC_RELEASE);
+}
+}  // namespace
+unsigned knob_generation() {
+    unsigned g = __atomic_load_n(&g_knob_gen, __ATOMIC_ACQUIRE);
+    if (g == 0) {
+        std::lock_guard<std::mutex> lk(g_knob_mu);
+        if (g_knob_gen == 0) knobs_snapshot_locked();
+        g = g_knob_gen;
+    }
+    return g;
+}
+const char* knob_lookup(const char* name) {
+    (void)knob_generation();
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    const auto& m = *g_knob_snaps.back();
+    auto it = m.find(name);
+    return it == m.end() ? nullptr : it->second.c_str();
+}
+void knobs_refresh() {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    knobs_snapshot_locked();
 }
 
 int fail(int code, const char* fmt, ...) {
@@ -209,6 +249,23 @@ __global__ void softmax_argmax_kernel(const float* logits, size_t n, int C, floa
             for (int c = 0; c < C; ++c) probs[p * C + c] = expf(z[c] - bv) / s;
         }
     }
+}
+
+// top-1 minus top-2 logit per pixel (the quantity the label-exact mode thresholds); C == 1 gives +inf
+__global__ void margin_from_logits_kernel(const float* logits, size_t n, int C, float* margin) {
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const float* z = logits + p * C;
+        float bv = z[0], sv = -3.4e38f;
+        for (int c = 1; c < C; ++c) {
+            const float v = z[c];
+            if (v > bv) { sv = bv; bv = v; }
+            else if (v > sv) sv = v;
+        }
+        margin[p] = C > 1 ? bv - sv : __builtin_inff();
+    }
+}
+void launch_margin_from_logits(const float* d_logits, size_t n, int C, float* d_margin, hipStream_t st) {
+    margin_from_logits_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(d_logits, n, C, d_margin);
 }
 
 // =============================================================================================
@@ -510,8 +567,15 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
 }
 
 static int run_bf16(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
-                    int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st) {
+                    int64_t* d_labels, uint8_t* d_labels_u8, float* d_margin, hipStream_t st) {
     PSEG_TRY(mfma_preprocess(e, d_img, st));
+    e.cur_margin = d_margin;
+    e.margin_done = false;
+    if (d_margin && !d_logits && !mfma_tail_emits_margin(e)) {
+        // this graph's tail kernel has no margin output: take the float32 logits and derive the margin from them
+        PSEG_TRY(ensure((void**)&e.d_logits_tmp, &e.logits_tmp_bytes, (size_t)e.H * e.W * e.n_classes * sizeof(float)));
+        d_logits = e.d_logits_tmp;
+    }
     e.cur_logits = d_logits;
     e.cur_probs = d_probs;
     e.cur_labels = d_labels;
@@ -531,20 +595,31 @@ static int run_bf16(Engine& e, const uint8_t* d_img, float* d_logits, float* d_p
         PSEG_HIP(hipGetLastError());
         PSEG_TRY(time_end(e, op, st, ev0));
     }
+    if (d_margin && !e.margin_done) {
+        if (!d_logits) return fail(PSEG_EINVAL, "margin map requested but neither the tail kernel nor a logits buffer provides it");
+        launch_margin_from_logits(d_logits, (size_t)e.H * e.W, e.n_classes, d_margin, st);
+    }
+    e.cur_margin = nullptr;
     return PSEG_OK;
 }
 
-static int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* d_logits,
-                          float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8,
-                          hipStream_t st) {
+int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* d_logits,
+                   float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8,
+                   hipStream_t st, float* d_margin) {
     PSEG_HIP(hipSetDevice(e.device));
     for (auto& p : e.params)
         if (!p.set) return fail(PSEG_EINVAL, "weight '%s' was never set", p.name.c_str());
     if (e.weights_dirty) PSEG_TRY(upload_weights(e));
     PSEG_TRY(set_canvas(e, H, W, st));
     if (e.mode == PSEG_MODE_BF16)
-        return run_bf16(e, d_img, d_logits, d_probs, d_labels, d_labels_u8, st);
-    return run_exact(e, d_img, d_logits, d_probs, d_labels, d_labels_u8, st);
+        return run_bf16(e, d_img, d_logits, d_probs, d_labels, d_labels_u8, d_margin, st);
+    if (d_margin && !d_logits) {
+        PSEG_TRY(ensure((void**)&e.d_logits_tmp, &e.logits_tmp_bytes, (size_t)H * W * e.n_classes * sizeof(float)));
+        d_logits = e.d_logits_tmp;
+    }
+    PSEG_TRY(run_exact(e, d_img, d_logits, d_probs, d_labels, d_labels_u8, st));
+    if (d_margin) launch_margin_from_logits(d_logits, (size_t)H * W, e.n_classes, d_margin, st);
+    return PSEG_OK;
 }
 
 // ---- page batches: copies of neighbouring pages overlap the compute of the current one -----------
@@ -554,7 +629,30 @@ struct BatchState {
     uint8_t* d_img[2] = {nullptr, nullptr};
     void* d_lab[2] = {nullptr, nullptr};
     size_t img_bytes[2] = {0, 0}, lab_bytes[2] = {0, 0};
+    // pinned staging ring for callers whose pages / label maps live in pageable memory: the page is copied into the
+    // slot by the calling thread and leaves it by DMA; label maps arrive in the slot by DMA and are copied out by the
+    // calling thread while the next page computes.  Buffers from pseg_host_alloc / pseg_host_register skip the ring.
+    uint8_t* h_in[2] = {nullptr, nullptr};
+    uint8_t* h_out[2] = {nullptr, nullptr};
+    size_t h_in_bytes[2] = {0, 0}, h_out_bytes[2] = {0, 0};
 };
+
+static int ensure_pinned(uint8_t** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p) return PSEG_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    PSEG_HIP(hipHostMalloc((void**)p, bytes, hipHostMallocDefault));
+    *cap = bytes;
+    return PSEG_OK;
+}
+
+// true when `p` is page-locked host memory the runtime knows (hipHostMalloc / hipHostRegister): DMA goes straight to it
+static bool is_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
 
 static void batch_free(Engine& e) {
     auto* b = (BatchState*)e.batch;
@@ -565,6 +663,8 @@ static void batch_free(Engine& e) {
         if (b->down[i]) (void)hipEventDestroy(b->down[i]);
         free_dev((void*&)b->d_img[i]);
         free_dev(b->d_lab[i]);
+        if (b->h_in[i]) (void)hipHostFree(b->h_in[i]);
+        if (b->h_out[i]) (void)hipHostFree(b->h_out[i]);
     }
     if (b->s_in) (void)hipStreamDestroy(b->s_in);
     if (b->s_out) (void)hipStreamDestroy(b->s_out);
@@ -587,14 +687,30 @@ static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int
         }
     }
     auto* b = (BatchState*)e.batch;
-    const size_t lab_esz = labels ? 8 : 1;
+    for (int i = 0; i < n; ++i) {
+        if (H[i] <= 0 || W[i] <= 0 || !imgs[i] || (labels && !labels[i]) || (labels_u8 && !labels_u8[i]))
+            return fail(PSEG_EINVAL, "page %d: empty shape or NULL buffer", i);
+    }
+    std::vector<char> in_pinned(n), out_pinned(n);
+    for (int i = 0; i < n; ++i) {
+        in_pinned[i] = is_pinned(imgs[i]);
+        out_pinned[i] = (!labels || is_pinned(labels[i])) && (!labels_u8 || is_pinned(labels_u8[i]));
+    }
     auto upload = [&](int i) -> int {        // page i -> slot i % 2 (its previous compute has been waited for)
         const int s = i & 1;
         const size_t npx = (size_t)H[i] * W[i];
         PSEG_TRY(ensure((void**)&b->d_img[s], &b->img_bytes[s], npx * e.in_ch));
         PSEG_TRY(ensure(&b->d_lab[s], &b->lab_bytes[s], npx * (labels ? 8 : 0) + npx * (labels_u8 ? 1 : 0) + 16));
         PSEG_HIP(hipStreamWaitEvent(b->s_in, b->done[s], 0));      // slot input consumed (no-op before first record)
-        PSEG_HIP(hipMemcpyAsync(b->d_img[s], imgs[i], npx * e.in_ch, hipMemcpyHostToDevice, b->s_in));
+        const uint8_t* src = imgs[i];
+        if (!in_pinned[i]) {
+            // the ring slot was last read by the upload of page i-2, recorded in up[s]
+            PSEG_HIP(hipEventSynchronize(b->up[s]));
+            PSEG_TRY(ensure_pinned(&b->h_in[s], &b->h_in_bytes[s], npx * e.in_ch));
+            memcpy(b->h_in[s], imgs[i], npx * e.in_ch);
+            src = b->h_in[s];
+        }
+        PSEG_HIP(hipMemcpyAsync(b->d_img[s], src, npx * e.in_ch, hipMemcpyHostToDevice, b->s_in));
         PSEG_HIP(hipEventRecord(b->up[s], b->s_in));
         return PSEG_OK;
     };
@@ -607,7 +723,7 @@ static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int
         PSEG_HIP(hipStreamWaitEvent(e.stream, b->down[s], 0));      // slot output of page i-2 has left
         int64_t* dl = labels ? (int64_t*)b->d_lab[s] : nullptr;
         uint8_t* du = labels_u8 ? (uint8_t*)b->d_lab[s] + (labels ? npx * 8 : 0) : nullptr;
-        PSEG_TRY(predict_device(e, b->d_img[s], H[i], W[i], nullptr, nullptr, dl, du, e.stream));
+        PSEG_TRY(predict_device(e, b->d_img[s], H[i], W[i], nullptr, nullptr, dl, du, e.stream, nullptr));
         PSEG_HIP(hipEventRecord(b->done[s], e.stream));
         return PSEG_OK;
     };
@@ -615,29 +731,49 @@ static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int
         const int s = i & 1;
         const size_t npx = (size_t)H[i] * W[i];
         PSEG_HIP(hipStreamWaitEvent(b->s_out, b->done[s], 0));
-        if (labels) PSEG_HIP(hipMemcpyAsync(labels[i], b->d_lab[s], npx * 8, hipMemcpyDeviceToHost, b->s_out));
-        if (labels_u8)
-            PSEG_HIP(hipMemcpyAsync(labels_u8[i], (uint8_t*)b->d_lab[s] + (labels ? npx * 8 : 0), npx, hipMemcpyDeviceToHost, b->s_out));
+        if (out_pinned[i]) {
+            if (labels) PSEG_HIP(hipMemcpyAsync(labels[i], b->d_lab[s], npx * 8, hipMemcpyDeviceToHost, b->s_out));
+            if (labels_u8)
+                PSEG_HIP(hipMemcpyAsync(labels_u8[i], (uint8_t*)b->d_lab[s] + (labels ? npx * 8 : 0), npx, hipMemcpyDeviceToHost, b->s_out));
+        } else {   // both maps in one DMA into the ring slot (its previous content was copied out by finish(i - 2))
+            const size_t nb = npx * (labels ? 8 : 0) + npx * (labels_u8 ? 1 : 0);
+            PSEG_TRY(ensure_pinned(&b->h_out[s], &b->h_out_bytes[s], nb));
+            PSEG_HIP(hipMemcpyAsync(b->h_out[s], b->d_lab[s], nb, hipMemcpyDeviceToHost, b->s_out));
+        }
         PSEG_HIP(hipEventRecord(b->down[s], b->s_out));
         return PSEG_OK;
     };
-    (void)lab_esz;
+    auto finish = [&](int i) -> int {        // pageable destination: ring slot -> caller's arrays, on the calling thread
+        if (out_pinned[i]) return PSEG_OK;
+        const int s = i & 1;
+        const size_t npx = (size_t)H[i] * W[i];
+        PSEG_HIP(hipEventSynchronize(b->down[s]));
+        if (labels) memcpy(labels[i], b->h_out[s], npx * 8);
+        if (labels_u8) memcpy(labels_u8[i], b->h_out[s] + (labels ? npx * 8 : 0), npx);
+        return PSEG_OK;
+    };
     // a reallocation of a slot must not race with work still using it: drain when sizes grow
-    for (int i = 0; i < n; ++i) {
-        if (H[i] <= 0 || W[i] <= 0 || !imgs[i] || (labels && !labels[i]) || (labels_u8 && !labels_u8[i]))
-            return fail(PSEG_EINVAL, "page %d: empty shape or NULL buffer", i);
-    }
     size_t max_px = 0;
     for (int i = 0; i < n; ++i) max_px = std::max(max_px, (size_t)H[i] * W[i]);
     for (int s = 0; s < 2; ++s) {
         PSEG_TRY(ensure((void**)&b->d_img[s], &b->img_bytes[s], max_px * e.in_ch));
         PSEG_TRY(ensure(&b->d_lab[s], &b->lab_bytes[s], max_px * 9 + 16));
     }
+    bool any_in = false, any_out = false;
+    for (int i = 0; i < n; ++i) { any_in |= !in_pinned[i]; any_out |= !out_pinned[i]; }
+    for (int s = 0; s < 2 && (any_in || any_out); ++s) {
+        PSEG_HIP(hipEventSynchronize(b->up[s]));
+        PSEG_HIP(hipEventSynchronize(b->down[s]));
+        if (any_in) PSEG_TRY(ensure_pinned(&b->h_in[s], &b->h_in_bytes[s], max_px * e.in_ch));
+        if (any_out) PSEG_TRY(ensure_pinned(&b->h_out[s], &b->h_out_bytes[s], max_px * ((labels ? 8 : 0) + (labels_u8 ? 1 : 0))));
+    }
     if (n > 0) { PSEG_TRY(upload(0)); PSEG_TRY(compute(0)); }
     for (int i = 0; i < n; ++i) {
         if (i + 1 < n) { PSEG_TRY(upload(i + 1)); PSEG_TRY(compute(i + 1)); }
         PSEG_TRY(download(i));
+        if (i > 0) PSEG_TRY(finish(i - 1));
     }
+    if (n > 0) PSEG_TRY(finish(n - 1));
     PSEG_HIP(hipStreamSynchronize(b->s_out));
     PSEG_HIP(hipStreamSynchronize(e.stream));
     return PSEG_OK;
@@ -675,6 +811,7 @@ int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
         return fail(PSEG_EHIP, "no HIP device visible: libpseg has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(PSEG_EINVAL, "device %d of %d", device, ndev);
     PSEG_HIP(hipSetDevice(device));
+    knobs_refresh();   // the PSEG_* developer knobs are read here, once per engine creation, never per launch
     auto* h = new pseg_engine();
     Engine& e = h->e;
     e.arch = arch;
@@ -707,6 +844,7 @@ int pseg_destroy(pseg_engine* h) {
     (void)hipSetDevice(e.device);
     if (e.stream) (void)hipStreamSynchronize(e.stream);
     train_free(e);
+    exact_free(e);
     batch_free(e);
     for (auto& t : e.tensors) free_dev(t.d);
     for (auto& op : e.ops) {
@@ -762,6 +900,7 @@ int pseg_set_weights(pseg_engine* h, const char* name, const float* data, const 
     std::copy(data, data + p->host.size(), p->host.begin());
     p->set = true;
     h->e.weights_dirty = true;
+    h->e.exact_dirty = true;
     return PSEG_OK;
 }
 
@@ -779,7 +918,7 @@ int pseg_predict_device(pseg_engine* h, const uint8_t* d_img, int H, int W, floa
                         float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8, void* stream) {
     if (!h || !d_img) return fail(PSEG_EINVAL, "NULL argument");
     hipStream_t st = stream ? (hipStream_t)stream : h->e.stream;
-    return predict_device(h->e, d_img, H, W, d_logits, d_probs, d_labels, d_labels_u8, st);
+    return predict_device(h->e, d_img, H, W, d_logits, d_probs, d_labels, d_labels_u8, st, nullptr);
 }
 
 int pseg_predict(pseg_engine* h, const uint8_t* img, int H, int W, float* logits, float* probs,
@@ -796,7 +935,7 @@ int pseg_predict(pseg_engine* h, const uint8_t* img, int H, int W, float* logits
     PSEG_HIP(hipMemcpyAsync(e.d_img_stage, img, npx * e.in_ch, hipMemcpyHostToDevice, e.stream));
     PSEG_TRY(predict_device(e, e.d_img_stage, H, W, logits ? e.d_logit_stage : nullptr,
                             probs ? e.d_prob_stage : nullptr, labels ? e.d_lab_stage : nullptr,
-                            nullptr, e.stream));
+                            nullptr, e.stream, nullptr));
     if (logits) PSEG_HIP(hipMemcpyAsync(logits, e.d_logit_stage, npx * C * 4, hipMemcpyDeviceToHost, e.stream));
     if (probs) PSEG_HIP(hipMemcpyAsync(probs, e.d_prob_stage, npx * C * 4, hipMemcpyDeviceToHost, e.stream));
     if (labels) PSEG_HIP(hipMemcpyAsync(labels, e.d_lab_stage, npx * 8, hipMemcpyDeviceToHost, e.stream));
@@ -809,6 +948,32 @@ int pseg_predict_batch(pseg_engine* h, int n_pages, const uint8_t* const* imgs, 
     if (!h || n_pages < 0 || (n_pages > 0 && (!imgs || !H || !W))) return fail(PSEG_EINVAL, "bad argument");
     if (!labels && !labels_u8) return fail(PSEG_EINVAL, "no output requested");
     return predict_batch(h->e, n_pages, imgs, H, W, labels, labels_u8);
+}
+
+int pseg_host_alloc(void** p, size_t bytes) {
+    if (!p) return fail(PSEG_EINVAL, "NULL argument");
+    *p = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(PSEG_EHIP, "no HIP device visible: libpseg has no CPU fallback");
+    PSEG_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+    return PSEG_OK;
+}
+
+int pseg_host_free(void* p) {
+    if (p) PSEG_HIP(hipHostFree(p));
+    return PSEG_OK;
+}
+
+int pseg_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return fail(PSEG_EINVAL, "NULL / empty buffer");
+    PSEG_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return PSEG_OK;
+}
+
+int pseg_host_unregister(void* p) {
+    if (p) PSEG_HIP(hipHostUnregister(p));
+    return PSEG_OK;
 }
 
 // bf16 -> f32 helper for activation read-back
@@ -845,6 +1010,8 @@ int pseg_get_activation(pseg_engine* h, const char* layer, float* out, int64_t c
     }
     return fail(PSEG_ENOTFOUND, "no layer named '%s'", layer);
 }
+
+void* pseg_engine_stream(pseg_engine* h) { return h ? (void*)h->e.stream : nullptr; }
 
 double pseg_flops_per_pixel(const pseg_engine* h) {
     if (!h) return 0;

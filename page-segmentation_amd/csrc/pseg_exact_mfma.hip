@@ -219,7 +219,7 @@ static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, int CB, dim3 g
 // Returns 1 when the layer was launched on the MFMA kernel, 0 when it does not fit (caller falls
 // back to the scalar kernel), < 0 on error.
 int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st) {
-    if (getenv("PSEG_EXACT_SCALAR")) return 0;
+    if (PSEG_KNOB("PSEG_EXACT_SCALAR")) return 0;
     const int Cin = a.C0 + a.C1;
     if (Cin < 1 || a.Cout < 1 || a.KH != a.KW) return 0;
     const int Ntot = a.deconv4 ? 4 * a.Cout : a.Cout;
@@ -235,7 +235,7 @@ int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st) {
     auto lds_of = [&](int mt) { return (size_t)((4 * (mt / 2) - 1) * a.stride + a.KH) * TWH * Cp * 4; };
     const size_t l4 = lds_of(4), l2 = lds_of(2);
     int CB = Cin;
-    if (l4 <= budget && (160 * 1024 / l4 >= 2 || l2 > budget || 160 * 1024 / l2 < 2 || getenv("PSEG_EXACT_MT4"))) MT = 4;
+    if (l4 <= budget && (160 * 1024 / l4 >= 2 || l2 > budget || 160 * 1024 / l2 < 2 || PSEG_KNOB("PSEG_EXACT_MT4"))) MT = 4;
     else if (l2 <= budget) MT = 2;
     if (!MT && a.relaxed && !flat) {
         // the caller tolerates another summation order (train step): blocks of channels whose 4-row tile fits twice per CU

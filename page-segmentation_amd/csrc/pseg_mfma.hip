@@ -121,6 +121,36 @@ __device__ __forceinline__ float lane_xor1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
 
+// Top-2 of a pixel's logits.  A lane holds four of them (classes c0 + r, r = 0..3; classes >= C do not count) and the
+// other classes of the pixel sit in the lanes lane ^ 16 / lane ^ 32 when NG > 1 lane groups share a pixel.  bv / bi =
+// maximum and its class (first maximum wins, as np.argmax), sv = the runner-up's value (== bv on an exact tie): the
+// margin bv - sv is what the label-exact mode thresholds (lib/network.py:259; DESIGN.md "label-exact mode").
+template <int NG>
+__device__ __forceinline__ void top2_classes(const f32x4 z, int c0, int C, float& bv, int& bi, float& sv) {
+    bv = -3.4e38f; sv = -3.4e38f; bi = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool ok = c0 + r < C;
+        const float v = z[r];
+        const bool take = ok & (v > bv);
+        sv = take ? bv : ((ok & (v > sv)) ? v : sv);
+        bv = take ? v : bv;
+        bi = take ? c0 + r : bi;
+    }
+    if constexpr (NG > 1) {
+#pragma unroll
+        for (int sh = 16; sh < 16 * NG; sh <<= 1) {
+            const float ov = __shfl_xor(bv, sh), os = __shfl_xor(sv, sh);
+            const int oi = __shfl_xor(bi, sh);
+            const bool take = (ov > bv) | ((ov == bv) & (oi < bi));
+            const float lose = take ? bv : ov;
+            sv = fmaxf(fmaxf(sv, os), lose);
+            bv = take ? ov : bv;
+            bi = take ? oi : bi;
+        }
+    }
+}
+
 __device__ __forceinline__ uint4 relu_bf16x8(uint4 v) {
     auto f = [](uint32_t w) -> uint32_t {
         if (w & 0x8000u) w &= 0xffff0000u;
@@ -957,6 +987,7 @@ struct TailC {
     const float* beta;             // [NTL*16]
     const float* S;                // skip-logits buffer [full-res canvas pixel][CP] written by the skip producer, or null
     float* out_logits; float* out_probs; int64_t* out_labels; uint8_t* out_labels_u8;
+    float* out_margin;             // top-1 minus top-2 logit per pixel, or null
 };
 
 template <int CP, int NKS0, int NKSS>
@@ -1029,28 +1060,14 @@ __global__ __launch_bounds__(256) void tail_composed_kernel(TailC a) {
         const int ab = row0 / CP, c0 = row0 - ab * CP;
         const int y = 2 * hy + (ab >> 1), x = 2 * hx + (ab & 1);
         const bool inb = y < a.H0 && x < a.W0;
-        float bv = -3.4e38f;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool take = (c0 + r < C) & (acc[t][r] > bv);
-            bv = take ? acc[t][r] : bv;
-            bi = take ? c0 + r : bi;
-        }
-        if constexpr (CP > 4) {
-#pragma unroll
-            for (int sh = 16; sh < 4 * CP; sh <<= 1) {
-                const float ov = __shfl_xor(bv, sh);
-                const int oi = __shfl_xor(bi, sh);
-                const bool take = (ov > bv) | ((ov == bv) & (oi < bi));
-                bv = take ? ov : bv;
-                bi = take ? oi : bi;
-            }
-        }
+        float bv, sv;
+        int bi;
+        top2_classes<CP / 4>(acc[t], c0, C, bv, bi, sv);
         const size_t p = (size_t)y * a.W0 + x;
         if (inb && c0 == 0) {
             if (a.out_labels_u8) a.out_labels_u8[p] = (uint8_t)bi;
             if (a.out_labels) a.out_labels[p] = bi;
+            if (a.out_margin) a.out_margin[p] = bv - sv;
         }
         if (a.out_logits && inb)
 #pragma unroll
@@ -1094,6 +1111,7 @@ struct Tail2 {
     const uint16_t* wC;            // composed kernel, c3 channels [tile][k-step 2][64][8]
     const float* beta;
     float* out_logits; float* out_probs; int64_t* out_labels; uint8_t* out_labels_u8;
+    float* out_margin;
 };
 
 constexpr int T2_ITER = 4;   // 16-pixel tiles a wave walks with one set of weight fragments in registers
@@ -1187,28 +1205,14 @@ __global__ __launch_bounds__(256) void tail_fused2_kernel(Tail2 a) {
             const int abo = row0 / CP, c0 = row0 - abo * CP;
             const int y = 2 * hy + (abo >> 1), x = 2 * hx + (abo & 1);
             const bool inb = inx && y < a.H0 && x < a.W0;
-            float bv = -3.4e38f;
-            int bi = 0x7fffffff;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool take = (c0 + r < C) & (acc[t][r] > bv);
-                bv = take ? acc[t][r] : bv;
-                bi = take ? c0 + r : bi;
-            }
-            if constexpr (CP > 4) {
-#pragma unroll
-                for (int sh = 16; sh < 4 * CP; sh <<= 1) {
-                    const float ov = __shfl_xor(bv, sh);
-                    const int oi = __shfl_xor(bi, sh);
-                    const bool take = (ov > bv) | ((ov == bv) & (oi < bi));
-                    bv = take ? ov : bv;
-                    bi = take ? oi : bi;
-                }
-            }
+            float bv, sv;
+            int bi;
+            top2_classes<CP / 4>(acc[t], c0, C, bv, bi, sv);
             const size_t p = (size_t)y * a.W0 + x;
             if (inb && c0 == 0) {
                 if (a.out_labels_u8) a.out_labels_u8[p] = (uint8_t)bi;
                 if (a.out_labels) a.out_labels[p] = bi;
+                if (a.out_margin) a.out_margin[p] = bv - sv;
             }
             if (a.out_logits && inb)
 #pragma unroll
@@ -1668,7 +1672,7 @@ static int producer_of(const Engine& e, int tensor) {
 // Fold every MaxPooling2D into the epilogue of the conv that produces its input.
 int mfma_plan_graph(Engine& e) {
     // deconv (k2 s2) feeding only the logits layer -> one fused tail kernel
-    if (!getenv("PSEG_NO_TAIL_FUSION"))
+    if (!PSEG_KNOB("PSEG_NO_TAIL_FUSION"))
         for (size_t li = 0; li < e.ops.size(); ++li) {
             Op& lg = e.ops[li];
             if (lg.type != OP_LOGITS || e.n_classes > 16) continue;
@@ -1684,7 +1688,7 @@ int mfma_plan_graph(Engine& e) {
         }
     // conv (64 couts = one N block of four tiles, stride 1) feeding only the logits layer -> logits / softmax /
     // argmax in that conv's epilogue (unet): its 64-channel full-resolution output is never written
-    if (!getenv("PSEG_NO_TAIL_FUSION") && !getenv("PSEG_NO_CONV_LOGITS"))
+    if (!PSEG_KNOB("PSEG_NO_TAIL_FUSION") && !PSEG_KNOB("PSEG_NO_CONV_LOGITS"))
         for (size_t li = 0; li < e.ops.size(); ++li) {
             Op& lg = e.ops[li];
             if (lg.type != OP_LOGITS || lg.fused_away || e.n_classes > 16 || lg.src1 >= 0) continue;
@@ -1702,7 +1706,7 @@ int mfma_plan_graph(Engine& e) {
             lg.fused_away = true;
         }
     // first layer (Cin = 1, k5, 20 couts) feeding only one k5 conv -> recomputed inside that conv
-    if (!getenv("PSEG_NO_CONV1_FUSION") && e.in_ch == 1)
+    if (!PSEG_KNOB("PSEG_NO_CONV1_FUSION") && e.in_ch == 1)
         for (size_t ci = 0; ci < e.ops.size(); ++ci) {
             Op& c1 = e.ops[ci];
             if (c1.type != OP_CONV || c1.src0 != e.input_tensor || c1.src1 >= 0 || c1.k != 5 || c1.Cout != 20 || c1.stride != 1) continue;
@@ -1730,7 +1734,7 @@ int mfma_plan_graph(Engine& e) {
     }
     // conv outputs nothing reads but their fused pool (fcn_skip: conv4; fcn: conv2, conv4, conv6) are not written: the
     // launch gives the output buffer descriptor zero length, which makes the hardware drop the stores
-    if (!getenv("PSEG_NO_POOL_ONLY"))
+    if (!PSEG_KNOB("PSEG_NO_POOL_ONLY"))
         for (auto& cv : e.ops) {
             if (cv.type != OP_CONV || cv.pool_dst < 0 || cv.add >= 0) continue;
             int users = 0;
@@ -1740,8 +1744,8 @@ int mfma_plan_graph(Engine& e) {
     // skip connection into a composed tail (fcn_skip: conv2 -> logits): when the full-resolution conv output has no
     // other reader than its fused pool and the logits layer, the conv stores its logits contribution (4 or 8 floats
     // per pixel) instead of the tensor, and the tail adds it: 64 + 64 B/px of HBM traffic become 16 + 16 (32 + 32).
-    if (!getenv("PSEG_NO_SKIPLOG") && !getenv("PSEG_NO_TAIL_COMPOSE") && !getenv("PSEG_NO_TAIL_FUSION") && !getenv("PSEG_GENERIC") &&
-        !getenv("PSEG_NO_CONV1_FUSION") && e.n_classes <= 8)
+    if (!PSEG_KNOB("PSEG_NO_SKIPLOG") && !PSEG_KNOB("PSEG_NO_TAIL_COMPOSE") && !PSEG_KNOB("PSEG_NO_TAIL_FUSION") && !PSEG_KNOB("PSEG_GENERIC") &&
+        !PSEG_KNOB("PSEG_NO_CONV1_FUSION") && e.n_classes <= 8)
         for (auto& dc : e.ops) {
             if (dc.type != OP_DECONV2 || dc.tail_logits < 0 || dc.relu) continue;
             Op& lg = e.ops[dc.tail_logits];
@@ -1759,7 +1763,7 @@ int mfma_plan_graph(Engine& e) {
             e.tensors[cv.dst].fused = true;
             // ... and the transposed conv in front of that tail (fcn_skip: deconv4, ReLU), whose output nothing else reads,
             // is computed inside the tail kernel (tail_fused2_kernel) instead of being stored and read back
-            if (getenv("PSEG_NO_TAIL2") || dc.src1 < 0 || e.tensors[dc.src1].Cs > 64) continue;
+            if (PSEG_KNOB("PSEG_NO_TAIL2") || dc.src1 < 0 || e.tensors[dc.src1].Cs > 64) continue;
             const int di = producer_of(e, dc.src0);
             if (di < 0) continue;
             Op& dq = e.ops[di];
@@ -1773,7 +1777,7 @@ int mfma_plan_graph(Engine& e) {
             e.tensors[dq.dst].fused = true;
         }
     // the same inner-deconv fusion for a tail without skips (fcn: deconv4 -> deconv5 o logits)
-    if (!getenv("PSEG_NO_TAIL2") && !getenv("PSEG_NO_TAIL_COMPOSE") && !getenv("PSEG_NO_TAIL_FUSION") && !getenv("PSEG_GENERIC") && e.n_classes <= 8)
+    if (!PSEG_KNOB("PSEG_NO_TAIL2") && !PSEG_KNOB("PSEG_NO_TAIL_COMPOSE") && !PSEG_KNOB("PSEG_NO_TAIL_FUSION") && !PSEG_KNOB("PSEG_GENERIC") && e.n_classes <= 8)
         for (auto& dc : e.ops) {
             if (dc.type != OP_DECONV2 || dc.tail_logits < 0 || dc.relu || dc.src1 >= 0 || e.ops[dc.tail_logits].src1 >= 0) continue;
             if (e.tensors[dc.src0].Cs != 32) continue;
@@ -1950,8 +1954,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     // Measured at 2048x1536 (unet): 1024->512 216 -> ~75 us, 512->256 228 -> ~110 us, 256->128 246 -> ~185 us; at
     // 128->64 the two extra passes over the full-resolution tensor cost more than the direct kernel (PSEG_UPSPLIT_MIN_CIN).
     if (op.type == OP_CONV && k == 2 && op.up0 && !s1 && op.stride == 1 && !op.in_relu && op.add < 0 && op.pool_dst < 0 &&
-        op.tail_logits < 0 && op.fuse1 < 0 && !op.transposed && !getenv("PSEG_NO_UPSPLIT") && !getenv("PSEG_GENERIC")) {
-        const int min_cin = getenv("PSEG_UPSPLIT_MIN_CIN") ? atoi(getenv("PSEG_UPSPLIT_MIN_CIN")) : 256;
+        op.tail_logits < 0 && op.fuse1 < 0 && !op.transposed && !PSEG_KNOB("PSEG_NO_UPSPLIT") && !PSEG_KNOB("PSEG_GENERIC")) {
+        const int min_cin = PSEG_KNOB("PSEG_UPSPLIT_MIN_CIN") ? atoi(PSEG_KNOB("PSEG_UPSPLIT_MIN_CIN")) : 256;
         if (Cin >= min_cin) {
             P->kind = PLAN_UPSPLIT;
             return upsplit_create(&P->upsplit, w, bias, Cin, Cs0, Cout, e.tensors[op.dst].Cs);
@@ -1974,7 +1978,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->MT = (NT <= 2 && !deconv) ? 8 : 4;
     // (the fused conv1+conv2 kernel was also tried with 8-row tiles -- 136 registers, 42 KB, three workgroups per
     // CU: 182 vs 164 us; the halo recompute of conv1 grows from 1.41x to 1.69x and the weights stream twice as often)
-    if (getenv("PSEG_MT")) P->MT = atoi(getenv("PSEG_MT")) == 8 && NT <= 2 ? 8 : 4;
+    if (PSEG_KNOB("PSEG_MT")) P->MT = atoi(PSEG_KNOB("PSEG_MT")) == 8 && NT <= 2 ? 8 : 4;
     // (the 1/8-resolution k5 layers -- conv7, deconv1: 192 eight-row tiles for 256 CUs on a 2048x1536 page -- were tried
     // with four-row tiles (384 workgroups: 28.0 -> 26.3 and 33.3 -> 31.0 us) and with two N blocks of 3 + 2 cout tiles
     // (no change): two workgroups sharing a CU gain little over one here, not worth the extra instances)
@@ -1982,7 +1986,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->stride = deconv ? 1 : op.stride;
     // 8-wave workgroups (16-row tiles, the whole CU's LDS) exist for the k5 stride-1 mid-layer shapes
     P->nw8_ok = !deconv && (KS == 5 || (KS == 3 && NT == 4)) && op.stride == 1 && P->MT == 4 && (NT == 3 || NT == 4) && !op.up0 && !op.up1 &&
-                !op.in_relu && op.add < 0 && op.fuse1 < 0 && (P->nblocks_n == 1 || KS == 3) && !getenv("PSEG_GENERIC") && !getenv("PSEG_NO_NW8");
+                !op.in_relu && op.add < 0 && op.fuse1 < 0 && (P->nblocks_n == 1 || KS == 3) && !PSEG_KNOB("PSEG_GENERIC") && !PSEG_KNOB("PSEG_NO_NW8");
     P->NW = (P->nw8_ok && op.nw_hint == 8) ? 8 : 4;
     const int TH = P->NW * (P->MT / 2);
     const int totc = (Cs0 + Cs1) / 8;
@@ -2011,12 +2015,12 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         // by the bank model) plus a two-slot ring fit 53 KB.  A workgroup's life is prologue -> k-loop ->
         // epilogue with the MFMA pipe used only in the middle; a third resident workgroup fills more of the
         // gaps: conv3 78 -> 67 us, deconv3 79 -> 66 us, better than the 16-row resident variant (70 us).
-        P->wg3 = P->NW == 4 && !deconv && ((KS == 5 && (NT == 3 || NT == 4) && P->nblocks_n == 1) || (KS == 3 && NT == 4 && !getenv("PSEG_NO_WG3_K3")) ||
-                                                 (KS == 2 && NT == 4 && op.up0 && !s1 && !getenv("PSEG_NO_WG3_K3"))) &&
+        P->wg3 = P->NW == 4 && !deconv && ((KS == 5 && (NT == 3 || NT == 4) && P->nblocks_n == 1) || (KS == 3 && NT == 4 && !PSEG_KNOB("PSEG_NO_WG3_K3")) ||
+                                                 (KS == 2 && NT == 4 && op.up0 && !s1 && !PSEG_KNOB("PSEG_NO_WG3_K3"))) &&
                  (P->nc_full == 4 || P->nc_full == 5) && op.stride == 1 &&
-                 (!op.up0 || KS == 2 || KS == 3) && !op.up1 && ((!op.in_relu && op.add < 0) || (KS == 3 && !getenv("PSEG_NO_WG3_RES"))) && op.fuse1 < 0 &&
-                 !getenv("PSEG_GENERIC") && !getenv("PSEG_NO_WG3");
-        if (P->wg3 || (!getenv("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16))) {
+                 (!op.up0 || KS == 2 || KS == 3) && !op.up1 && ((!op.in_relu && op.add < 0) || (KS == 3 && !PSEG_KNOB("PSEG_NO_WG3_RES"))) && op.fuse1 < 0 &&
+                 !PSEG_KNOB("PSEG_GENERIC") && !PSEG_KNOB("PSEG_NO_WG3");
+        if (P->wg3 || (!PSEG_KNOB("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16))) {
             sigma = P->nc_full;
             int best_cyc = 1 << 30;
             for (int pad = 0; pad < 16; ++pad) {
@@ -2053,7 +2057,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     const int ks_max = std::max(P->ks_full, P->ks_last);
     const int tab_bytes = ks_max * 16;
     int budget = P->NW == 8 ? 156 * 1024 : 80 * 1024;
-    if (const char* ev = getenv("PSEG_LDS_KB")) budget = atoi(ev) * 1024;
+    if (const char* ev = PSEG_KNOB("PSEG_LDS_KB")) budget = atoi(ev) * 1024;
     if (P->wg3) budget = 53 * 1024;
     auto total = [&](int gk, int nbuf) { return round_up(in_bytes, 16) + nbuf * gk * NT * 1024 + tab_bytes + 16; };
     const int gstep = P->NW != 4 ? 1 : ((NT % 4 == 0) ? 1 : (NT % 2 == 0 ? 2 : 4));
@@ -2071,12 +2075,12 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     // all weights of a single-block layer resident in one slot: no ring, no group barriers
     const bool can_reside = P->nblk == 1 && total(round_up(ks_max, gstep), 1) <= budget && round_up(ks_max, gstep) <= 32;
     P->nw8_resident = P->NW == 8 && can_reside;
-    if (can_reside && !getenv("PSEG_NO_RESIDENT")) {
+    if (can_reside && !PSEG_KNOB("PSEG_NO_RESIDENT")) {
         NB = 1;
         GK = round_up(ks_max, gstep);
     }
-    if (const char* ev = getenv("PSEG_NB")) { NB = std::max(2, std::min(4, atoi(ev))); GK = std::max(best_gk(NB), gstep); }
-    if (const char* ev = getenv("PSEG_GK")) GK = std::max(gstep, atoi(ev) / gstep * gstep);
+    if (const char* ev = PSEG_KNOB("PSEG_NB")) { NB = std::max(2, std::min(4, atoi(ev))); GK = std::max(best_gk(NB), gstep); }
+    if (const char* ev = PSEG_KNOB("PSEG_GK")) GK = std::max(gstep, atoi(ev) / gstep * gstep);
     if (total(GK, NB) > 160 * 1024) return fail(PSEG_EUNSUPPORTED, "layer %s needs %d B of LDS", op.layer.c_str(), total(GK, NB));
     P->GK = GK;
     P->NB = NB;
@@ -2230,7 +2234,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         const int CP = C <= 4 ? 4 : (C <= 8 ? 8 : 16);
         const bool shapes_ok = (nks0 == 3 && nkss == 1) || (nks0 == 1 && nkss == 0) || (nks0 == 3 && skip_in_buffer);
         if (skip_in_buffer && (op.relu || !shapes_ok || CP > 8)) return fail(PSEG_EUNSUPPORTED, "skip-logits fusion was planned for a tail that cannot be composed");
-        if (!op.relu && !getenv("PSEG_NO_TAIL_COMPOSE") && shapes_ok) {
+        if (!op.relu && !PSEG_KNOB("PSEG_NO_TAIL_COMPOSE") && shapes_ok) {
             const int NTL = CP / 4;
             std::vector<double> M((size_t)4 * C * Cin, 0.0);       // [ab][cls][ci]
             for (int ab = 0; ab < 4; ++ab)
@@ -2344,7 +2348,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     // ring doubles the group barriers)
     if (P.NW != 4) return fail(PSEG_EUNSUPPORTED, "no %d-wave kernel instance for this layer shape", P.NW);
 #define PSEG_TRY_INST(MT_, NT_, KS_, ST_, SG_, MODE_, FL_)                                          \
-    if (!getenv("PSEG_GENERIC") && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == (FL_)) \
+    if (!PSEG_KNOB("PSEG_GENERIC") && P.MT == MT_ && P.NT == NT_ && ks == KS_ && st_ == ST_ && sg == SG_ && mode == MODE_ && fl == (FL_)) \
         return launch_inst<MT_, NT_, KS_, ST_, SG_, MODE_, (FL_)>(a, P, grid, st);
     PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL | FL_FUSE1 | FL_PERSIST | FL_SKIPLOG)   // conv1 + conv2 fused, persistent, skip logits instead of the tensor
     PSEG_TRY_INST(8, 2, 5, 1, 3, MODE_CONV, FL_POOL | FL_FUSE1 | FL_SKIPLOG)
@@ -2389,7 +2393,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
         PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_TAIL, 0)        // deconv5 + logits (fcn)
     }
 #undef PSEG_TRY_INST
-    if (getenv("PSEG_LOG_GENERIC"))
+    if (PSEG_KNOB("PSEG_LOG_GENERIC"))
         fprintf(stderr, "[pseg] generic instance: MT %d NT %d KS %d stride %d sigma %d mode %d flags %d\n", P.MT, P.NT, ks, P.stride, sg, mode, fl);
     if (P.MT == 8) {
         if (P.NT == 1) return launch_inst<8, 1, -1, -1, -1, -1, -1>(a, P, grid, st);
@@ -2407,7 +2411,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
 
 static int launch_generic_any(const MConv& a0, const MfmaPlan& P, dim3 grid, hipStream_t st, const char* layer) {
 #if PSEG_DIAG
-    const char* tr = getenv("PSEG_TRACE");
+    const char* tr = PSEG_KNOB("PSEG_TRACE");
     if (tr && strcmp(tr, layer) == 0) {
         MConv a = a0;
         const size_t n = (size_t)grid.x * grid.y * 12;
@@ -2456,8 +2460,8 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.CoP = P.CoP;
     a.nb_loop = 1;
     a.nb_total = P.nblocks_n;
-    a.dbg = (PSEG_DIAG && getenv("PSEG_DBG")) ? atoi(getenv("PSEG_DBG")) : 0;
-    if (getenv("PSEG_INRELU_VGPR")) a.dbg |= 16;
+    a.dbg = (PSEG_DIAG && PSEG_KNOB("PSEG_DBG")) ? atoi(PSEG_KNOB("PSEG_DBG")) : 0;
+    if (PSEG_KNOB("PSEG_INRELU_VGPR")) a.dbg |= 16;
 }
 
 int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
@@ -2466,14 +2470,14 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     const Tensor& d = e.tensors[op.dst];
     if (P->kind == PLAN_CONV1) {
         const uint8_t* img = e.cur_img;  // raw uint8 page (x/255 and pad-to-32 are fused)
-        if ((P->KS == 3 && (op.Cout == 64 || op.Cout == 32)) && !getenv("PSEG_CONV1_MFMA") && !getenv("PSEG_CONV1_VALU")) {
+        if ((P->KS == 3 && (op.Cout == 64 || op.Cout == 32)) && !PSEG_KNOB("PSEG_CONV1_MFMA") && !PSEG_KNOB("PSEG_CONV1_VALU")) {
             constexpr int RB = 16;
             dim3 g(cdiv(e.Wp, 64), cdiv(e.Hp, 4 * RB));
             if (op.Cout == 64) conv1_rows_kernel<3, 64, RB><<<g, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
             else conv1_rows_kernel<3, 32, RB><<<g, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
             return PSEG_OK;
         }
-        if (!getenv("PSEG_CONV1_VALU")) {
+        if (!PSEG_KNOB("PSEG_CONV1_VALU")) {
             dim3 g1(e.Wp / 32, cdiv(e.Hp, 16));
             uint16_t* o = (uint16_t*)d.d;
             if (P->KS == 5 && op.Cout == 20) conv1_mfma_kernel<5, 20><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
@@ -2503,7 +2507,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         // stays resident in LDS (conv3: 80 -> 68 us); with a streamed ring they only tie (the halved
         // weight traffic is offset by losing the second workgroup's overlap).  PSEG_NW=4|8 forces.
         int want = (cdiv(e.tW(d), TW) * cdiv(e.tH(d), 16) >= 224 && sigma_for(P->nc_full) == 6 && !P->wg3) ? 8 : 4;
-        const char* ev = getenv("PSEG_NW");
+        const char* ev = PSEG_KNOB("PSEG_NW");
         if (ev) want = atoi(ev) == 8 ? 8 : 4;
         if (want != P->NW && want != P->nw_tried) {
             const std::vector<float> w = P->w_keep, b = P->b_keep;
@@ -2572,13 +2576,13 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         a.lds_f1_off = P->lds_f1_off;
     }
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, P->NW * (P->MT / 2)), P->nblocks_n);
-    a.xq = getenv("PSEG_NO_XCD") ? -1 : (int)grid.x / 8;
+    a.xq = PSEG_KNOB("PSEG_NO_XCD") ? -1 : (int)grid.x / 8;
     a.xr = (int)grid.x % 8;
     // persistent instance (PSEG_NO_PERSIST=1 disables): resident weights (NB == 1), single channel block, two
     // workgroups per CU walking 12 tiles each: the 38 KB weight set and the k-chunk table are staged once per
     // workgroup instead of once per tile.  Worth 1-3 % on the fused conv1+conv2 kernel (the DMA it saves was
     // mostly hidden by the co-resident workgroup); needs the per-trip opaque lane ids to keep two waves per SIMD.
-    if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && !getenv("PSEG_NO_PERSIST") && !getenv("PSEG_GENERIC")) {
+    if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && !PSEG_KNOB("PSEG_NO_PERSIST") && !PSEG_KNOB("PSEG_GENERIC")) {
         static int cus = 0;   // one device model per process
         if (!cus) {
             int dev = 0;
@@ -2603,7 +2607,7 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
     a.deconv = 1;
     if (op.tail_logits >= 0) {
         const Op& lg = e.ops[op.tail_logits];
-        if (P->tc_CP > 0 && !getenv("PSEG_GENERIC")) {
+        if (P->tc_CP > 0 && !PSEG_KNOB("PSEG_GENERIC")) {
             // composed tail: one small GEMM per half-resolution pixel, no LDS
             const Tensor& s0 = e.tensors[op.src0];
             TailC t{};
@@ -2626,6 +2630,8 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
                 }
             }
             t.out_logits = e.cur_logits; t.out_probs = e.cur_probs; t.out_labels = e.cur_labels; t.out_labels_u8 = e.cur_labels_u8;
+            t.out_margin = e.cur_margin;
+            e.margin_done = e.cur_margin != nullptr;
             if (t.Wh % 16) return fail(PSEG_EINVAL, "composed tail needs a canvas width multiple of 32");
             if (P->tail2) {
                 const Op& dq = e.ops[producer_of(e, op.src0)];
@@ -2640,6 +2646,7 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
                 u.S = t.S; u.Hh = t.Hh; u.Wh = t.Wh; u.H0 = t.H0; u.W0 = t.W0; u.C = t.C;
                 u.wQ = PQ->d_q_w; u.biasQ = PQ->d_q_bias; u.wD = P->d_t2_wD; u.wC = P->d_t2_wC; u.beta = P->d_tc_beta;
                 u.out_logits = t.out_logits; u.out_probs = t.out_probs; u.out_labels = t.out_labels; u.out_labels_u8 = t.out_labels_u8;
+                u.out_margin = t.out_margin;
                 const int nwaves = t.Hh * cdiv((t.Wh + 31) / 32, T2_ITER) * 2;
                 if (P->tc_CP == 4) tail_fused2_kernel<4><<<cdiv(nwaves, 4), 256, 0, st>>>(u);
                 else tail_fused2_kernel<8><<<cdiv(nwaves, 4), 256, 0, st>>>(u);
@@ -2677,11 +2684,11 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
         a.out_labels = e.cur_labels;
         a.out_labels_u8 = e.cur_labels_u8;
         // the specialised tail instances walk both N blocks in one workgroup (NBL = 2 in the kernel)
-        if (P->nblk == 1 && P->nblocks_n == 2 && !getenv("PSEG_GENERIC") && (a.sigma == 10 || a.sigma == 6)) a.nb_loop = 2;
+        if (P->nblk == 1 && P->nblocks_n == 2 && !PSEG_KNOB("PSEG_GENERIC") && (a.sigma == 10 || a.sigma == 6)) a.nb_loop = 2;
     }
-    if (op.tail_logits < 0 && P->nblk == 1 && P->nblocks_n == 2 && !getenv("PSEG_GENERIC") && a.sigma == 14 && P->NT == 4) a.nb_loop = 2;   // deconv4 (fcn_skip)
+    if (op.tail_logits < 0 && P->nblk == 1 && P->nblocks_n == 2 && !PSEG_KNOB("PSEG_GENERIC") && a.sigma == 14 && P->NT == 4) a.nb_loop = 2;   // deconv4 (fcn_skip)
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, 2 * P->MT), P->nblocks_n / a.nb_loop);
-    a.xq = getenv("PSEG_NO_XCD") ? -1 : (int)grid.x / 8;
+    a.xq = PSEG_KNOB("PSEG_NO_XCD") ? -1 : (int)grid.x / 8;
     a.xr = (int)grid.x % 8;
     return launch_generic_any(a, *P, grid, st, op.layer.c_str());
 }
@@ -2704,7 +2711,7 @@ int mfma_launch_logits(Engine& e, Op& op, float* d_logits, float* d_probs, int64
     const uint16_t* p0 = (const uint16_t*)s0.d;
     const uint16_t* p1 = s1 ? (const uint16_t*)s1->d : nullptr;
     const int n0 = s0.Cs / 8, n1 = s1 ? s1->Cs / 8 : 0;
-    if (!getenv("PSEG_LOGITS_VALU") && P->cmax <= 16) {
+    if (!PSEG_KNOB("PSEG_LOGITS_VALU") && P->cmax <= 16) {
         const int waves = e.H * cdiv(e.W, 16);
         logits_mfma_kernel<<<cdiv(waves, 4), 256, 0, st>>>(p0, n0, p1, n1, e.Wp, e.H, e.W, op.Cout, P->d_wpk, P->d_bias,
                                                           d_logits, d_probs, d_labels, d_labels_u8);
@@ -2720,6 +2727,16 @@ int mfma_launch_logits(Engine& e, Op& op, float* d_logits, float* d_probs, int64
     else LG(64);
 #undef LG
     return PSEG_OK;
+}
+
+bool mfma_tail_emits_margin(const Engine& e) {
+    if (PSEG_KNOB("PSEG_GENERIC")) return false;
+    for (auto& op : e.ops)
+        if (op.type == OP_DECONV2 && op.tail_logits >= 0 && !op.fused_away) {
+            auto* P = (MfmaPlan*)op.plan;
+            return P && P->tc_CP > 0;
+        }
+    return false;
 }
 
 // The fused first-layer kernels read the uint8 page directly (e.cur_img); graphs whose first

@@ -6,6 +6,7 @@
 // row-major access, wave-aggregated atomics where many lanes hit one counter.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 #include "pseg_common.h"
 
@@ -235,7 +236,7 @@ static int ccl_run(const uint8_t* d_bin, const int64_t* d_cls, int* d_L, int H, 
                    hipStream_t st, int* d_hist = nullptr, int ncls = 0) {
     const int n = H * W;
     const int grid = cdiv(n, 256);
-    if (getenv("PSEG_CCL_GLOBAL")) {
+    if (PSEG_KNOB("PSEG_CCL_GLOBAL")) {
         ccl_rows_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
         ccl_cols_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
     } else {
@@ -264,7 +265,8 @@ int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hi
 // per distinct key.  Only the rows of roots are ever touched: the labelling's compress pass clears exactly those
 // instead of a page-sized memset.
 constexpr int VT = 32, VSLOTS = 2048;
-__global__ __launch_bounds__(256) void vote_count_kernel(const int* L, const int64_t* pred, int* hist, int H, int W, int ncls) {
+template <typename LT>
+__global__ __launch_bounds__(256) void vote_count_kernel(const int* L, const LT* pred, int* hist, int H, int W, int ncls) {
     __shared__ int keys[VSLOTS];
     __shared__ int vals[VSLOTS];
     for (int i = threadIdx.x; i < VSLOTS; i += 256) { keys[i] = -1; vals[i] = 0; }
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void vote_count_kernel(const int* L, const int
             if (x < W) {
                 const size_t p = (size_t)y * W + x;
                 const int r = L[p];
-                const int64_t c = pred[p];
+                const int64_t c = (int64_t)pred[p];
                 if (r >= 0 && c >= 0 && c < ncls) k = r * ncls + (int)c;
             }
             if (k == key) { ++cnt; continue; }
@@ -303,7 +305,8 @@ __global__ __launch_bounds__(256) void vote_count_kernel(const int* L, const int
 
 // Every ink pixel reads its component's counters (a few cache lines per component) and takes
 // np.argmax(bins) = the lowest class among the most frequent (lib/postprocess.py:22-23).
-__global__ void vote_apply_kernel(const int* L, const int* hist, int64_t* pred, int n, int ncls) {
+template <typename LT>
+__global__ void vote_apply_kernel(const int* L, const int* hist, LT* pred, int n, int ncls) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int r = L[p];
@@ -314,42 +317,70 @@ __global__ void vote_apply_kernel(const int* L, const int* hist, int64_t* pred, 
         const int v = h[c];
         if (v > bv) { bv = v; best = c; }
     }
-    pred[p] = best;
+    pred[p] = (LT)best;
 }
 
-static int cc_vote_device(int64_t* d_pred, const uint8_t* d_bin, int H, int W, int ncls,
+// Label / histogram workspace of the vote: grow-only, one per device, shared by every caller.  A 4096x3072 6-class
+// page needs 50 + 302 MB; allocating and freeing it per call cost more than the kernels.  Calls are ordered by an
+// event: a call on another stream than the previous user's first waits for that user's kernels, so two streams (or
+// two threads) never run on the buffers at once.  pseg_release_workspace() frees it.
+struct VoteWs {
+    void* p[2] = {nullptr, nullptr};
+    size_t bytes[2] = {0, 0};
+    hipEvent_t last = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+};
+static std::mutex g_ws_mu;
+static VoteWs g_ws[64];
+
+int release_workspace(int dev) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    VoteWs& w = g_ws[dev & 63];
+    if (w.used && w.last) (void)hipEventSynchronize(w.last);
+    for (int i = 0; i < 2; ++i) { if (w.p[i]) (void)hipFree(w.p[i]); w.p[i] = nullptr; w.bytes[i] = 0; }
+    if (w.last) (void)hipEventDestroy(w.last);
+    w.last = nullptr; w.used = false; w.last_stream = nullptr;
+    return PSEG_OK;
+}
+
+template <typename LT>
+static int cc_vote_device(LT* d_pred, const uint8_t* d_bin, int H, int W, int ncls,
                           hipStream_t st) {
     if (H <= 0 || W <= 0) return PSEG_OK;
     if ((int64_t)H * W * std::max(ncls, 1) > 0x7fffffffLL)
         return fail(PSEG_EUNSUPPORTED, "page too large for 32-bit component indices");
     const int n = H * W;
-    // label + histogram workspace: grow-only, cached per calling thread and device (a 4096x3072 6-class
-    // page needs 50 + 302 MB; allocating and freeing it per call cost more than the kernels)
     int dev = 0;
     PSEG_HIP(hipGetDevice(&dev));
-    struct Ws { void* p = nullptr; size_t bytes = 0; };
-    static thread_local Ws ws[64][2];
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    VoteWs& w = g_ws[dev & 63];
+    if (!w.last) PSEG_HIP(hipEventCreateWithFlags(&w.last, hipEventDisableTiming));
     auto need = [&](int slot, size_t bytes) -> void* {
-        Ws& w = ws[dev & 63][slot];
-        if (w.bytes < bytes) {
-            if (w.p) (void)hipFree(w.p);
-            w.p = nullptr; w.bytes = 0;
-            if (hipMalloc(&w.p, bytes) != hipSuccess) { w.p = nullptr; return nullptr; }
-            w.bytes = bytes;
+        if (w.bytes[slot] < bytes) {
+            if (w.used) (void)hipEventSynchronize(w.last);     // the previous user may still be running on the old block
+            if (w.p[slot]) (void)hipFree(w.p[slot]);
+            w.p[slot] = nullptr; w.bytes[slot] = 0;
+            if (hipMalloc(&w.p[slot], bytes) != hipSuccess) { w.p[slot] = nullptr; return nullptr; }
+            w.bytes[slot] = bytes;
         }
-        return w.p;
+        return w.p[slot];
     };
     int* d_L = (int*)need(0, (size_t)n * 4);
     int* d_hist = (int*)need(1, (size_t)n * ncls * 4);
     if (!d_L || !d_hist) return fail(PSEG_ENOMEM, "hipMalloc(vote workspace) failed");
+    if (w.used && w.last_stream != st) PSEG_HIP(hipStreamWaitEvent(st, w.last, 0));
     int rc = ccl_run<0>(d_bin, nullptr, d_L, H, W, st, d_hist, ncls);     // the compress pass clears the roots' counters
     if (rc == PSEG_OK) {
         const int grid = cdiv(n, 256);
-        vote_count_kernel<<<cdiv(W, VT) * cdiv(H, VT), 256, 0, st>>>(d_L, d_pred, d_hist, H, W, ncls);
-        vote_apply_kernel<<<grid, 256, 0, st>>>(d_L, d_hist, d_pred, n, ncls);
+        vote_count_kernel<LT><<<cdiv(W, VT) * cdiv(H, VT), 256, 0, st>>>(d_L, d_pred, d_hist, H, W, ncls);
+        vote_apply_kernel<LT><<<grid, 256, 0, st>>>(d_L, d_hist, d_pred, n, ncls);
         if (hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "vote kernel launch failed");
     }
-    return rc;   // asynchronous on `st`; the cached workspace is reused by the next call on this thread (stream order)
+    PSEG_HIP(hipEventRecord(w.last, st));
+    w.used = true;
+    w.last_stream = st;
+    return rc;   // asynchronous on `st`
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,45 +503,104 @@ static int bbox_fill_device(const int64_t* d_pred, int64_t* d_out, int H, int W,
 }
 
 // ---------------------------------------------------------------------------------------------
-// colour / overlay masks (lib/output.py:44-60): 4 pixels per thread, 12-byte stores
+// colour / overlay masks (lib/output.py:44-60).  HBM-bound: 1 (uint8 labels; 8 for the reference's int64) + 1 bytes
+// in, 12 bytes out per pixel and mask set.  A workgroup owns 1024 consecutive pixels; a thread converts four of them
+// (one dword of labels, one of the binarisation) and the 3072 bytes of each mask are exchanged through LDS so that
+// every store instruction writes 16 bytes per lane of one contiguous run (whole 128-byte lines).
 // ---------------------------------------------------------------------------------------------
-__global__ void masks_kernel(const int64_t* pred, const uint8_t* bin, const uint8_t* lut, int n_lut,
-                             int n, uint8_t* color, uint8_t* overlay, uint8_t* inverted,
-                             uint8_t* fgc) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 pixels
-    const int p0 = q * 4;
-    if (p0 >= n) return;
-    uint8_t c[12], ov[12], iv[12], fg[12];
-    const int cnt = min(4, n - p0);
-    for (int i = 0; i < 4; ++i) {
-        uint8_t r = 0, g = 0, b = 0, bb = 0;
-        if (i < cnt) {
-            const int64_t l = pred[p0 + i];
-            if (l >= 0 && l < n_lut) { r = lut[l * 3]; g = lut[l * 3 + 1]; b = lut[l * 3 + 2]; }
-            bb = bin[p0 + i];
-        }
-        const uint8_t fgd = (uint8_t)(1 - bb);  // uint8 wrap-around as numpy does
-        c[3 * i] = r; c[3 * i + 1] = g; c[3 * i + 2] = b;
-        const bool ko = fgd == 0, ki = bb == 0, kf = fgd != 0;
-        ov[3 * i] = ko ? 0 : r; ov[3 * i + 1] = ko ? 0 : g; ov[3 * i + 2] = ko ? 0 : b;
-        iv[3 * i] = ki ? 0 : r; iv[3 * i + 1] = ki ? 0 : g; iv[3 * i + 2] = ki ? 0 : b;
-        fg[3 * i] = kf ? 0 : r; fg[3 * i + 1] = kf ? 0 : g; fg[3 * i + 2] = kf ? 0 : b;
+template <typename LT>
+__global__ __launch_bounds__(256) void masks_kernel(const LT* pred, const uint8_t* bin, const uint8_t* lut, int n_lut,
+                                                    int n, uint8_t* color, uint8_t* overlay, uint8_t* inverted,
+                                                    uint8_t* fgc, int wide) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[4][768];
+    __shared__ uint32_t slut[256];                     // 0x00BBGGRR per label
+    {
+        const int l = threadIdx.x;
+        slut[l] = l < n_lut ? (uint32_t)lut[l * 3] | ((uint32_t)lut[l * 3 + 1] << 8) | ((uint32_t)lut[l * 3 + 2] << 16) : 0u;
     }
-    auto put = [&](uint8_t* dst, const uint8_t* v) {
-        if (!dst) return;
-        if (cnt == 4) {
-            uint32_t w[3];
-            memcpy(w, v, 12);
-            uint32_t* d = (uint32_t*)(dst + (size_t)p0 * 3);
-            d[0] = w[0]; d[1] = w[1]; d[2] = w[2];
+    __syncthreads();
+    const int pb = blockIdx.x * 1024;                  // first pixel of this workgroup
+    const int p0 = pb + threadIdx.x * 4;
+    const int cnt = min(4, n - p0);                    // <= 0: nothing for this thread
+    uint32_t rgb[4] = {0, 0, 0, 0};
+    uint32_t wb = 0;                                   // the four binarisation bytes
+    if (cnt == 4) {
+        if constexpr (sizeof(LT) == 1) {
+            const uint32_t w = *(const uint32_t*)(pred + p0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const uint32_t l = (w >> (8 * i)) & 0xff; rgb[i] = l < (uint32_t)n_lut ? slut[l] : 0u; }
         } else {
-            for (int i = 0; i < cnt * 3; ++i) dst[(size_t)p0 * 3 + i] = v[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int64_t l = (int64_t)pred[p0 + i]; rgb[i] = (l >= 0 && l < n_lut) ? slut[l] : 0u; }
         }
-    };
-    put(color, c);
-    put(overlay, ov);
-    put(inverted, iv);
-    put(fgc, fg);
+        wb = *(const uint32_t*)(bin + p0);
+    } else {
+        for (int i = 0; i < cnt; ++i) {
+            const int64_t l = (int64_t)pred[p0 + i];
+            rgb[i] = (l >= 0 && l < n_lut) ? slut[l] : 0u;
+            wb |= (uint32_t)bin[p0 + i] << (8 * i);
+        }
+    }
+    // lib/output.py:44-60 with numpy's uint8 arithmetic: fg = 1 - binary (wraps); overlay is black where fg == 0 (binary ==
+    // 1), inverted_overlay where binary == 0, fg_color_mask where fg != 0 (binary != 1)
+    uint32_t m[4][4];                                  // [mask][pixel]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = (wb >> (8 * i)) & 0xff;
+        m[0][i] = rgb[i];
+        m[1][i] = b == 1 ? 0u : rgb[i];
+        m[2][i] = b == 0 ? 0u : rgb[i];
+        m[3][i] = b != 1 ? 0u : rgb[i];
+    }
+    uint8_t* const dsts[4] = {color, overlay, inverted, fgc};
+    if (wide) {
+        // every output is 16-byte aligned: exchange through LDS, then 16-byte stores of contiguous runs
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!dsts[k]) continue;
+            stage[k][3 * threadIdx.x] = m[k][0] | (m[k][1] << 24);
+            stage[k][3 * threadIdx.x + 1] = (m[k][1] >> 8) | (m[k][2] << 16);
+            stage[k][3 * threadIdx.x + 2] = (m[k][2] >> 16) | (m[k][3] << 8);
+        }
+        __syncthreads();
+        const int nbytes = min(1024, n - pb) * 3;      // bytes of this workgroup's run
+        if (threadIdx.x < 192) {
+            const int o = threadIdx.x * 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!dsts[k]) continue;
+                uint8_t* d = dsts[k] + (size_t)pb * 3 + o;
+                if (o + 16 <= nbytes) *(uint4*)d = *(const uint4*)((const uint8_t*)stage[k] + o);
+                else for (int i = 0; o + i < nbytes; ++i) d[i] = ((const uint8_t*)stage[k])[o + i];
+            }
+        }
+        return;
+    }
+    if (cnt <= 0) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint8_t* dst = dsts[k];
+        if (!dst) continue;
+        for (int i = 0; i < cnt; ++i) {
+            uint8_t* d = dst + (size_t)(p0 + i) * 3;
+            d[0] = (uint8_t)m[k][i]; d[1] = (uint8_t)(m[k][i] >> 8); d[2] = (uint8_t)(m[k][i] >> 16);
+        }
+    }
+}
+
+template <typename LT>
+static int masks_device(const LT* d_pred, const uint8_t* d_binary, const uint8_t* d_lut, int n_lut, int H, int W,
+                        uint8_t* d_color, uint8_t* d_overlay, uint8_t* d_inverted, uint8_t* d_fg_color, hipStream_t st) {
+    if (n_lut < 1 || n_lut > 256) return fail(PSEG_EINVAL, "n_lut %d out of range (1..256)", n_lut);
+    const int n = H * W;
+    const uintptr_t al = (uintptr_t)d_color | (uintptr_t)d_overlay | (uintptr_t)d_inverted | (uintptr_t)d_fg_color;
+    const int wide = (al & 15) == 0 && (((uintptr_t)d_pred | (uintptr_t)d_binary) & 3) == 0;
+    if ((((uintptr_t)d_pred | (uintptr_t)d_binary) & 3) != 0 && sizeof(LT) == 1)
+        return fail(PSEG_EINVAL, "uint8 label / binary maps must be 4-byte aligned");
+    masks_kernel<LT><<<cdiv(n, 1024), 256, 0, st>>>(d_pred, d_binary, d_lut, n_lut, n, d_color, d_overlay, d_inverted,
+                                                   d_fg_color, wide);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -579,7 +669,20 @@ int pseg_cc_vote_device(int device, int64_t* d_pred, const uint8_t* d_binary, in
     if (!d_pred || !d_binary) return fail(PSEG_EINVAL, "NULL argument");
     if (n_classes < 1) return fail(PSEG_EINVAL, "n_classes must be >= 1");
     PSEG_TRY(set_dev(device));
-    return cc_vote_device(d_pred, d_binary, H, W, n_classes, (hipStream_t)stream);
+    return cc_vote_device<int64_t>(d_pred, d_binary, H, W, n_classes, (hipStream_t)stream);
+}
+
+int pseg_cc_vote_device_u8(int device, uint8_t* d_pred, const uint8_t* d_binary, int H, int W,
+                           int n_classes, void* stream) {
+    if (!d_pred || !d_binary) return fail(PSEG_EINVAL, "NULL argument");
+    if (n_classes < 1 || n_classes > 256) return fail(PSEG_EINVAL, "n_classes must be in 1..256");
+    PSEG_TRY(set_dev(device));
+    return cc_vote_device<uint8_t>(d_pred, d_binary, H, W, n_classes, (hipStream_t)stream);
+}
+
+int pseg_release_workspace(int device) {
+    PSEG_TRY(set_dev(device));
+    return release_workspace(device);
 }
 
 int pseg_cc_vote(int device, int64_t* pred, const uint8_t* binary, int H, int W, int n_classes) {
@@ -601,7 +704,7 @@ int pseg_cc_vote(int device, int64_t* pred, const uint8_t* binary, int H, int W,
     if (hipMemcpy(d_pred, pred, n * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d_bin, binary, n, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(PSEG_EHIP, "H2D copy failed");
-    if (rc == PSEG_OK) rc = cc_vote_device(d_pred, d_bin, H, W, n_classes, nullptr);
+    if (rc == PSEG_OK) rc = cc_vote_device<int64_t>(d_pred, d_bin, H, W, n_classes, nullptr);
     if (rc == PSEG_OK && hipMemcpy(pred, d_pred, n * 8, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(PSEG_EHIP, "D2H copy failed");
     (void)hipFree(d_pred);
@@ -636,11 +739,16 @@ int pseg_masks_device(int device, const int64_t* d_pred, const uint8_t* d_binary
     if (!d_pred || !d_binary || !d_lut) return fail(PSEG_EINVAL, "NULL argument");
     if (H <= 0 || W <= 0) return PSEG_OK;
     PSEG_TRY(set_dev(device));
-    const int n = H * W;
-    masks_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, (hipStream_t)stream>>>(
-        d_pred, d_binary, d_lut, n_lut, n, d_color, d_overlay, d_inverted, d_fg_color);
-    PSEG_HIP(hipGetLastError());
-    return PSEG_OK;
+    return masks_device<int64_t>(d_pred, d_binary, d_lut, n_lut, H, W, d_color, d_overlay, d_inverted, d_fg_color, (hipStream_t)stream);
+}
+
+int pseg_masks_device_u8(int device, const uint8_t* d_pred, const uint8_t* d_binary,
+                         const uint8_t* d_lut, int n_lut, int H, int W, uint8_t* d_color,
+                         uint8_t* d_overlay, uint8_t* d_inverted, uint8_t* d_fg_color, void* stream) {
+    if (!d_pred || !d_binary || !d_lut) return fail(PSEG_EINVAL, "NULL argument");
+    if (H <= 0 || W <= 0) return PSEG_OK;
+    PSEG_TRY(set_dev(device));
+    return masks_device<uint8_t>(d_pred, d_binary, d_lut, n_lut, H, W, d_color, d_overlay, d_inverted, d_fg_color, (hipStream_t)stream);
 }
 
 int pseg_masks(int device, const int64_t* pred, const uint8_t* binary, const uint8_t* lut,

@@ -480,10 +480,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
 
 static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     // grid = (strips, taps) for the scalar kernel; the matrix-core kernel takes (taps, strips)
-    if (a.XC <= 16 * WGM_MAXT && a.Cout <= 16 * WGM_MAXT && !getenv("PSEG_WGRAD_SCALAR")) {
+    if (a.XC <= 16 * WGM_MAXT && a.Cout <= 16 * WGM_MAXT && !PSEG_KNOB("PSEG_WGRAD_SCALAR")) {
         const int ti = (a.XC + 15) / 16, tj = (a.Cout + 15) / 16;
         // a whole kernel row per workgroup for the small k5 layers (mode 0: taps of a row share dY)
-        if (a.mode == 0 && a.KW == 5 && grid.y % 5 == 0 && !getenv("PSEG_WGRAD_KX1")) {
+        if (a.mode == 0 && a.KW == 5 && grid.y % 5 == 0 && !PSEG_KNOB("PSEG_WGRAD_KX1")) {
             WgradArgs a5 = a;                                  // five times fewer "taps": five times more strips
             a5.strip_rows = std::max(1, a.strip_rows / 5);
             const dim3 g5(grid.y / 5, cdiv(a.Hy, a5.strip_rows));
@@ -496,7 +496,7 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
         PSEG_WG(1, 2) PSEG_WG(2, 2) PSEG_WG(2, 3) PSEG_WG(3, 3) PSEG_WG(3, 5) PSEG_WG(5, 3) PSEG_WG(5, 5)
 #undef PSEG_WG
         return fail(PSEG_EUNSUPPORTED, "no weight-gradient instance for %d x %d channels", a.XC, a.Cout);
-    } else if (!getenv("PSEG_WGRAD_SCALAR")) {
+    } else if (!PSEG_KNOB("PSEG_WGRAD_SCALAR")) {
         // wide layers (unet / res_unet): 64 x 64 channel blocks on blockIdx.z
         const dim3 g3(grid.y, grid.x, cdiv(a.XC, 64) * cdiv(a.Cout, 64));
         wgrad_mfma_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
@@ -724,7 +724,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     const uint32_t drop_key = backward ? (t->drop_seed * 0x632BE5ABu + (uint32_t)t->fwd_count * 0x9E3779B9u) | 1u : 0u;
     if (backward) ++t->fwd_count;
     e.drop_key = drop_key;
-    e.relaxed_f32 = getenv("PSEG_TRAIN_STRICT") ? 0 : 1;   // wide layers: channel-blocked matrix-core kernel (summation order differs from predict)
+    e.relaxed_f32 = PSEG_KNOB("PSEG_TRAIN_STRICT") ? 0 : 1;   // wide layers: channel-blocked matrix-core kernel (summation order differs from predict)
     const int rc_fwd = run_exact(e, t->d_img, t->d_logits, nullptr, nullptr, nullptr, st);
     e.drop_key = 0;
     e.relaxed_f32 = 0;
@@ -835,7 +835,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.pt = k - 1 - pt; a.pl = k - 1 - pl;
                 a.Hout = lg ? H : Hx; a.Wout = lg ? W : Wx; a.Cout = nc;
                 a.mask = maskd;
-                a.relaxed = getenv("PSEG_TRAIN_STRICT") ? 0 : 1;
+                a.relaxed = PSEG_KNOB("PSEG_TRAIN_STRICT") ? 0 : 1;
                 a.dst = direct ? t->tgrad[src] : t->d_tmp;
                 a.add = direct ? t->tgrad[src] : nullptr;
                 a.dst_pitch = Wx;

@@ -41,22 +41,25 @@ class Network:
                  loss_func=None,
                  *,
                  device: int = 0,
-                 exact: bool = False,
+                 exact=None,
                  ):
         """
         :param type: "train" enables the training state, anything else ("Predict") is inference
         :param model: Keras HDF5 weight / full-model file (read by pseg_amd.h5lite, no h5py needed)
                       or the .npz written by save_weights(); no extension means '.h5' as in the reference
         :param device: HIP device index (keyword-only extension)
-        :param exact: True = float32 sequential-fmaf mode (bit-identical to the CPU oracle),
-                      False = bf16 MFMA throughput mode (keyword-only extension)
+        :param exact: arithmetic of predict (keyword-only extension).  True (default, as the reference computes in
+                      float32): float32 sequential-fmaf engine, bit-identical to the CPU oracle; 'labels': bf16 MFMA
+                      throughput engine with the float32 referee on near-ties -- `pred` equals the float32 engine's,
+                      logits / probabilities carry bf16 accuracy; False: bf16 throughput engine alone (label maps may
+                      differ from float32 at near-ties of the two largest logits).  None reads PSEG_NETWORK_MODE
+                      ('f32' default, 'bf16').
         """
         self.architecture = model_constructor.value
         self._data: Dataset = Dataset([], ColorMap({}))
         self.type = type
         self.has_binary = has_binary
         self.foreground_masks = foreground_masks
-        self.n_classes = n_classes
         self.l_rate = l_rate
         self.optimizer = optimizer
         self.optimizer_norm_clipping = optimizer_norm_clipping
@@ -64,15 +67,38 @@ class Network:
         self.optimizer_clipping = optimizer_clipping
         self.optimizer_clip_value = optimizer_clip_value
         self.loss_func = loss_func
+        # lib/network.py:75-86: a saved full model decides the graph (tf.keras.models.load_model) -- its name replaces
+        # the constructor's architecture (:251) and its logits kernel the class count (PredictSettings.n_classes
+        # defaults to -1, lib/predictor_data.py:19-26); only when no file loads is model_constructor built (:89)
+        path = self._resolve(model)
+        file_w = None
+        if path is not None and os.path.exists(path):
+            file_w = self._read_weight_file(path)
+            arch, n_cls, file_in_ch = self._graph_of_file(path, file_w)
+            if arch is not None:
+                self.architecture = arch
+            if n_classes < 1:
+                n_classes = n_cls
+            if file_in_ch in (1, 3):
+                input_image_dimension = file_in_ch
+        if n_classes < 1:
+            raise Exception("n_classes is not set and no model file provides it (model=%r)" % (model,))
+        self.n_classes = n_classes
         _, rgb = Architecture(self.architecture).preprocess()
         self._rgb = rgb
         in_ch = 3 if rgb else input_image_dimension
-
-        self.model = _eng.Engine(model_constructor.model(), n_classes, in_channels=in_ch, device=device,
-                                 mode=_eng.MODE_F32_EXACT if exact else _eng.MODE_BF16)
-        path = self._resolve(model)
-        if path is not None and os.path.exists(path):
-            self.load_weights(path)
+        if exact is None:
+            exact = os.environ.get("PSEG_NETWORK_MODE", "f32") != "bf16"
+        self.exact = exact
+        if exact is True:
+            mode = _eng.MODE_F32_EXACT
+        elif exact in (False, "labels"):
+            mode = _eng.MODE_BF16
+        else:
+            raise Exception("exact must be True (float32), 'labels' (bf16 + float32 referee) or False (bf16)")
+        self.model = _eng.Engine(Architecture(self.architecture).model(), n_classes, in_channels=in_ch, device=device, mode=mode)
+        if file_w is not None:
+            self._set_file_weights(path, file_w)
         else:
             if model and continue_training:
                 raise Exception("Model file %s not found, cannot continue training" % model)
@@ -111,40 +137,125 @@ class Network:
                 if not layers or layers[-1][0] != lname:
                     layers.append((lname, []))
                 layers[-1][1].append((name + ':0', arr))
-            h5lite.write_keras_weights(path, layers)
+            h5lite.write_keras_weights(path, self._keras_layer_order(layers))
             return path
         if not path.endswith('.npz'):
             path = os.path.splitext(path)[0] + '.npz'
         np.savez(path, **{k.replace('/', '__'): v for k, v in w.items()})
         return path
 
-    def load_weights(self, path):
+    @staticmethod
+    def _read_weight_file(path):
+        """-> [(weight name, array), ...] in the file's order."""
         if path.endswith('.h5'):
-            # Keras load_weights(by_name=False): layers that own weights are matched BY ORDER (names in a
-            # trained file carry Keras' per-process counters, e.g. conv2d_14), shapes must agree
             from pseg_amd import h5lite
-            file_w = [(wn, a) for _, ws in h5lite.read_keras_weights(path) for wn, a in ws]
-            specs = self.model.weight_specs()
-            if len(file_w) != len(specs):
-                raise Exception("%s holds %d weight tensors, the %s graph has %d"
-                                % (path, len(file_w), self.architecture, len(specs)))
-            out = {}
-            for (name, shape), (wn, a) in zip(specs, file_w):
-                if tuple(a.shape) != tuple(shape):
-                    raise Exception("%s: %s has shape %s, %s expects %s" % (path, wn, a.shape, name, tuple(shape)))
-                out[name] = np.ascontiguousarray(a, dtype=np.float32)
-            self.model.set_weights(out)
-            return
+            return [(wn, a) for _, ws in h5lite.read_keras_weights(path) for wn, a in ws]
         with np.load(path, allow_pickle=False) as z:
-            self.model.set_weights({k.replace('__', '/'): z[k] for k in z.files})
+            return [(k.replace('__', '/'), z[k]) for k in z.files]
+
+    @staticmethod
+    def _graph_of_file(path, file_w):
+        """(architecture value | None, n_classes, input channels) of a model file: the saved model's name when the file
+        carries one of the in-scope graphs' names (lib/model.py:91,202,233,306 name their models), else the weight-shape
+        signature; classes = last dimension of the logits kernel (the last 4-D tensor)."""
+        known = {a.value for a in (Architecture.FCN_SKIP, Architecture.FCN, Architecture.UNET, Architecture.RES_UNET)}
+        name = None
+        if path.endswith('.h5'):
+            from pseg_amd import h5lite
+            name = h5lite.read_keras_model_name(path)
+        kernels = [a for _, a in file_w if a.ndim == 4]
+        if not kernels:
+            raise Exception("%s holds no convolution kernels" % path)
+        n_cls = int(kernels[-1].shape[-1])
+        first = kernels[0].shape
+        arch = name if name in known else None
+        if arch is None:
+            if first[:2] == (5, 5) and first[3] == 20:
+                # fcn vs fcn_skip: the third transposed conv reads 120 channels with skips, 60 without (lib/model.py:75,219)
+                cin = [a.shape[3] for n, a in file_w if a.ndim == 4 and 'transpose' in n and a.shape[0] == 5]
+                arch = Architecture.FCN_SKIP.value if (len(cin) > 1 and cin[1] == 120) else Architecture.FCN.value
+            elif first[:2] == (3, 3) and first[3] == 64:
+                arch = Architecture.UNET.value
+            elif first[:2] == (3, 3) and first[3] == 32:
+                arch = Architecture.RES_UNET.value
+        return arch, n_cls, int(first[2])
+
+    @staticmethod
+    def _split_name(lname):
+        base, _, suf = lname.rpartition('_')
+        return (base, int(suf)) if base and suf.isdigit() else (lname, 0)
+
+    def _keras_layer_order(self, layers):
+        """model.layers order of the saved file for the engine's layer list (Keras creation order).  Keras sorts layers
+        by depth and breaks ties by the order a traversal from the output meets them: in res_unet's residual_block
+        (lib/model.py:243-249) the second conv and the shortcut conv tie and Add([shortcut, res]) reaches the shortcut
+        first, so a file lists (conv_a, shortcut, conv_b) where creation order is (conv_a, conv_b, shortcut).  The
+        other graphs are linear in depth."""
+        if self.architecture != Architecture.RES_UNET.value:
+            return list(layers)
+        out = list(layers)
+        blocks = [3 + 3 * i for i in range(4)] + [17 + 3 * i for i in range(4)]   # stem 0-2, encoder 3-14, bridge 15-16, decoder 17-28
+        for b in blocks:
+            out[b + 1], out[b + 2] = out[b + 2], out[b + 1]
+        return out
+
+    def load_weights(self, path):
+        self._set_file_weights(path, self._read_weight_file(path))
+
+    def _set_file_weights(self, path, file_w):
+        specs = self.model.weight_specs()
+        if not path.endswith('.h5'):
+            self.model.set_weights(dict(file_w))
+            return
+        if len(file_w) != len(specs):
+            raise Exception("%s holds %d weight tensors, the %s graph has %d"
+                            % (path, len(file_w), self.architecture, len(specs)))
+        # Names in a trained file carry Keras' per-process counters (conv2d_14, ...) and the file lists layers in
+        # model.layers order, which is not creation order for res_unet: within each layer class (conv2d,
+        # conv2d_transpose, logits) the numeric suffix IS creation order, the order of the engine's table.
+        def by_class(names):
+            groups = {}
+            for idx, wn in enumerate(names):
+                base, num = self._split_name(wn.split('/')[0])
+                groups.setdefault(base, []).append((num, idx))
+            return {b: [i for _, i in sorted(v)] for b, v in groups.items()}
+        fg, sg = by_class([wn for wn, _ in file_w]), by_class([n for n, _ in specs])
+        if {b: len(v) for b, v in fg.items()} == {b: len(v) for b, v in sg.items()}:
+            pairs = [(si, fi) for base, sidx in sg.items() for si, fi in zip(sidx, fg[base])]
+        else:
+            # layer names that do not follow Keras' <class>_<n> pattern: file order, as load_weights(by_name=False)
+            pairs = [(i, i) for i in range(len(specs))]
+        out = {}
+        for si, fi in pairs:
+            (name, shape), (wn, a) = specs[si], file_w[fi]
+            if tuple(a.shape) != tuple(shape):
+                raise Exception("%s: %s has shape %s, %s expects %s" % (path, wn, a.shape, name, tuple(shape)))
+            out[name] = np.ascontiguousarray(a, dtype=np.float32)
+        self.model.set_weights(out)
 
     # -- predict (lib/network.py:248-260) --------------------------------------------------------
     def predict_single_data(self, data: SingleData):
         image = data.image
         if self._rgb:
             image = gray_to_rgb(image)
+        if self.exact == "labels":
+            # bf16 throughput pass for logits / probabilities, label map through the float32 referee (== float32 argmax)
+            logit, prob, _ = self.model.predict(image, want_labels=False)
+            pred = self.model.predict_exact_labels(image)
+            return logit, prob, pred
         logit, prob, pred = self.model.predict(image)
         return logit, prob, pred
+
+    def predict_labels(self, images):
+        """int64 label maps (np.argmax of the logits, lib/network.py:259) of a list of pages without moving logits or
+        probabilities off the device: the bf16 engine takes the overlapped batch entry (pseg_predict_batch), the
+        'labels' mode the float32 referee per page, the float32 engine one predict per page."""
+        imgs = [gray_to_rgb(im) if self._rgb else im for im in images]
+        if self.exact is False and not self._rgb:
+            return self.model.predict_batch(imgs, dtype=np.int64)
+        if self.exact == "labels" and not self._rgb:
+            return [self.model.predict_exact_labels(im) for im in imgs]
+        return [self.model.predict(im, want_logits=False, want_probs=False)[2] for im in imgs]
 
     # -- training (lib/network.py:127-246) --------------------------------------------------------
     def create_dataset_inputs(self, train_data: Dataset, data_augmentation=True,
@@ -196,8 +307,7 @@ class Network:
         if getattr(self, "_train_ready", False):
             return
         if self.model.mode != _eng.MODE_F32_EXACT:
-            raise Exception("training needs the float32 engine: construct Network(..., exact=True) "
-                            "(Trainer does this)")
+            raise Exception("training needs the float32 engine: construct Network(..., exact=True), the default")
         self.model.train_init(clipnorm=self.optimizer_norm_clip_value if self.optimizer_norm_clipping else 0.0,
                               clipvalue=self.optimizer_clip_value if self.optimizer_clipping else 0.0)
         self.model.train_set_optimizer(self.optimizer.value)      # Optimizers enum value = Keras name
@@ -280,7 +390,8 @@ class Network:
                         callback.update_loss(it, row[0], row[1])
                     it += 1
             else:                                   # all ranks must share np.random's seed (same shuffle)
-                rows = dp_train_epoch(n, rank, world, fb, lambda: grad_tensor(self.model), apply)
+                rows = dp_train_epoch(n, rank, world, fb, lambda: grad_tensor(self.model), apply,
+                                      engine_stream=self.model.stream())
                 if callback:
                     for j, row in enumerate(rows):
                         callback.update_loss(it - len(rows) + j, row[0], row[1])

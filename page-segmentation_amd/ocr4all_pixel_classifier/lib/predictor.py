@@ -6,7 +6,7 @@ from typing import Generator
 from .dataset import Dataset, SingleData
 from .network import Network, tf_backend_allow_growth
 from .output import Masks, generate_output_masks, scale_to_original_shape
-from .predictor_data import Prediction, PredictSettings
+from .predictor_data import LazyArray, Prediction, PredictSettings
 
 
 class Predictor:
@@ -30,9 +30,27 @@ class Predictor:
             pred = processor(pred, data)
         return data, prob, pred
 
+    #: pages per pseg_predict_batch call in predict(): uploads / downloads of neighbouring pages overlap the compute
+    BATCH_PAGES = 8
+
+    def _finish(self, data: SingleData, pred):
+        """Everything of _labels() after the network: rescale to the original resolution, post-process chain."""
+        page = data
+        if self.settings.high_res_output:
+            data, pred = scale_to_original_shape(data, pred)
+        for processor in (self.settings.post_process or []):
+            pred = processor(pred, data)
+        prob = LazyArray(lambda page=page: self.network.predict_single_data(page)[1])
+        return Prediction(pred, prob, data)
+
     def predict(self, dataset: Dataset) -> Generator[Prediction, None, None]:
-        for data in dataset.data:
-            yield self.predict_single(data)
+        """lib/predictor.py:27-30, a plain page loop in the reference.  Here the label maps of BATCH_PAGES pages at a
+        time come from Network.predict_labels (the overlapped batch entry); probabilities are fetched on first read."""
+        pages = list(dataset.data)
+        for i in range(0, len(pages), self.BATCH_PAGES):
+            chunk = pages[i:i + self.BATCH_PAGES]
+            for data, pred in zip(chunk, self.network.predict_labels([d.image for d in chunk])):
+                yield self._finish(data, pred)
 
     def predict_single(self, data: SingleData) -> Prediction:
         data, prob, pred = self._labels(data)

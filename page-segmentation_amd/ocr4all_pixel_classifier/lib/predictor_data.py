@@ -9,8 +9,44 @@ import numpy as np
 from .colors import ColorMap
 from .dataset import SingleData
 
-#: one predicted page: label map (H,W) int64, probabilities (H,W,C) float32, the input record
-Prediction = collections.namedtuple("Prediction", ("labels", "probabilities", "data"))
+_PredictionFields = collections.namedtuple("Prediction", ("labels", "probabilities", "data"))
+
+
+class LazyArray:
+    """A probabilities map that is computed when first read: 12 bytes per pixel and class leave the device only for
+    callers that look at them (the label map is what Predictor's consumers use)."""
+
+    def __init__(self, thunk):
+        self._thunk, self._value = thunk, None
+
+    def get(self):
+        if self._thunk is not None:
+            self._value, self._thunk = self._thunk(), None
+        return self._value
+
+
+class Prediction(_PredictionFields):
+    """One predicted page: label map (H,W) int64, probabilities (H,W,C) float32, the input record
+    (lib/predictor_data.py:12-15: a NamedTuple of these three).  `probabilities` may be handed in as a LazyArray; it
+    is resolved on attribute access, indexing and unpacking, so readers always see an ndarray."""
+    __slots__ = ()
+
+    @property
+    def probabilities(self):
+        v = tuple.__getitem__(self, 1)
+        return v.get() if isinstance(v, LazyArray) else v
+
+    def __getitem__(self, i):
+        v = tuple.__getitem__(self, i)
+        if isinstance(i, slice):
+            return tuple(x.get() if isinstance(x, LazyArray) else x for x in v)
+        return v.get() if isinstance(v, LazyArray) else v
+
+    def __iter__(self):
+        for v in tuple.__iter__(self):
+            yield v.get() if isinstance(v, LazyArray) else v
+
+
 Prediction.__annotations__ = {"labels": np.ndarray, "probabilities": np.ndarray, "data": SingleData}
 
 _PostProcessors = Optional[List[Callable[[np.ndarray, SingleData], np.ndarray]]]

@@ -15,11 +15,14 @@ MODE_BF16 = 1
 EXPORTED_SYMBOLS = (
     "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_destroy",
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
-    "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_get_activation", "pseg_flops_per_pixel",
+    "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
+    "pseg_host_alloc", "pseg_host_free", "pseg_host_register", "pseg_host_unregister",
+    "pseg_predict_margin_device", "pseg_predict_exact_labels_device", "pseg_predict_exact_labels", "pseg_label_exact_stats",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
     "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_set_loss", "pseg_train_set_dropout_seed", "pseg_train_forward_backward", "pseg_train_forward_backward_f32", "pseg_train_grad_buffer", "pseg_train_metrics",
     "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
-    "pseg_cc_vote", "pseg_cc_vote_device", "pseg_bbox_fill", "pseg_masks", "pseg_masks_device",
+    "pseg_cc_vote", "pseg_cc_vote_device", "pseg_cc_vote_device_u8", "pseg_release_workspace", "pseg_bbox_fill",
+    "pseg_masks", "pseg_masks_device", "pseg_masks_device_u8",
     "pseg_otsu_char_height",
     "pseg_rescale_shape", "pseg_gaussian_kernel", "pseg_resize_nearest", "pseg_scale_image",
     "pseg_prepare_images", "pseg_affine_warp",
@@ -60,7 +63,17 @@ def lib():
     L.pseg_predict.argtypes = [vp, vp, i, i, vp, vp, vp]
     L.pseg_predict_device.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp]
     L.pseg_predict_batch.argtypes = [vp, i, vp, vp, vp, vp, vp]
+    L.pseg_predict_margin_device.argtypes = [vp, vp, i, i, vp, vp, vp]
+    L.pseg_predict_exact_labels_device.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
+    L.pseg_predict_exact_labels.argtypes = [vp, vp, i, i, vp, vp]
+    L.pseg_label_exact_stats.argtypes = [vp, c.POINTER(c.c_double)]
+    L.pseg_host_alloc.argtypes = [c.POINTER(vp), c.c_size_t]
+    L.pseg_host_free.argtypes = [vp]
+    L.pseg_host_register.argtypes = [vp, c.c_size_t]
+    L.pseg_host_unregister.argtypes = [vp]
     L.pseg_get_activation.argtypes = [vp, c.c_char_p, vp, i64, c.POINTER(i)]
+    L.pseg_engine_stream.argtypes = [vp]
+    L.pseg_engine_stream.restype = vp
     L.pseg_flops_per_pixel.argtypes = [vp]
     L.pseg_flops_per_pixel.restype = c.c_double
     L.pseg_timing_enable.argtypes = [vp, i]
@@ -89,6 +102,9 @@ def lib():
     L.pseg_prepare_images.argtypes = [i, vp, vp, i, i, i, i, vp, i, vp, i, i, i, vp, i, vp, i, vp, vp, vp, vp]
     L.pseg_affine_warp.argtypes = [i, vp, i, i, vp, vp, i, vp]
     L.pseg_cc_vote_device.argtypes = [i, vp, vp, i, i, i, vp]
+    L.pseg_cc_vote_device_u8.argtypes = [i, vp, vp, i, i, i, vp]
+    L.pseg_release_workspace.argtypes = [i]
+    L.pseg_masks_device_u8.argtypes = [i, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp]
     L.pseg_eval_confusion.argtypes = [i, vp, i, vp, i, vp, i64, i, vp]
     L.pseg_cc_label.argtypes = [i, vp, i, i, i, vp, c.POINTER(c.c_int32)]
     L.pseg_cc_tables.argtypes = [i, vp, i, i, i, vp, i, vp, i, i, vp, vp, vp, vp, vp, vp]
@@ -111,6 +127,42 @@ def device_count():
 
 def _ptr(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class _PinnedBlock:
+    """Owner of one pseg_host_alloc block; freed when the last array viewing it goes away."""
+
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        _check(lib().pseg_host_alloc(ctypes.byref(p), int(nbytes)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().pseg_host_free(ctypes.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """NumPy array in page-locked host memory (pseg_host_alloc): pages and label maps kept in such arrays move by DMA
+    straight from / to the array in Engine.predict_batch, overlapped with compute."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    blk = _PinnedBlock(max(n, 1))
+    buf = (ctypes.c_char * max(n, 1)).from_address(blk.ptr)
+    buf._pseg_block = blk                       # keeps the block alive as long as any view of the buffer
+    a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+    return a
+
+
+def pinned_copy(a):
+    """A page-locked copy of `a`."""
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
 
 
 class Engine:
@@ -193,6 +245,39 @@ class Engine:
                                          ctypes.c_void_p(d_logits or None), ctypes.c_void_p(d_probs or None),
                                          ctypes.c_void_p(d_labels or None), ctypes.c_void_p(d_labels_u8 or None),
                                          ctypes.c_void_p(stream or None)))
+
+    def predict_margin_device(self, d_img, H, W, d_margin, d_labels_u8=0, stream=0):
+        """As predict_device, plus the float32 (H,W) margin map: top-1 minus top-2 logit per pixel."""
+        _check(lib().pseg_predict_margin_device(self._h, ctypes.c_void_p(d_img), int(H), int(W), ctypes.c_void_p(d_labels_u8 or None),
+                                                ctypes.c_void_p(d_margin), ctypes.c_void_p(stream or None)))
+
+    def predict_exact_labels_device(self, d_img, H, W, d_labels_u8, d_labels=0, d_margin=0, stream=0):
+        """Label-exact throughput mode: the uint8 label map equals the float32 engine's (bf16 pass + margin map,
+        float32 referee on the blocks that hold near-ties).  Synchronises the stream."""
+        _check(lib().pseg_predict_exact_labels_device(self._h, ctypes.c_void_p(d_img), int(H), int(W), ctypes.c_void_p(d_labels_u8),
+                                                      ctypes.c_void_p(d_labels or None), ctypes.c_void_p(d_margin or None),
+                                                      ctypes.c_void_p(stream or None)))
+
+    def predict_exact_labels(self, image, dtype=np.int64):
+        """uint8 (H,W) page -> label map equal to the float32 engine's (host arrays; label-exact mode)."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        H, W = img.shape[:2]
+        out = np.empty((H, W), dtype)
+        if np.dtype(dtype) == np.int64:
+            _check(lib().pseg_predict_exact_labels(self._h, _ptr(img), H, W, _ptr(out), None))
+        elif np.dtype(dtype) == np.uint8:
+            _check(lib().pseg_predict_exact_labels(self._h, _ptr(img), H, W, None, _ptr(out)))
+        else:
+            raise PsegError("labels dtype must be int64 or uint8")
+        return out
+
+    def label_exact_stats(self):
+        """Statistics of the last predict_exact_labels_device call."""
+        v = (ctypes.c_double * 8)()
+        _check(lib().pseg_label_exact_stats(self._h, v))
+        return {"tau": float(v[0]), "calib_logit_err": float(v[1]), "flagged_px_frac": float(v[2]), "referee_tile_frac": float(v[3]),
+                "referee_area_frac": float(v[4]), "tau_escalations": int(v[5]), "whole_page_fallback": int(v[6]),
+                "labels_changed": int(v[7])}
 
     def predict_batch(self, images, dtype=np.int64, out=None):
         """Label maps of a list of (H,W) uint8 pages (sizes may differ); copies overlap compute.
@@ -302,6 +387,10 @@ class Engine:
             _check(L.pseg_train_get_gradient(self._h, name.encode(), _ptr(a), a.size))
             out[name] = a
         return out
+
+    def stream(self):
+        """Raw hipStream_t (int) of the engine's own stream."""
+        return int(lib().pseg_engine_stream(self._h) or 0)
 
     def flops_per_pixel(self):
         return float(lib().pseg_flops_per_pixel(self._h))

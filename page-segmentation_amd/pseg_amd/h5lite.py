@@ -386,6 +386,24 @@ def read_keras_weights(path):
     return out
 
 
+def read_keras_model_name(path):
+    """Name of the model a full-model Keras file was saved from (`model_config` attribute -> config.name, e.g.
+    'fcn_skip', 'res_unet', or Keras' default 'model'); None for a weights-only file."""
+    import json
+    f = H5File(path)
+    cfg = f.obj(f.root).attrs.get("model_config")
+    if cfg is None:
+        return None
+    if isinstance(cfg, np.ndarray):
+        cfg = cfg.ravel()[0]
+    if isinstance(cfg, bytes):
+        cfg = cfg.decode("utf8", "replace")
+    try:
+        return json.loads(cfg).get("config", {}).get("name")
+    except (ValueError, AttributeError):
+        return None
+
+
 # ------------------------------------------------------------------------------------------------
 # writer (weights-only Keras file: what model.save_weights('x.h5') produces)
 # ------------------------------------------------------------------------------------------------

@@ -19,22 +19,42 @@ def predict_pages_sharded(predict_fn: Callable[[np.ndarray], np.ndarray], pages:
                           rank: int = 0, world: int = 1, gather: bool = True) -> Optional[List[np.ndarray]]:
     """Every rank predicts its own pages with `predict_fn(page) -> label map`; with gather=True
     rank 0 returns all label maps in page order (other ranks return None).  Pages may differ
-    in size (ragged) and a rank may own no page at all."""
+    in size (ragged) and a rank may own no page at all.  Label maps travel as plain tensors, one point-to-point
+    message per page (a label map has its page's shape, which rank 0 knows; nothing is pickled)."""
     mine = shard_pages(len(pages), rank, world)
     local = [(i, np.ascontiguousarray(predict_fn(pages[i]))) for i in mine]
     if world == 1:
         return [lab for _, lab in local]
     if not gather:
         return None
+    import torch
     import torch.distributed as dist
-    bucket = [None] * world if rank == 0 else None
-    dist.gather_object(local, bucket, dst=0)
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    dtype = local[0][1].dtype if local else None
+    # every rank tells rank 0 the dtype code of its maps (a rank may own no page)
+    code = torch.tensor([{None: 0, np.dtype(np.uint8): 1, np.dtype(np.int64): 2}.get(np.dtype(dtype) if dtype is not None else None, 3)],
+                        dtype=torch.int64, device=dev)
+    codes = [torch.zeros_like(code) for _ in range(world)] if rank == 0 else None
+    dist.gather(code, codes, dst=0)
     if rank != 0:
+        for _, lab in local:
+            dist.send(torch.from_numpy(lab).to(dev), dst=0)
         return None
     out: List[Optional[np.ndarray]] = [None] * len(pages)
-    for part in bucket:
-        for i, lab in part:
-            out[i] = lab
+    for i, lab in local:
+        out[i] = lab
+    tdt = {1: torch.uint8, 2: torch.int64}
+    for i in range(len(pages)):                      # page order = interleaved rank order: every sender's queue is drained in its send order
+        r = i % world
+        if r == 0:
+            continue
+        c = int(codes[r].item())
+        if c not in tdt:
+            raise ValueError("rank %d sends label maps of an unsupported dtype" % r)
+        buf = torch.empty(tuple(pages[i].shape[:2]), dtype=tdt[c], device=dev)
+        dist.recv(buf, src=r)
+        out[i] = buf.cpu().numpy()
     return out  # type: ignore[return-value]
 
 
@@ -54,18 +74,38 @@ def grad_tensor(engine):
     return torch.as_tensor(_DevBuf(ptr, n), device="cuda:%d" % engine.device)
 
 
-def allreduce_flat(flat, world):
+def allreduce_flat(flat, world, engine_stream=None):
     """Sum the flat gradient vector over the ranks in place (RCCL on device tensors, gloo on CPU
-    tensors in the tests).  The 1/world factor is applied by train_apply(grad_scale=1/world)."""
+    tensors in the tests).  The 1/world factor is applied by train_apply(grad_scale=1/world).
+
+    The engine writes / reads the buffer on its own HIP stream.  With `engine_stream` (the raw hipStream_t from
+    Engine.stream()) the collective is ENQUEUED in stream order -- RCCL's stream waits for the backward kernels on the
+    engine stream, the engine stream then waits for the collective, the host never blocks -- so the clip + Adam
+    kernels of train_apply queue up behind it.  (Bucketed overlap with the tail of backward is not worth having: the
+    whole gradient is 2.7 MB, ~25 us over xGMI against a 38 ms step.)  Without it the device is synchronised on both sides."""
     if world <= 1:
         return flat
     import torch
     import torch.distributed as dist
-    if flat.is_cuda:                       # the engine writes / reads the buffer on its own stream
+    if not flat.is_cuda:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+    if dist.get_backend() != "nccl":
+        # gloo rehearsal on a GPU box: stage through the host
         torch.cuda.synchronize(flat.device)
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+        torch.cuda.synchronize(flat.device)
+        return flat
+    if engine_stream:
+        ext = torch.cuda.ExternalStream(int(engine_stream), device=flat.device)
+        with torch.cuda.stream(ext):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)     # blocking form = the CURRENT (engine) stream waits, not the host
+        return flat
+    torch.cuda.synchronize(flat.device)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    if flat.is_cuda:
-        torch.cuda.synchronize(flat.device)
+    torch.cuda.synchronize(flat.device)
     return flat
 
 
@@ -74,10 +114,10 @@ def allreduce_gradients(engine, world):
     gradient (673 013 + metric slots for fcn_skip C=3, 2.7 MB) per train step."""
     if world <= 1:
         return
-    allreduce_flat(grad_tensor(engine), world)
+    allreduce_flat(grad_tensor(engine), world, engine_stream=engine.stream())
 
 
-def dp_train_epoch(n_samples, rank, world, forward_backward, flat_gradient, apply):
+def dp_train_epoch(n_samples, rank, world, forward_backward, flat_gradient, apply, engine_stream=None):
     """One data-parallel pass: rank r takes samples r, r+world, ... (ranks that run out repeat
     their last sample with zero weight so that every rank enters every all-reduce), the flat
     gradients are summed over the ranks and applied with scale 1/contributors."""
@@ -89,8 +129,13 @@ def dp_train_epoch(n_samples, rank, world, forward_backward, flat_gradient, appl
         m = forward_backward(k if live else n_samples - 1)
         g = flat_gradient()
         if not live:
-            g.zero_()
-        allreduce_flat(g, world)
+            if engine_stream and g.is_cuda:
+                import torch
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(engine_stream), device=g.device)):
+                    g.zero_()           # behind the backward kernels that wrote it, on the engine's stream
+            else:
+                g.zero_()
+        allreduce_flat(g, world, engine_stream=engine_stream)
         contributors = min(world, n_samples - st * world)
         apply(1.0 / contributors)
         if live:

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "pseg_common.h"
 
@@ -149,6 +150,13 @@ __device__ __forceinline__ void top2_classes(const f32x4 z, int c0, int C, float
             bi = take ? oi : bi;
         }
     }
+}
+
+typedef short pk_i16x2 __attribute__((ext_vector_type(2)));
+// ReLU of two packed bf16 values in one v_pk_max_i16: a negative bf16 is a negative int16 (floor = 0), floor = -32768 leaves
+// the values alone.  Equals rounding max(v, 0): rounding is monotone and -0.0 (0x8000) becomes +0 either way.
+__device__ __forceinline__ uint32_t relu_pk_bf16(uint32_t v, uint32_t floor2) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_i16x2, v), __builtin_bit_cast(pk_i16x2, floor2)));
 }
 
 __device__ __forceinline__ uint4 relu_bf16x8(uint4 v) {
@@ -296,6 +304,9 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the bias is the accumulators' start value (the first MFMA's C operand) in every instance, as in conv12_ws_kernel:
+    // no epilogue adds it, and all paths of the engine round in one order
+    constexpr bool c_bias0 = true;
 
     const uint16_t* wsrc = a.wpk + ((size_t)nb * a.GK * NT + wave) * 512 + lane * 8;
     const size_t wgstride = (size_t)a.nb_total * a.GK * NT * 512;   // elements per group
@@ -331,6 +342,12 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     float4 biasr[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) biasr[t] = *(const float4*)(a.bias + (nb * NT + t) * 16 + 4 * g);
+    if constexpr (c_bias0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{biasr[n].x, biasr[n].y, biasr[n].z, biasr[n].w};
+    }
     const int D = a.NB > 1 ? a.NB - 1 : 1;  // prefetch distance in groups (NB == 1: single resident group)
     for (int q = 0; q < D && q < G; ++q) stage_w(q, q);
     int slot_c = 0;             // ring slot of the group being computed
@@ -355,7 +372,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = c_bias0 ? f32x4{biasr[n].x, biasr[n].y, biasr[n].z, biasr[n].w} : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     int gq = 0;  // global group index
     long long acc_wait = 0, acc_issue = 0;   // PSEG_DIAG: cycles of wave 0 in group waits / weight-DMA issue
@@ -445,7 +463,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             // remainder slot is real only for wave 0 -- the others redo theirs, same values).
             static_assert(HR % 4 == 0 && HC == 36, "conv1 tile walk: halo rows in fours, two 16-pixel tiles + 4 columns per row");
             auto c1_tile = [&](const char* src, char* dst, bool inc) {
-                f32x4 z0 = f32x4{0.f, 0.f, 0.f, 0.f}, z1 = z0;
+                // the bias is the accumulators' start value (one rounding order for every first-layer kernel of the engine)
+                f32x4 z0 = f32x4{b1a.x, b1a.y, b1a.z, b1a.w}, z1 = f32x4{b1b.x, b1b.y, b1b.z, b1b.w};
 #pragma unroll
                 for (int s1 = 0; s1 < 2; ++s1) {
                     // kernel row ky = g (first k-step) or 4 (second; rows past the kernel carry zero weights)
@@ -454,14 +473,11 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
                     z0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s1][0], __builtin_bit_cast(bf16x8, xv), z0, 0, 0, 0);
                     z1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s1][1], __builtin_bit_cast(bf16x8, xv), z1, 0, 0, 0);
                 }
-                float v0 = z0[0] + b1a.x, v1 = z0[1] + b1a.y, v2 = z0[2] + b1a.z, v3 = z0[3] + b1a.w;
-                float u0 = z1[0] + b1b.x, u1 = z1[1] + b1b.y, u2 = z1[2] + b1b.z, u3 = z1[3] + b1b.w;
-                if (a.f1_relu) {
-                    v0 = vmax(v0, 0.f); v1 = vmax(v1, 0.f); v2 = vmax(v2, 0.f); v3 = vmax(v3, 0.f);
-                    u0 = vmax(u0, 0.f); u1 = vmax(u1, 0.f); u2 = vmax(u2, 0.f); u3 = vmax(u3, 0.f);
-                }
-                uint2 pa = make_uint2(pk_bf16(v0, v1), pk_bf16(v2, v3));
-                uint2 pb = make_uint2(pk_bf16(u0, u1), pk_bf16(u2, u3));
+                // round, then ReLU on the packed pairs (the MFMA results must be read by instructions the compiler's hazard
+                // recogniser sees -- an inline-asm v_max straight on them reads before they have landed)
+                const uint32_t fl2 = a.f1_relu ? 0u : 0x80008000u;
+                uint2 pa = make_uint2(relu_pk_bf16(pk_bf16(z0[0], z0[1]), fl2), relu_pk_bf16(pk_bf16(z0[2], z0[3]), fl2));
+                uint2 pb = make_uint2(relu_pk_bf16(pk_bf16(z1[0], z1[1]), fl2), relu_pk_bf16(pk_bf16(z1[2], z1[3]), fl2));
                 if (!inc) { pa = make_uint2(0, 0); pb = make_uint2(0, 0); }   // halo outside the canvas = conv2's zero padding
                 *(uint2*)(dst + g * 8) = pa;                  // couts 4g .. 4g+3
                 if (g < 2) *(uint2*)(dst + 32 + g * 8) = pb;  // couts 16..19 (g = 0), zero pad 20..23 (g = 1)
@@ -621,12 +637,14 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             // two-stage software pipeline: the fragments of k-step s+1 are in flight while the
             // MFMAs of k-step s issue (A/B are static register sets; index clamped at the tail).
             bf16x8 xa[MT], wa[NT], xb[MT], wbq[NT];
+            // (read order = the order the next step's MFMAs need them: cout tile 0, the pixel tiles, the other cout tiles)
 #define PSEG_LOAD(XF, WF, S, OFF)                                                                \
             {                                                                                    \
                 const int s_ = (S) < n ? (S) : n - 1;                                            \
+                WF[0] = *(const bf16x8*)(wb + (s_ * NT) * 1024);                                 \
                 _Pragma("unroll") for (int m = 0; m < MT; ++m)                                   \
                     XF[m] = *(const bf16x8*)(in_t + pixbase[m] + OFF);                           \
-                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                   \
+                _Pragma("unroll") for (int t = 1; t < NT; ++t)                                   \
                     WF[t] = *(const bf16x8*)(wb + (s_ * NT + t) * 1024);                         \
             }
 #define PSEG_TAB(S) tb[((S) < n ? (S) : n - 1) * 4]
@@ -634,23 +652,33 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             _Pragma("unroll") for (int t = 0; t < NT; ++t)                                       \
                 _Pragma("unroll") for (int m = 0; m < MT; ++m)                                   \
                     acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[t], XF[m], acc[m][t], 0, 0, 0);
+            // One scheduling region per k-step: its MT x NT MFMAs with the fragment reads of the NEXT k-step issued between them
+            // (one read and one address add behind each MFMA).  Issuing all reads first and then all MFMAs -- the earlier
+            // form -- left the matrix pipe idle while the wave issued its reads; co-resident waves filled only part of that.
+#define PSEG_INTERLEAVE                                                                          \
+            _Pragma("unroll") for (int q_ = 0; q_ < MT * NT; ++q_) {                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                \
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                \
+            }
             int offa = PSEG_TAB(0), offb = PSEG_TAB(1);
             PSEG_LOAD(xa, wa, 0, offa)
             int s = 0;
             for (; s + 2 <= n; s += 2) {
                 __builtin_amdgcn_sched_barrier(0);
+                offa = PSEG_TAB(s + 2);                     // the table read goes first: the next region opens with its result
                 PSEG_LOAD(xb, wbq, s + 1, offb)
-                offa = PSEG_TAB(s + 2);
-                __builtin_amdgcn_sched_barrier(0);
                 PSEG_MMA(xa, wa)
+                PSEG_INTERLEAVE
                 __builtin_amdgcn_sched_barrier(0);
-                PSEG_LOAD(xa, wa, s + 2, offa)
                 offb = PSEG_TAB(s + 3);
-                __builtin_amdgcn_sched_barrier(0);
+                PSEG_LOAD(xa, wa, s + 2, offa)
                 PSEG_MMA(xb, wbq)
+                PSEG_INTERLEAVE
             }
             __builtin_amdgcn_sched_barrier(0);
             if (n & 1) { PSEG_MMA(xa, wa) }
+#undef PSEG_INTERLEAVE
 #undef PSEG_TAB
 #undef PSEG_LOAD
 #undef PSEG_MMA
@@ -665,6 +693,9 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     do {
     // ---- epilogue -----------------------------------------------------------------------------
     // D layout: lane holds pixel (lane & 15) x couts 4*(lane>>4) .. +3 of each 16x16 tile.
+    // The inline-asm max / DPP instructions below may be the first readers of accumulator registers, and the compiler's
+    // hazard recogniser does not look inside inline asm: let the last MFMAs of the k-loop (8 passes) retire first.
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     if (c_dbg & 4) { if (acc[0][0][0] == 123.456f) a.dst[0] = 1; return; }
     if constexpr (NT == 4 || NT == 8) {
         if (c_tail) {
@@ -689,13 +720,12 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
                     const int ab = ab0 + abl;
                     const int y = 2 * hy + (ab >> 1), x = 2 * hx + (ab & 1);
                     const bool inb = (y < a.H0 && x < a.W0);
-                    const float4 b0 = biasr[2 * abl], b1 = biasr[2 * abl + 1];
                     const f32x4 t0 = acc[m][2 * abl], t1 = acc[m][2 * abl + 1];
                     uint4 dq;
-                    dq.x = pk_bf16(t0[0] + b0.x, t0[1] + b0.y);
-                    dq.y = pk_bf16(t0[2] + b0.z, t0[3] + b0.w);
-                    dq.z = pk_bf16(t1[0] + b1.x, t1[1] + b1.y);
-                    dq.w = pk_bf16(t1[2] + b1.z, t1[3] + b1.w);
+                    dq.x = pk_bf16(t0[0], t0[1]);        // (the deconv bias was the accumulators' start value)
+                    dq.y = pk_bf16(t0[2], t0[3]);
+                    dq.z = pk_bf16(t1[0], t1[1]);
+                    dq.w = pk_bf16(t1[2], t1[3]);
                     f32x4 z = f32x4{lb.x, lb.y, lb.z, lb.w};
                     z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, dq), z, 0, 0, 0);
                     if (a.skip)
@@ -761,9 +791,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
                 const int n = (nb * NT + t) * 16 + 4 * g;
                 const int ab = n / a.CoP, co = n - ab * a.CoP;
                 if (ab >= 4) continue;
-                const float4 bv = biasr[t];
-                float v0 = acc[m][t][0] + bv.x, v1 = acc[m][t][1] + bv.y;
-                float v2 = acc[m][t][2] + bv.z, v3 = acc[m][t][3] + bv.w;
+                float v0 = acc[m][t][0], v1 = acc[m][t][1];
+                float v2 = acc[m][t][2], v3 = acc[m][t][3];
                 if (a.relu) {
                     v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
                     v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
@@ -801,8 +830,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                float v0 = acc[m][t][0] + biasr[t].x, v1 = acc[m][t][1] + biasr[t].y;
-                float v2 = acc[m][t][2] + biasr[t].z, v3 = acc[m][t][3] + biasr[t].w;
+                float v0 = acc[m][t][0], v1 = acc[m][t][1];
+                float v2 = acc[m][t][2], v3 = acc[m][t][3];
                 if (c_add) {
                     v0 += d_bf2f((uint16_t)(adr[t].x & 0xffff)); v1 += d_bf2f((uint16_t)(adr[t].x >> 16));
                     v2 += d_bf2f((uint16_t)(adr[t].y & 0xffff)); v3 += d_bf2f((uint16_t)(adr[t].y >> 16));
@@ -897,8 +926,7 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            v[m][0] = acc[m][t][0] + biasr[t].x; v[m][1] = acc[m][t][1] + biasr[t].y;
-            v[m][2] = acc[m][t][2] + biasr[t].z; v[m][3] = acc[m][t][3] + biasr[t].w;
+            v[m][0] = acc[m][t][0]; v[m][1] = acc[m][t][1]; v[m][2] = acc[m][t][2]; v[m][3] = acc[m][t][3];
             const unsigned o = (pixoff[m] == OOBS || noff == OOBS) ? OOBS : pixoff[m] + noff;
             if (c_add) {
                 const uint2 ad = adr[m];
@@ -963,6 +991,370 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
 #undef PSEG_STAMP
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// conv1 + conv2 (+ pool, + skip logits) of fcn / fcn_skip as a persistent, WAVE-SPECIALISED kernel: the dominant launch
+// of the page (27 % of the FLOPs).  One 512-thread workgroup per CU walks its tiles (16 x 32 output pixels each):
+//   * waves 4-7 (one per SIMD) are PRODUCERS: they recompute conv1 (1 -> 20, k5, ReLU) on the next tile's 20 x 36 halo
+//     straight from the uint8 page (x/255 fused) into one of TWO conv2 input tiles in LDS.  A producer wave owns five halo
+//     rows: it loads the nine page rows they need, keeps its two shifted bf16 copies of them in an LDS area of its own and
+//     reads only that area, so the producers never wait for each other;
+//   * waves 0-3 (one per SIMD) are CONSUMERS: the implicit-GEMM k-loop of conv2 on the current tile (19 k-steps x 16
+//     MFMAs, weights resident in LDS for the whole kernel, two-stage software pipeline) and the epilogue from registers
+//     (bias, fused 2x2 max-pool, the logits layer's skip rows by one more MFMA);
+//   * ONE s_barrier per tile hands the filled tile to the consumers and the drained one back to the producers.
+// In conv_mfma_kernel<.., FL_FUSE1 | FL_PERSIST> every wave did staging, k-loop and epilogue in turn and only the k-loop
+// (a third of a tile's life) fed the matrix pipe; here the SIMD's matrix pipe belongs to a wave that does little else
+// while the VALU / LDS-write work of the first layer runs beside it on the same SIMD.
+// Arithmetic and summation order per output are those of the fused kernel (same k-chunk order, same packing): the two
+// produce identical bits (tests/test_bf16_gpu.py).
+// ---------------------------------------------------------------------------------------------
+constexpr int WS_ROWP = 1744;     // row pitch of the dense sigma = 3 tile ((36 * 3 + 1) slots, pair_chunks' choice)
+constexpr int WS_KSTEPS = 19;     // 25 taps x 3 chunks = 75 k-chunks + 1 dummy
+
+template <bool SKIPLOG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv12_ws_kernel(MConv a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 8, NT = 2, TH = 16, HR = TH + 4, HC = TW + 4, PS2 = 48, ROWP = WS_ROWP, KSTEPS = WS_KSTEPS;
+    constexpr int UCB = 96, PR = 9;                       // producer staging: bytes per copy row (48 px), page rows per wave
+    constexpr int PRIV = 2 * PR * UCB + 16;               // two shifted copies + a 16-byte sink for stores that carry nothing
+    static_assert(HR % 4 == 0 && HR / 4 == 5, "a producer wave owns five halo rows");
+    const int TB = a.lds_w_off;                           // bytes of one input tile (HR rows), 16-aligned (host)
+    char* const w_t = smem + 2 * TB;
+    int* const tab_l = (int*)(w_t + KSTEPS * NT * 1024);
+    char* const priv_all = (char*)tab_l + ((KSTEPS * 16 + 15) & ~15);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, g = lane >> 4;
+    const int tiles_x = (a.Wout + TW - 1) / TW;
+    auto xcd_tile = [&](int t) {
+        if (a.xq < 0) return t;
+        const int x = t & 7, j = t >> 3;
+        return x * a.xq + min(x, a.xr) + j;
+    };
+    // ---- resident weights + k-chunk table: once per workgroup ------------------------------------------------------
+    {
+        for (int pc = wave; pc < KSTEPS * NT; pc += 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wpk + (size_t)pc * 512 + lane * 8),
+                                             (__attribute__((address_space(3))) void*)(w_t + pc * 1024), 16, 0, 0);
+        if (tid < KSTEPS * 4) tab_l[tid] = a.tab_full[tid];
+    }
+    const int n_my = ((int)a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
+
+    if (wave >= 4) {
+        // =============================== PRODUCERS ===============================
+        const int pw = wave - 4;
+        char* const priv = priv_all + pw * PRIV;
+        if ((a.dbg & 0x300) == 0x100) __builtin_amdgcn_s_setprio(1);   // PSEG_WS_PRIO=1: the producers win issue arbitration
+        bf16x8 w1[2][2];
+#pragma unroll
+        for (int s1 = 0; s1 < 2; ++s1)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) w1[s1][q] = *(const bf16x8*)(a.f1_wpk + ((size_t)(s1 * 2 + q) * 64 + lane) * 8);
+        const float4 b1a = *(const float4*)(a.f1_bias + 4 * g), b1b = *(const float4*)(a.f1_bias + 16 + 4 * g);
+        const f32x4 zb0 = f32x4{b1a.x, b1a.y, b1a.z, b1a.w}, zb1 = f32x4{b1b.x, b1b.y, b1b.z, b1b.w};
+        const uint32_t floor2 = a.f1_relu ? 0u : 0x80008000u;
+        const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc((void*)a.f1_img, 0, (unsigned)((size_t)a.f1_H * a.f1_W), 0x00020000);
+        // the wave's 12 first-layer tiles: five rows x two full 16-pixel column tiles (ct = 0, 1), the four remainder
+        // columns of rows 0-3 in one tile (type 2) and of row 4 in another (type 3: its surplus lanes redo row 4).
+        // Per-lane constants of the four tile types: page-copy offsets of k-step 0 (kernel row g) and k-step 1 (kernel
+        // row 4), the tile-buffer offsets of the two 8-byte stores (couts 4g..4g+3; then couts 16..19 / the zero pad
+        // 20..23 for g < 2 -- the other lanes repeat their first store, which keeps the code branch-free).
+        int srcA[4], srcB[4], dst1[4], dst2[4], hxT[4], jT[4];
+        const int sink = (int)(priv - smem) + 2 * PR * UCB + (g & 1) * 8;      // lanes g >= 2: their second store goes nowhere
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            const int hx = ty < 2 ? ty * 16 + p16 : 32 + (p16 & 3);
+            const int j = ty < 2 ? 0 : (ty == 2 ? (p16 >> 2) : 4);          // row inside the band (full tiles add it as an immediate)
+            const int c = (hx & 1) * (PR * UCB) + (hx & ~1) * 2 + j * UCB;
+            srcA[ty] = c + g * UCB;
+            srcB[ty] = c + 4 * UCB;
+            const int d = hx * PS2 + (5 * pw + j) * ROWP;
+            dst1[ty] = d + g * 8;
+            dst2[ty] = d + 32 + g * 8;
+            hxT[ty] = hx; jT[ty] = j;
+        }
+        const bool low_g = g < 2;
+        float ubf[PR];
+        auto tile_origin = [&](int i, int& oy, int& ox) {
+            const int t = xcd_tile((int)blockIdx.x + i * (int)gridDim.x);
+            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+            oy = ty * TH; ox = tx * TW;
+        };
+        auto load_u8 = [&](int oy, int ox) {
+            const int xg = ox - 4 + lane, y0 = oy - 4 + 5 * pw;
+            if (oy >= 4 && ox >= 4 && oy + TH + 4 <= a.f1_H && ox + TW + 4 <= a.f1_W) {
+                // the whole 24 x 40 page tile lies inside the page (every tile but the border ones): one lane offset, the
+                // row step rides in the scalar offset
+                const unsigned off = (unsigned)(y0 * a.f1_W + ox - 4 + min(lane, HC + 3));
+#pragma unroll
+                for (int u = 0; u < PR; ++u) ubf[u] = (float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rimg, off, u * a.f1_W, 0);
+                return;
+            }
+            const bool colok = lane < HC + 4 && xg >= 0 && xg < a.f1_W;
+#pragma unroll
+            for (int u = 0; u < PR; ++u) {
+                const int y = y0 + u;                                   // wave-uniform
+                const bool ok = colok && y >= 0 && y < a.f1_H;
+                const unsigned off = ok ? (unsigned)(y * a.f1_W + xg) : 0xfffffff0u;   // out of range reads 0
+                ubf[u] = (float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rimg, off, 0, 0);
+            }
+        };
+        int noy = 0, nox = 0;                               // origin of the tile whose page bytes sit in ubf
+        auto fill = [&](int i, int bufoff) {                // tile number i of this workgroup -> smem + bufoff; ubf holds its page bytes
+            const int oy0 = noy, ox0 = nox;
+            if (lane < 48) {
+                char* pA = priv + lane * 2;
+#pragma unroll
+                for (int u = 0; u < PR; ++u) *(uint16_t*)(pA + u * UCB) = d_f2bf(ubf[u] * 0.00392156886f);
+                if (lane >= 1) {
+#pragma unroll
+                    for (int u = 0; u < PR; ++u) *(uint16_t*)(pA + PR * UCB - 2 + u * UCB) = d_f2bf(ubf[u] * 0.00392156886f);
+                }
+            }
+            if (i + 1 < n_my) {                            // the next tile's bytes: their latency hides under this tile's conv1
+                tile_origin(i + 1, noy, nox);
+                load_u8(noy, nox);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own copies (nobody else reads them)
+            // a halo pixel outside the canvas is conv2's zero padding, not conv1(0): only tiles on the canvas border have any
+            const bool interior = oy0 >= 2 && ox0 >= 2 && oy0 + TH + 2 <= a.Hin && ox0 + TW + 2 <= a.Win;   // wave-uniform
+            bool colT[4], incT[4];
+#pragma unroll
+            for (int ty = 0; ty < 4; ++ty) {
+                const int gx = ox0 - 2 + hxT[ty];
+                colT[ty] = gx >= 0 && gx < a.Win;
+                const int gy = oy0 - 2 + 5 * pw + jT[ty];
+                incT[ty] = colT[ty] && gy >= 0 && gy < a.Hin;
+            }
+            // straight-line, three batches of four tiles: all fragment reads of a batch, its 16 MFMAs (the two k-steps of a
+            // tile are eight MFMAs apart), then the four epilogues -- no branches inside, so the scheduler overlaps the batches
+            auto batches = [&](auto border_tag) {
+                constexpr bool BORDER = decltype(border_tag)::value;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    uint4 xa[4], xb[4];
+                    int d1[4], d2[4];
+                    bool inc[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = b * 4 + q;                       // tiles 0-4: ct 0 rows 0-4, 5-9: ct 1, 10: type 2, 11: type 3
+                        const int ty = k < 5 ? 0 : (k < 10 ? 1 : k - 8);
+                        const int j = k < 10 ? k % 5 : 0;              // immediate row step of the full tiles
+                        const uint32_t* ra = (const uint32_t*)(priv + srcA[ty] + j * UCB);
+                        const uint32_t* rb = (const uint32_t*)(priv + srcB[ty] + j * UCB);
+                        xa[q] = make_uint4(ra[0], ra[1], ra[2], ra[3]);
+                        xb[q] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
+                        d1[q] = bufoff + dst1[ty] + j * ROWP;
+                        d2[q] = low_g ? bufoff + dst2[ty] + j * ROWP : sink;
+                        inc[q] = true;
+                        if constexpr (BORDER) {
+                            if (k < 10) { const int gy = oy0 - 2 + 5 * pw + j; inc[q] = colT[ty] && gy >= 0 && gy < a.Hin; }
+                            else inc[q] = incT[ty];
+                        }
+                    }
+                    f32x4 z0[4], z1[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        z0[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[0][0], __builtin_bit_cast(bf16x8, xa[q]), zb0, 0, 0, 0);
+                        z1[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[0][1], __builtin_bit_cast(bf16x8, xa[q]), zb1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        z0[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[1][0], __builtin_bit_cast(bf16x8, xb[q]), z0[q], 0, 0, 0);
+                        z1[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[1][1], __builtin_bit_cast(bf16x8, xb[q]), z1[q], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t pa0 = relu_pk_bf16(pk_bf16(z0[q][0], z0[q][1]), floor2), pa1 = relu_pk_bf16(pk_bf16(z0[q][2], z0[q][3]), floor2);
+                        uint32_t pb0 = relu_pk_bf16(pk_bf16(z1[q][0], z1[q][1]), floor2), pb1 = relu_pk_bf16(pk_bf16(z1[q][2], z1[q][3]), floor2);
+                        if constexpr (BORDER) {
+                            pa0 = inc[q] ? pa0 : 0u; pa1 = inc[q] ? pa1 : 0u;
+                            pb0 = inc[q] ? pb0 : 0u; pb1 = inc[q] ? pb1 : 0u;
+                        }
+                        *(uint2*)(smem + d1[q]) = make_uint2(pa0, pa1);
+                        *(uint2*)(smem + d2[q]) = make_uint2(pb0, pb1);
+                    }
+                }
+            };
+            if (interior) batches(std::false_type{});
+            else batches(std::true_type{});
+        };
+        tile_origin(0, noy, nox);
+        load_u8(noy, nox);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // weight DMA pieces of this wave + the first page bytes
+        lds_barrier();                                         // (A) weights and table resident
+        fill(0, 0);
+        lds_barrier();                                         // (B) tile 0 is full
+        long long tf = 0, tw = 0;
+        for (int i = 0; i < n_my; ++i) {
+            const long long c0 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            if (i + 1 < n_my) fill(i + 1, ((i + 1) & 1) * TB);
+            const long long c1 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            lds_barrier();                                     // tile i + 1 full, tile i drained
+            if (a.trace) { tf += c1 - c0; tw += (long long)__builtin_amdgcn_s_memtime() - c1; }
+        }
+        if (a.trace && lane == 0) {
+            unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 4;
+            o[0] = (unsigned long long)tf; o[1] = 0; o[2] = (unsigned long long)tw; o[3] = (unsigned long long)n_my;
+        }
+        return;
+    }
+
+    // =============================== CONSUMERS ===============================
+    // A wave owns four rows x 32 pixels of the tile = eight 16-pixel tiles m (row m >> 1, column tile m & 1) x two cout tiles.
+    // The tile is computed in TWO PHASES of four pixel tiles each (rows 0-1, then rows 2-3): while a phase's 19 k-steps
+    // accumulate one half, the epilogue of the half finished just before -- bias is already in, fused 2x2 max-pool (its row
+    // pairs lie inside a half), bf16 rounding, the skip-logits MFMAs, all stores -- is issued in pieces between that phase's
+    // MFMAs.  A wave alone on its SIMD's matrix pipe therefore never leaves it to run an epilogue: only the very last half of
+    // the workgroup's last tile drains on its own.  (Cost: the A fragments are read once per phase, +20 % LDS reads.)
+    // B fragment of pixel tile m for k-step s: one ds_read_b128 at (tile + lane pixel + chunk offset of (s, g)) + an
+    // immediate ((m >> 1) rows, (m & 1) * 16 pixels); A fragment (s, t): weights + lane * 16 + an immediate.  The 19 chunk
+    // offsets of this lane group stay in registers for the whole kernel.
+    if ((a.dbg & 0x300) == 0x200) __builtin_amdgcn_s_setprio(1);       // PSEG_WS_PRIO=2: the consumers win issue arbitration
+    const float4 bias0 = *(const float4*)(a.bias + 4 * g), bias1 = *(const float4*)(a.bias + 16 + 4 * g);
+    bf16x8 wq;
+    if constexpr (SKIPLOG) wq = *(const bf16x8*)(a.tail_wa + lane * 8);
+    const int CsO = a.nch_out * 8;
+    constexpr unsigned OOBS = 0xfffffff0u;
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, a.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)a.pool_dst, 0, a.pool_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(SKIPLOG ? (void*)a.skip_logits : (void*)a.dst), 0,
+                                                                        SKIPLOG ? (unsigned)((size_t)a.Hout * a.Wout * a.skip_CP * 4) : 0u, 0x00020000);
+    const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
+    const unsigned noff0 = 4 * g < CsO ? (unsigned)(4 * g) * 2u : OOBS, noff1 = 16 + 4 * g < CsO ? (unsigned)(16 + 4 * g) * 2u : OOBS;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // weight DMA pieces of this wave
+    lds_barrier();                                             // (A)
+    int offv[KSTEPS];
+#pragma unroll
+    for (int s2 = 0; s2 < KSTEPS; ++s2) offv[s2] = tab_l[s2 * 4 + g] + (wave * (MT / 2)) * ROWP + p16 * PS2;
+    const char* const wb = w_t + lane * 16;
+    lds_barrier();                                             // (B)
+
+    f32x4 accA[4][NT], accB[4][NT];                            // the two halves: pixel tiles 0-3 (rows 0, 1) and 4-7 (rows 2, 3)
+    uint2 pks[NT][4];                                          // bf16 pairs of the half being drained (B operand of the skip-logits MFMA)
+    // one piece of the epilogue of half `HB` (0: rows 0-1, 1: rows 2-3) of the tile at (doy, dox); `acc` holds it
+    // P(t2, c): column tile c (local tiles c and c + 2 are vertical neighbours): rounding + pool + stores of cout tile t2
+    auto piece_P = [&](f32x4 (&acc)[4][NT], int hb, int doy, int dox, bool valid, auto t2c, auto cc) {
+        constexpr int t2 = decltype(t2c)::value, c = decltype(cc)::value;
+        const unsigned noff = t2 == 0 ? noff0 : noff1;
+        float q[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = vmax_xor1(vmax(acc[c][t2][r], acc[c + 2][t2][r]));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 v = acc[c + 2 * h][t2];
+            const uint2 pk = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+            if constexpr (SKIPLOG) pks[t2][c + 2 * h] = pk;
+            else {
+                const int y = doy + wave * (MT / 2) + 2 * hb + h, x = dox + c * 16 + p16;
+                const unsigned o = (valid && y < a.Hout && x < a.Wout && noff != OOBS) ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) + noff : OOBS;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
+            }
+        }
+        const int y = (doy >> 1) + wave * (MT / 4) + hb;
+        const int x = (dox >> 1) + ((c * 16 + p16) >> 1);
+        const bool ok = valid && !(p16 & 1) && y < Ho2 && x < Wo2 && noff != OOBS;
+        const unsigned o = ok ? (unsigned)(y * Wo2 + x) * (unsigned)(CsO * 2) + noff : OOBS;
+        const uint2 pk = make_uint2(pk_bf16(q[0], q[1]), pk_bf16(q[2], q[3]));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rp, o, 0, 0);
+    };
+    // S(c): the skip-logits products of local tiles c and c + 2 (both cout tiles rounded by then)
+    auto piece_S = [&](int hb, int doy, int dox, bool valid, auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (SKIPLOG) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int lm = c + 2 * h;
+                f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, __builtin_bit_cast(bf16x8, make_uint4(pks[0][lm].x, pks[0][lm].y, pks[1][lm].x, pks[1][lm].y)), z, 0, 0, 0);
+                const int y = doy + wave * (MT / 2) + 2 * hb + h, x = dox + c * 16 + p16;
+                const unsigned o = (valid && y < a.Hout && x < a.Wout && 4 * g < a.skip_CP) ? ((unsigned)(y * a.Wout + x) * (unsigned)a.skip_CP + 4u * g) * 4u : OOBS;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, z), rs, o, 0, 0);
+            }
+        }
+    };
+    // one phase: accumulate half `hb` of the tile in `in_t` into `acc`; between the MFMAs, drain `dacc` = half `dhb` of the tile
+    // at (doy, dox) (valid = such a half exists)
+    auto phase = [&](const char* in_t, f32x4 (&acc)[4][NT], auto hbc, f32x4 (&dacc)[4][NT], int dhb, int doy, int dox, bool valid) {
+        constexpr int hb = decltype(hbc)::value;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {                           // start value = bias (the first MFMA's C operand: no add later)
+            acc[m][0] = f32x4{bias0.x, bias0.y, bias0.z, bias0.w};
+            acc[m][1] = f32x4{bias1.x, bias1.y, bias1.z, bias1.w};
+        }
+        bf16x8 xs[2][4], ws2[2][NT];
+#define WS_LOAD(SET, S)                                                                                   \
+        {                                                                                                 \
+            const char* va_ = in_t + offv[S];                                                             \
+            ws2[SET][0] = *(const bf16x8*)(wb + ((S) * NT) * 1024);                                       \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                 \
+                xs[SET][m] = *(const bf16x8*)(va_ + (2 * hb + (m >> 1)) * ROWP + (m & 1) * 16 * PS2);     \
+            ws2[SET][1] = *(const bf16x8*)(wb + ((S) * NT + 1) * 1024);                                   \
+        }
+        WS_LOAD(0, 0)
+#pragma unroll
+        for (int s2 = 0; s2 < KSTEPS; ++s2) {
+            __builtin_amdgcn_sched_barrier(0);                  // a k-step is one scheduling region
+            if (s2 + 1 < KSTEPS) WS_LOAD((s2 + 1) & 1, s2 + 1)
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[m][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws2[s2 & 1][t2], xs[s2 & 1][m], acc[m][t2], 0, 0, 0);
+            // the drained half's epilogue, one piece per k-step (P needs nothing; S(c) needs P(0, c) and P(1, c))
+            if (s2 == 1) piece_P(dacc, dhb, doy, dox, valid, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            if (s2 == 3) piece_P(dacc, dhb, doy, dox, valid, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            if (s2 == 5) piece_S(dhb, doy, dox, valid, std::integral_constant<int, 0>{});
+            if (s2 == 7) piece_P(dacc, dhb, doy, dox, valid, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            if (s2 == 9) piece_P(dacc, dhb, doy, dox, valid, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            if (s2 == 11) piece_S(dhb, doy, dox, valid, std::integral_constant<int, 1>{});
+            // issue order: the address add, then behind each MFMA one fragment read of the next step (six of them) and two
+            // VALU instructions of the epilogue piece
+            if (s2 + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (r < 6 && s2 + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#undef WS_LOAD
+    };
+    long long tk = 0, te = 0, tw = 0;
+    int poy = 0, pox = 0;
+    for (int i = 0; i < n_my; ++i) {
+        const long long c0 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const char* in_t = smem + (i & 1) * TB;
+        const int t = xcd_tile((int)blockIdx.x + i * (int)gridDim.x);
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        phase(in_t, accA, std::integral_constant<int, 0>{}, accB, 1, poy, pox, i > 0);     // rows 0-1; drains rows 2-3 of the previous tile
+        phase(in_t, accB, std::integral_constant<int, 1>{}, accA, 0, oy0, ox0, true);      // rows 2-3; drains rows 0-1 of this tile
+        poy = oy0; pox = ox0;
+        const long long c2 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        lds_barrier();                                         // tile i drained, tile i + 1 full
+        if (a.trace) { tk += c2 - c0; tw += (long long)__builtin_amdgcn_s_memtime() - c2; }
+    }
+    {   // rows 2-3 of the last tile: nothing left to hide behind
+        const long long c1 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // (inline-asm readers of accumulator registers follow)
+        piece_P(accB, 1, poy, pox, n_my > 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        piece_P(accB, 1, poy, pox, n_my > 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        piece_S(1, poy, pox, n_my > 0, std::integral_constant<int, 0>{});
+        piece_P(accB, 1, poy, pox, n_my > 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        piece_P(accB, 1, poy, pox, n_my > 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        piece_S(1, poy, pox, n_my > 0, std::integral_constant<int, 1>{});
+        if (a.trace) te += (long long)__builtin_amdgcn_s_memtime() - c1;
+    }
+    if (a.trace && lane == 0) {
+        unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 4;
+        o[0] = (unsigned long long)tk; o[1] = (unsigned long long)te; o[2] = (unsigned long long)tw; o[3] = (unsigned long long)n_my;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Composed tail (fcn / fcn_skip): Conv2DTranspose k2 s2 (linear) -> [concat skip] -> crop ->
@@ -1177,7 +1569,8 @@ __global__ __launch_bounds__(256) void tail_fused2_kernel(Tail2 a) {
             acc[t] = f32x4{bt[t].x + sv.x, bt[t].y + sv.y, bt[t].z + sv.z, bt[t].w + sv.w};
         }
         // ---- inner deconv: d4[co][pixel] for this wave's sub-pixel ----
-        f32x4 d4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // (bias = start value, as every MFMA conv of the engine: the stand-alone deconv kernel rounds the same way)
+        f32x4 d4[2] = {f32x4{bq[0].x, bq[0].y, bq[0].z, bq[0].w}, f32x4{bq[1].x, bq[1].y, bq[1].z, bq[1].w}};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1186,8 +1579,8 @@ __global__ __launch_bounds__(256) void tail_fused2_kernel(Tail2 a) {
         uint32_t pk[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            pk[t][0] = pk_bf16(vmax(d4[t][0] + bq[t].x, 0.f), vmax(d4[t][1] + bq[t].y, 0.f));
-            pk[t][1] = pk_bf16(vmax(d4[t][2] + bq[t].z, 0.f), vmax(d4[t][3] + bq[t].w, 0.f));
+            pk[t][0] = relu_pk_bf16(pk_bf16(d4[t][0], d4[t][1]), 0u);     // round, then ReLU on the packed pair (same value)
+            pk[t][1] = relu_pk_bf16(pk_bf16(d4[t][2], d4[t][3]), 0u);
         }
         const uint4 xd = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
         // ---- composed deconv5 o logits ----
@@ -1413,7 +1806,7 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const uint8_t* img, int
         const char* base = cp + (xl & 7) * CSTR + (xl >> 3) * 16;
         f32x4 acc[NT];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NT; ++q) acc[q] = f32x4{bv[q].x, bv[q].y, bv[q].z, bv[q].w};   // bias = start value (as the fused kernels)
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
             const int ky = min(4 * s + g, KS - 1);   // rows past the kernel carry zero weights
@@ -1425,7 +1818,7 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const uint8_t* img, int
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
             const int n = q * 16 + 4 * g;
-            float v0 = acc[q][0] + bv[q].x, v1 = acc[q][1] + bv[q].y, v2 = acc[q][2] + bv[q].z, v3 = acc[q][3] + bv[q].w;
+            float v0 = acc[q][0], v1 = acc[q][1], v2 = acc[q][2], v3 = acc[q][3];
             if (relu) {
                 v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
                 v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
@@ -2582,6 +2975,46 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     // workgroups per CU walking 12 tiles each: the 38 KB weight set and the k-chunk table are staged once per
     // workgroup instead of once per tile.  Worth 1-3 % on the fused conv1+conv2 kernel (the DMA it saves was
     // mostly hidden by the co-resident workgroup); needs the per-trip opaque lane ids to keep two waves per SIMD.
+    // wave-specialised persistent kernel (conv12_ws_kernel): one 512-thread workgroup per CU, two input tiles + the resident
+    // weights in LDS.  PSEG_NO_WS=1 falls back to the every-wave-does-everything fused instance below.
+    if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && P->MT == 8 && P->NT == 2 && P->KS == 5 && a.sigma == 3 &&
+        a.pool_dst && !a.add && !a.in_relu && !a.relu && !PSEG_KNOB("PSEG_NO_WS") && !PSEG_KNOB("PSEG_NO_PERSIST") && !PSEG_KNOB("PSEG_GENERIC") && !a.trace) {
+        const bool ws_trace = PSEG_KNOB("PSEG_WS_TRACE") != nullptr;   // developer aid: per-wave phase cycles -> gpurun_out/ws_trace.bin
+        static int cus_ws = 0;
+        int dev = 0;
+        PSEG_HIP(hipGetDevice(&dev));
+        if (!cus_ws) PSEG_HIP(hipDeviceGetAttribute(&cus_ws, hipDeviceAttributeMultiprocessorCount, dev));
+        MConv w = a;
+        const int TB = round_up(P->THH * P->row_pitch, 16);
+        w.lds_w_off = TB;                                   // the kernel's tile stride
+        w.ntiles = (int)grid.x;
+        const int lds = 2 * TB + P->ks_full * P->NT * 1024 + round_up(P->ks_full * 16, 16) + 4 * (2 * 9 * 96 + 16);
+        if (const char* pr = PSEG_KNOB("PSEG_WS_PRIO")) w.dbg |= (atoi(pr) & 3) << 8;
+        if (lds <= 160 * 1024 && P->GK >= P->ks_full && P->row_pitch == WS_ROWP && P->ks_full == WS_KSTEPS) {
+            const unsigned gx = std::min<unsigned>(grid.x, (unsigned)cus_ws);
+            static bool attr_ws[64][2] = {{false}};
+            const int sk = op.skiplog >= 0 ? 1 : 0;
+            if (!attr_ws[dev & 63][sk]) {
+                if (sk) PSEG_HIP(hipFuncSetAttribute((const void*)conv12_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                else PSEG_HIP(hipFuncSetAttribute((const void*)conv12_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_ws[dev & 63][sk] = true;
+            }
+            if (ws_trace) {
+                PSEG_HIP(hipMalloc((void**)&w.trace, (size_t)gx * 8 * 4 * 8));
+                PSEG_HIP(hipMemset(w.trace, 0, (size_t)gx * 8 * 4 * 8));
+            }
+            if (sk) conv12_ws_kernel<true><<<dim3(gx), 512, lds, st>>>(w);
+            else conv12_ws_kernel<false><<<dim3(gx), 512, lds, st>>>(w);
+            if (ws_trace) {
+                PSEG_HIP(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hbuf((size_t)gx * 8 * 4);
+                PSEG_HIP(hipMemcpy(hbuf.data(), w.trace, hbuf.size() * 8, hipMemcpyDeviceToHost));
+                (void)hipFree(w.trace);
+                if (FILE* f = fopen("gpurun_out/ws_trace.bin", "wb")) { fwrite(hbuf.data(), 8, hbuf.size(), f); fclose(f); }
+            }
+            return PSEG_OK;
+        }
+    }
     if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && !PSEG_KNOB("PSEG_NO_PERSIST") && !PSEG_KNOB("PSEG_GENERIC")) {
         static int cus = 0;   // one device model per process
         if (!cus) {

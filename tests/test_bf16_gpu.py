@@ -62,7 +62,10 @@ def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, monkeypatch, arch, C, shape):
         err = np.abs(g - a).max()
         assert err <= TOL * max(1.0, np.abs(a).max()), "%s: max err %g (max |a| %g)" % (name, err, np.abs(a).max())
     assert checked >= len(acts) - 3      # logits + at most two tensors that live only inside fused kernels
-    assert np.abs(logit - z_o).max() <= TOL * max(1.0, np.abs(z_o).max())
+    # whole-net logits: the 19- and 23-conv graphs collect more one-ulp bf16 flips (MFMA sums a k-step in hardware order and
+    # starts from the bias; the oracle adds the bias last) than the 13-layer fcn graphs: 3 % there, as tests/test_api_gpu.py
+    logit_tol = 0.03 if arch in ("unet", "res_unet") else TOL
+    assert np.abs(logit - z_o).max() <= logit_tol * max(1.0, np.abs(z_o).max())
     bad, total = _check_labels(pred, logit, z_o)
     assert np.array_equal(pred, np.argmax(logit, -1))
     assert bad == 0, "%d label mismatches outside near-ties (%d total)" % (bad, total)
@@ -247,3 +250,32 @@ def test_bf16_fused_paths_random_page_sizes(gpu, oracle_mod, monkeypatch):
         plain.close()
         for k in ("PSEG_NO_TAIL2", "PSEG_NO_SKIPLOG", "PSEG_NO_POOL_ONLY", "PSEG_NO_XCD"):
             monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("arch", ["fcn_skip", "fcn"])
+def test_bf16_wave_specialised_conv12_is_bit_identical_to_the_fused_instance(gpu, oracle_mod, monkeypatch, arch):
+    """conv12_ws_kernel (producer waves recompute conv1 into a double-buffered LDS tile, consumer waves run conv2's
+    k-loop) against the every-wave-does-everything fused instance (PSEG_NO_WS): same k order, same packing -> the same
+    bits, on page sizes around every tile edge and on a page with several tiles per workgroup."""
+    rng = np.random.default_rng(77)
+    shapes = [(1, 1), (16, 32), (17, 33), (31, 65), (96, 80), (100, 7), (129, 200), (512, 384), (1100, 900)]
+    for C in (3, 6):
+        Wt = oracle_mod.init_weights(arch, C, seed=C + 1, gain=1.5, bias_scale=0.05)
+        imgs = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in shapes]
+        ws = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
+        ws.set_weights(Wt)
+        outs = []
+        for im in imgs:
+            z, _, l = ws.predict(im, want_probs=False)
+            pooled = ws.activation("max_pooling2d")
+            outs.append((z, l, pooled))
+        ws.close()
+        monkeypatch.setenv("PSEG_NO_WS", "1")
+        ref = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
+        ref.set_weights(Wt)
+        for im, (z1, l1, p1) in zip(imgs, outs):
+            z0, _, l0 = ref.predict(im, want_probs=False)
+            assert np.array_equal(p1, ref.activation("max_pooling2d")), im.shape
+            assert np.array_equal(z1, z0) and np.array_equal(l1, l0), im.shape
+        ref.close()
+        monkeypatch.delenv("PSEG_NO_WS")

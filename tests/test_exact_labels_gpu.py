@@ -58,7 +58,8 @@ def _exact_vs_f32(gpu, arch, C, Wt, img, expect_partial=None):
                                           ("fcn_skip", 3, (33, 1)), ("unet", 3, (64, 96)), ("res_unet", 4, (96, 64))])
 def test_label_exact_small_pages_every_graph(gpu, oracle_mod, arch, C, shape):
     from pseg_amd import synth
-    img = synth.synth_page(3, shape[0], shape[1], C)[0]
+    img = (synth.synth_page(3, shape[0], shape[1], C)[0] if min(shape) >= 32
+           else np.random.default_rng(3).integers(0, 256, size=shape, dtype=np.uint8))
     Wt = oracle_mod.init_weights(arch, C, seed=42, gain=1.5, bias_scale=0.05)
     _exact_vs_f32(gpu, arch, C, Wt, img)
 

@@ -1512,12 +1512,16 @@ template <int CP>
 __global__ __launch_bounds__(256) void tail_fused2_kernel(Tail2 a) {
     constexpr int NTL = CP / 4;
     const int lane = threadIdx.x & 63, p16 = lane & 15, g = lane >> 4;
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the four waves of a workgroup are the four sub-pixel parities (row hy & 1, column b) over the SAME quarter-resolution
+    // pixels: the quarter-resolution sources are fetched from HBM once (the other three waves hit the CU's L1 / the XCD's L2)
+    // instead of once per XCD that happens to own one of the parities
+    const int w4 = threadIdx.x >> 6;
     const int tiles_x = (a.Wh + 31) >> 5, groups_x = (tiles_x + T2_ITER - 1) / T2_ITER;
-    const int b = wv & 1, tl = wv >> 1;
-    const int hy = tl / groups_x;
+    const int b = w4 & 1;
+    const int qy = blockIdx.x / groups_x;
+    const int hy = 2 * qy + (w4 >> 1);
     if (hy >= a.Hh) return;
-    const int xt0 = (tl - hy * groups_x) * T2_ITER;
+    const int xt0 = (blockIdx.x - qy * groups_x) * T2_ITER;
     const int ab = (hy & 1) * 2 + b;
     // the weight fragments of this wave's sub-pixel stay in registers for all of its tiles (they were 11 of the 18
     // loads per tile: the kernel is bound by load issue, not by the 11 MFMAs)
@@ -3080,9 +3084,9 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
                 u.wQ = PQ->d_q_w; u.biasQ = PQ->d_q_bias; u.wD = P->d_t2_wD; u.wC = P->d_t2_wC; u.beta = P->d_tc_beta;
                 u.out_logits = t.out_logits; u.out_probs = t.out_probs; u.out_labels = t.out_labels; u.out_labels_u8 = t.out_labels_u8;
                 u.out_margin = t.out_margin;
-                const int nwaves = t.Hh * cdiv((t.Wh + 31) / 32, T2_ITER) * 2;
-                if (P->tc_CP == 4) tail_fused2_kernel<4><<<cdiv(nwaves, 4), 256, 0, st>>>(u);
-                else tail_fused2_kernel<8><<<cdiv(nwaves, 4), 256, 0, st>>>(u);
+                const int nwg = cdiv(t.Hh, 2) * cdiv((t.Wh + 31) / 32, T2_ITER);      // one workgroup = 2 rows x 2 column parities
+                if (P->tc_CP == 4) tail_fused2_kernel<4><<<nwg, 256, 0, st>>>(u);
+                else tail_fused2_kernel<8><<<nwg, 256, 0, st>>>(u);
                 PSEG_HIP(hipGetLastError());
                 return PSEG_OK;
             }

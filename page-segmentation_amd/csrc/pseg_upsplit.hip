@@ -4,15 +4,19 @@
 // P_ab(Y, X) = W[a][b] . src(Y, X) of a SOURCE pixel, and each P_ab(Y, X) is used by (up to) four output pixels.
 // Computing the four products once per source pixel is a plain GEMM  D[M][4 Cout] = src[M][Cin] . Wg^T  with a
 // quarter of the direct form's MACs (Cin Cout per output pixel instead of 4 Cin Cout); the output is then a
-// 4-term gather-sum over D (+ bias, ReLU), an HBM-bound pass.  The GEMM is a plain library GEMM (hipBLASLt, bf16
-// operands, f32 accumulation, the "TN" layout: both operands K-contiguous); the partial products are stored as
+// 4-term gather-sum over D (+ bias, ReLU), an HBM-bound pass.  The GEMM is upsplit_gemm_kernel below (hand-written MFMA
+// kernel, bf16 operands, f32 accumulation, both operands K-contiguous); the partial products are stored as
 // bf16, one more rounding than the direct kernel (same class as the per-layer activation rounding; the bf16
 // parity tests cover it).  Used where the deep layers make the direct kernel weight-stream bound (Cin >= 256).
-#include <hipblaslt/hipblaslt.h>
+#include <algorithm>
+#include <cstring>
 
 #include "pseg_common.h"
 
 namespace pseg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct UpSplit {
     int Cs0 = 0, CoS = 0;
@@ -20,36 +24,141 @@ struct UpSplit {
     float* d_bias = nullptr;     // [CoS]
     uint16_t* d_D = nullptr;     // [M][4 CoS] bf16 partial products
     size_t D_bytes = 0;
-    void* d_ws = nullptr;
-    size_t ws_bytes = 32u << 20;
-    hipblasLtMatmulDesc_t desc = nullptr;
-    hipblasLtMatrixLayout_t lA = nullptr, lB = nullptr, lD = nullptr;
-    hipblasLtMatmulHeuristicResult_t algo{};
-    int64_t algo_M = -1;
 };
-
-static hipblasLtHandle_t lt_handle() {
-    static thread_local hipblasLtHandle_t h[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (!h[dev & 63] && hipblasLtCreate(&h[dev & 63]) != HIPBLAS_STATUS_SUCCESS) h[dev & 63] = nullptr;
-    return h[dev & 63];
-}
-
-#define PSEG_LT(expr)                                                                             \
-    do {                                                                                          \
-        const hipblasStatus_t s_ = (expr);                                                        \
-        if (s_ != HIPBLAS_STATUS_SUCCESS) return fail(PSEG_EHIP, "hipBLASLt: %s -> %d", #expr, (int)s_); \
-    } while (0)
 
 void upsplit_free(UpSplit* u) {
     if (!u) return;
-    (void)hipFree(u->d_w); (void)hipFree(u->d_bias); (void)hipFree(u->d_D); (void)hipFree(u->d_ws);
-    if (u->lA) hipblasLtMatrixLayoutDestroy(u->lA);
-    if (u->lB) hipblasLtMatrixLayoutDestroy(u->lB);
-    if (u->lD) hipblasLtMatrixLayoutDestroy(u->lD);
-    if (u->desc) hipblasLtMatmulDescDestroy(u->desc);
+    (void)hipFree(u->d_w); (void)hipFree(u->d_bias); (void)hipFree(u->d_D);
     delete u;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// D[M][N] = A[M][K] . B[N][K]^T, bf16 operands (both K-contiguous), float32 accumulation on v_mfma_f32_16x16x32_bf16,
+// bf16 result.  A = the source pixels (M = Hs Ws, K = Cin as stored), B = the regrouped kernel (N = 4 Cout).
+// One 256-thread workgroup per 128 x 128 tile of D, K in steps of 64 through a two-stage LDS ring filled by LDS-DMA
+// (buffer_load ... lds: rows past M / N and chunks past K use an out-of-range offset, for which the hardware writes
+// zeros).  An operand tile is [128 rows][8 chunks of 16 B]; the DMA lets every lane pick its SOURCE chunk freely, so
+// the tile is stored XOR-swizzled -- slot (row, c ^ (row & 7)) holds chunk c -- which makes the MFMA fragment reads
+// (lane (p16, g) reads chunk 4 ks + g of row p16: one ds_read_b128) conflict-free without padding.  A wave owns a
+// 64 x 64 sub-tile: 4 x 4 accumulator tiles, per 32-deep k-step four pixel fragments and four kernel fragments for
+// sixteen MFMAs, the reads of the next k-step issued between the MFMAs of the current one.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GM = 128, GN = 128, GK = 64;
+
+__device__ __forceinline__ void gemm_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void upsplit_gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                              uint16_t* __restrict__ D, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 stages][A tile 16 KiB | B tile 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)M * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)N * K * 2), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    // DMA pieces of this wave: piece jj = wave * 4 + j fills slots jj * 64 .. + 63 of a tile; slot s = (row s >> 3, position s & 7)
+    unsigned offA[4], offB[4], chk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sl = (wave * 4 + j) * 64 + lane, row = sl >> 3, c = (sl & 7) ^ (row & 7);
+        chk[j] = (unsigned)c;
+        offA[j] = m0 + row < M ? (unsigned)(((size_t)(m0 + row) * K + c * 8) * 2) : OOB;
+        offB[j] = n0 + row < N ? (unsigned)(((size_t)(n0 + row) * K + c * 8) * 2) : OOB;
+    }
+    auto stage = [&](int k0, int buf) {
+        char* base = smem + buf * 32768 + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool kin = k0 + (int)chk[j] * 8 < K;                      // a chunk past K reads zeros
+            const unsigned oa = (offA[j] == OOB || !kin) ? OOB : offA[j] + (unsigned)k0 * 2u;
+            const unsigned ob = (offB[j] == OOB || !kin) ? OOB : offB[j] + (unsigned)k0 * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, oa, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base + 16384 + j * 1024), 16, ob, 0, 0, 0);
+        }
+    };
+    const int nk = (K + GK - 1) / GK;
+    stage(0, 0);
+    if (nk > 1) stage(GK, 1);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses inside a stage: row * 128 + ((4 ks + g) ^ (p16 & 7)) * 16
+    const int sw0 = ((g) ^ (p16 & 7)) * 16, sw1 = ((4 + g) ^ (p16 & 7)) * 16;
+    const int rowA = (wm * 64 + p16) * 128, rowB = 16384 + (wn * 64 + p16) * 128;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gemm_lds_barrier();                                                   // stage kt has landed for every wave
+        const char* sb = smem + (kt & 1) * 32768;
+        bf16x8 xf[2][4], wf[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xf[0][i] = *(const bf16x8*)(sb + rowA + i * 2048 + sw0);
+            wf[0][i] = *(const bf16x8*)(sb + rowB + i * 2048 + sw0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xf[1][i] = *(const bf16x8*)(sb + rowA + i * 2048 + sw1);
+            wf[1][i] = *(const bf16x8*)(sb + rowB + i * 2048 + sw1);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ni], xf[0][mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                                          // the second k-step's reads ride behind the first's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ni], xf[1][mi], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) {
+            gemm_lds_barrier();                                               // every wave is done reading this buffer
+            stage((kt + 2) * GK, kt & 1);
+        }
+    }
+    // D layout of an accumulator tile: lane (p16, g) holds pixel p16 x columns 4g .. 4g+3 (8 bytes).  The wave's 64 x 64 bf16
+    // block goes through its quarter of the (now idle) LDS ring so that every store instruction writes whole 128-byte rows:
+    // 8 lanes x 16 B per row, 8 rows per instruction.
+    gemm_lds_barrier();                                                       // every wave is done with the last stage
+    char* tr = smem + wave * 8192;                                            // [64 rows][128 B]
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 v = acc[mi][ni];
+            uint2 pk;
+            pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{v[0], v[1]}, b2));
+            pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{v[2], v[3]}, b2));
+            // 16-byte slot (ni*2 + g/2) of row r, XOR-swizzled by the row so that the 16 rows of a tile spread over the banks
+            const int r = mi * 16 + p16, slot = (ni * 2 + (g >> 1)) ^ (r & 7);
+            *(uint2*)(tr + r * 128 + slot * 16 + (g & 1) * 8) = pk;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // the wave reads back only what it wrote itself
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;
+        const uint4 v = *(const uint4*)(tr + r * 128 + ((c ^ (r & 7)) * 16));
+        const int m = m0 + wm * 64 + r, n = n0 + wn * 64 + c * 8;
+        if (m < M && n < N) *(uint4*)(D + (size_t)m * N + n) = v;
+    }
 }
 
 static inline uint16_t h_f2bf(float f) {
@@ -73,18 +182,11 @@ int upsplit_create(UpSplit** out, const std::vector<float>& w, const std::vector
     std::vector<float> bb(CoS, 0.0f);
     for (int c = 0; c < Cout; ++c) bb[c] = bias[c];
     auto bail = [&](int rc) { upsplit_free(u); return rc; };
-    if (hipMalloc((void**)&u->d_w, wg.size() * 2) != hipSuccess || hipMalloc((void**)&u->d_bias, bb.size() * 4) != hipSuccess ||
-        hipMalloc(&u->d_ws, u->ws_bytes) != hipSuccess)
+    if (hipMalloc((void**)&u->d_w, wg.size() * 2) != hipSuccess || hipMalloc((void**)&u->d_bias, bb.size() * 4) != hipSuccess)
         return bail(fail(PSEG_ENOMEM, "hipMalloc(split up-conv weights) failed"));
     if (hipMemcpy(u->d_w, wg.data(), wg.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(u->d_bias, bb.data(), bb.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(PSEG_EHIP, "hipMemcpy(split up-conv weights) failed"));
-    if (hipblasLtMatmulDescCreate(&u->desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS)
-        return bail(fail(PSEG_EHIP, "hipblasLtMatmulDescCreate failed"));
-    const hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
-    if (hipblasLtMatmulDescSetAttribute(u->desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) != HIPBLAS_STATUS_SUCCESS ||
-        hipblasLtMatmulDescSetAttribute(u->desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)) != HIPBLAS_STATUS_SUCCESS)
-        return bail(fail(PSEG_EHIP, "hipblasLtMatmulDescSetAttribute failed"));
     *out = u;
     return PSEG_OK;
 }
@@ -127,9 +229,9 @@ __global__ __launch_bounds__(256) void upsplit_sum_kernel(const uint16_t* __rest
 }
 
 int upsplit_launch(UpSplit* u, const uint16_t* src, int Hs, int Ws, uint16_t* dst, int relu, hipStream_t st) {
-    hipblasLtHandle_t h = lt_handle();
-    if (!h) return fail(PSEG_EHIP, "hipblasLtCreate failed");
     const int64_t M = (int64_t)Hs * Ws, N = 4 * (int64_t)u->CoS, K = u->Cs0;
+    if (M * K * 2 >= (int64_t)0xfffffff0u || N * K * 2 >= (int64_t)0xfffffff0u)
+        return fail(PSEG_EUNSUPPORTED, "split up-conv operand larger than a 32-bit buffer range");
     const size_t need = (size_t)M * N * 2;
     if (need > u->D_bytes) {
         PSEG_HIP(hipStreamSynchronize(st));                            // the old buffer may still be read by a queued pass
@@ -138,27 +240,14 @@ int upsplit_launch(UpSplit* u, const uint16_t* src, int Hs, int Ws, uint16_t* ds
         if (hipMalloc((void**)&u->d_D, need) != hipSuccess) return fail(PSEG_ENOMEM, "hipMalloc(%zu) for the split up-conv failed", need);
         u->D_bytes = need;
     }
-    if (u->algo_M != M) {
-        if (u->lA) hipblasLtMatrixLayoutDestroy(u->lA);
-        if (u->lB) hipblasLtMatrixLayoutDestroy(u->lB);
-        if (u->lD) hipblasLtMatrixLayoutDestroy(u->lD);
-        u->lA = u->lB = u->lD = nullptr;
-        // column-major view: D'(N x M) = op_T(Wg'(K x N)) . src'(K x M)
-        PSEG_LT(hipblasLtMatrixLayoutCreate(&u->lA, HIP_R_16BF, K, N, K));
-        PSEG_LT(hipblasLtMatrixLayoutCreate(&u->lB, HIP_R_16BF, K, M, K));
-        PSEG_LT(hipblasLtMatrixLayoutCreate(&u->lD, HIP_R_16BF, N, M, N));
-        hipblasLtMatmulPreference_t pref = nullptr;
-        PSEG_LT(hipblasLtMatmulPreferenceCreate(&pref));
-        hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &u->ws_bytes, sizeof(u->ws_bytes));
-        int found = 0;
-        const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(h, u->desc, u->lA, u->lB, u->lD, u->lD, pref, 1, &u->algo, &found);
-        hipblasLtMatmulPreferenceDestroy(pref);
-        if (hs != HIPBLAS_STATUS_SUCCESS || found < 1) return fail(PSEG_EUNSUPPORTED, "hipBLASLt has no bf16 GEMM for %lld x %lld x %lld", (long long)M, (long long)N, (long long)K);
-        u->algo_M = M;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    PSEG_HIP(hipGetDevice(&dev));
+    if (!attr_set[dev & 63]) {
+        PSEG_HIP(hipFuncSetAttribute((const void*)upsplit_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr_set[dev & 63] = true;
     }
-    const float alpha = 1.0f, beta = 0.0f;
-    PSEG_LT(hipblasLtMatmul(h, u->desc, &alpha, u->d_w, u->lA, src, u->lB, &beta, u->d_D, u->lD, u->d_D, u->lD, &u->algo.algo,
-                            u->d_ws, u->ws_bytes, st));
+    upsplit_gemm_kernel<<<dim3((unsigned)cdiv((int)M, GM), (unsigned)cdiv((int)N, GN)), 256, 65536, st>>>(src, u->d_w, u->d_D, (int)M, (int)N, (int)K);
     const int nch = u->CoS / 8;
     const size_t total = (size_t)4 * M * nch;
     upsplit_sum_kernel<<<(int)std::min<size_t>((total + 255) / 256, 16384), 256, 0, st>>>(u->d_D, Hs, Ws, nch, u->d_bias, relu, dst);

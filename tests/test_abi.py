@@ -57,3 +57,11 @@ def test_fails_loudly_without_a_gpu():
     assert L.pseg_create(0, 3, 1, 0, 1, ctypes.byref(h)) != 0
     assert L.pseg_create(99, 3, 1, 0, 1, ctypes.byref(h)) != 0
     assert len(L.pseg_last_error()) > 0
+
+
+def test_library_links_no_vendor_gemm():
+    """Every GEMM on the hot path is a hand-written MFMA kernel: libpseg.so must not pull in hipBLASLt / rocBLAS / MIOpen."""
+    import subprocess
+    import pseg_amd
+    out = subprocess.run(["ldd", pseg_amd.lib_path()], capture_output=True, text=True).stdout.lower()
+    assert not any(k in out for k in ("hipblas", "rocblas", "miopen")), out

@@ -7,6 +7,7 @@ WRITE_SIZE is exact for wide stores.
 import csv, glob, json, os, sys, collections
 
 LAYER_OF = [  # kernel-name fragment -> layer key used by bench.py's timing slots (fcn_skip, 2048x1536)
+    ("conv12_ws_kernel", "conv2d_1"),
     ("conv_mfma_kernel<8, 2, 5, 1, 3, 0, 33", "conv2d_1"),
     ("conv_mfma_kernel<8, 2, 5, 1, 3, 0, 97", "conv2d_1"),
     ("conv_mfma_kernel<8, 2, 5, 1, 3, 0, 353", "conv2d_1"),

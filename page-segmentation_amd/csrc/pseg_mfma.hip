@@ -1011,11 +1011,16 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
 // ---------------------------------------------------------------------------------------------
 constexpr int WS_ROWP = 1744;     // row pitch of the dense sigma = 3 tile ((36 * 3 + 1) slots, pair_chunks' choice)
 constexpr int WS_KSTEPS = 19;     // 25 taps x 3 chunks = 75 k-chunks + 1 dummy
+constexpr int WS_KSTEPS_PAIR = 17; // 25 taps x 2 chunks + 15 paired half chunks = 65 k-chunks + 3 dummies
+constexpr int WS_TILE0 = 16;      // the tiles start 16 bytes into LDS: a pixel's paired half chunk is stored 8 bytes BEFORE its slot
 
-template <bool SKIPLOG>
+// PAIRC2: channels 16-19 of a pixel are written twice -- into bytes 32-39 of its own 48-byte slot and into bytes 40-47 of its
+// LEFT neighbour's slot -- so that the k-chunk "third chunk under tap kx" also carries tap kx + 1 (see pair_chunks): 17 k-steps.
+template <bool SKIPLOG, bool PAIRC2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv12_ws_kernel(MConv a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = 8, NT = 2, TH = 16, HR = TH + 4, HC = TW + 4, PS2 = 48, ROWP = WS_ROWP, KSTEPS = WS_KSTEPS;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* const smem = smem_raw + WS_TILE0;
+    constexpr int MT = 8, NT = 2, TH = 16, HR = TH + 4, HC = TW + 4, PS2 = 48, ROWP = WS_ROWP, KSTEPS = PAIRC2 ? WS_KSTEPS_PAIR : WS_KSTEPS;
     constexpr int UCB = 96, PR = 9;                       // producer staging: bytes per copy row (48 px), page rows per wave
     constexpr int PRIV = 2 * PR * UCB + 16;               // two shifted copies + a 16-byte sink for stores that carry nothing
     static_assert(HR % 4 == 0 && HR / 4 == 5, "a producer wave owns five halo rows");
@@ -1039,6 +1044,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wpk + (size_t)pc * 512 + lane * 8),
                                              (__attribute__((address_space(3))) void*)(w_t + pc * 1024), 16, 0, 0);
         if (tid < KSTEPS * 4) tab_l[tid] = a.tab_full[tid];
+        // bytes no producer ever writes (row padding; with PAIRC2 the right half chunk of the last column) meet zero weights,
+        // but must not hold NaN patterns
+        for (int i = tid * 16 - WS_TILE0; i < 2 * TB; i += 512 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
     }
     const int n_my = ((int)a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
 
@@ -1062,7 +1070,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // row 4), the tile-buffer offsets of the two 8-byte stores (couts 4g..4g+3; then couts 16..19 / the zero pad
         // 20..23 for g < 2 -- the other lanes repeat their first store, which keeps the code branch-free).
         int srcA[4], srcB[4], dst1[4], dst2[4], hxT[4], jT[4];
-        const int sink = (int)(priv - smem) + 2 * PR * UCB + (g & 1) * 8;      // lanes g >= 2: their second store goes nowhere
+        const int sink = (int)(priv - smem) + 2 * PR * UCB + (g & 1) * 8;      // stores of lanes that carry nothing go here
 #pragma unroll
         for (int ty = 0; ty < 4; ++ty) {
             const int hx = ty < 2 ? ty * 16 + p16 : 32 + (p16 & 3);
@@ -1147,7 +1155,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         xa[q] = make_uint4(ra[0], ra[1], ra[2], ra[3]);
                         xb[q] = make_uint4(rb[0], rb[1], rb[2], rb[3]);
                         d1[q] = bufoff + dst1[ty] + j * ROWP;
-                        d2[q] = low_g ? bufoff + dst2[ty] + j * ROWP : sink;
+                        // couts 16-19 (lane group 0) [and the zero pad 20-23 (lane group 1) without PAIRC2]
+                        d2[q] = (PAIRC2 ? g == 0 : low_g) ? bufoff + dst2[ty] + j * ROWP : sink;
                         inc[q] = true;
                         if constexpr (BORDER) {
                             if (k < 10) { const int gy = oy0 - 2 + 5 * pw + j; inc[q] = colT[ty] && gy >= 0 && gy < a.Hin; }
@@ -1175,6 +1184,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         }
                         *(uint2*)(smem + d1[q]) = make_uint2(pa0, pa1);
                         *(uint2*)(smem + d2[q]) = make_uint2(pb0, pb1);
+                        if constexpr (PAIRC2)       // ... and once more as the left neighbour's right half (its slot ends 8 bytes before ours)
+                            *(uint2*)(smem + (g == 0 ? d2[q] - 40 : sink)) = make_uint2(pb0, pb1);
                     }
                 }
             };
@@ -2040,6 +2051,7 @@ struct MfmaPlan {
     uint16_t* d_t2_wD = nullptr;   // composed tail with the inner deconv: composed kernel fragments
     uint16_t* d_t2_wC = nullptr;
     bool tail2 = false;
+    bool pairc2 = false;           // fused conv1+conv2 (conv12_ws_kernel): channels 16-19 of two neighbouring pixels share a k-chunk (17 k-steps instead of 19)
     float* d_skiplog = nullptr;    // skip-logits buffer [canvas pixel][skip_CP] (op.skiplog >= 0), grown with the canvas
     size_t skiplog_bytes = 0;
     int skip_CP = 0;
@@ -2227,10 +2239,15 @@ static int pair_cost(int o0, int o1, int sigma) {
 // Order the k-chunks of a channel block into (g0,g1),(g2,g3) pairs that read conflict-free:
 // greedy matching on the bank model.  pitch_slots = row pitch in 16-byte slots.  Returns the
 // ordered chunks (padded with dummies to a multiple of 4) and the total modelled LDS cycles.
-static std::vector<Chunk> pair_chunks(int KS, int nc, int sigma, int pitch_slots, int* cycles_out = nullptr) {
+// pairc2: the last chunk of a pixel holds four channels of that pixel and four of its right neighbour (conv12_ws_kernel's
+// tile): the k-chunk (tap (ky, kx), last chunk) with even kx covers taps kx and kx + 1, the odd-kx ones do not exist.
+static std::vector<Chunk> pair_chunks(int KS, int nc, int sigma, int pitch_slots, int* cycles_out = nullptr, bool pairc2 = false) {
     std::vector<Chunk> all;
     for (int t = 0; t < KS * KS; ++t)
-        for (int c = 0; c < nc; ++c) all.push_back(Chunk{t, c});
+        for (int c = 0; c < nc; ++c) {
+            if (pairc2 && c == nc - 1 && ((t % KS) & 1)) continue;
+            all.push_back(Chunk{t, c});
+        }
     auto slot = [&](const Chunk& c) { return (c.tap / KS) * pitch_slots + (c.tap % KS) * sigma + c.cc; };
     std::vector<char> used(all.size(), 0);
     std::vector<Chunk> out;
@@ -2387,6 +2404,11 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->NW = (P->nw8_ok && op.nw_hint == 8) ? 8 : 4;
     const int TH = P->NW * (P->MT / 2);
     const int totc = (Cs0 + Cs1) / 8;
+    // fused conv1 + conv2 on the wave-specialised kernel: 20 input channels = 2.5 chunks per pixel -- the half chunk pairs up
+    // with the right neighbour's (the producers write the tile that way), 65 k-chunks instead of 75
+    P->pairc2 = op.fuse1 >= 0 && !deconv && KS == 5 && C0 == 20 && Cs0 == 24 && !s1 && op.stride == 1 && op.pool_dst >= 0 && !op.relu &&
+                op.add < 0 && !op.in_relu && Cout <= 32 && !PSEG_KNOB("PSEG_NO_WS") && !PSEG_KNOB("PSEG_NO_PAIRC2") && !PSEG_KNOB("PSEG_NO_PERSIST") &&
+                !PSEG_KNOB("PSEG_GENERIC");
     P->nc_full = totc <= 5 ? totc : (KS == 1 && totc <= 16 ? totc : 4);
     P->nblk = cdiv(totc, P->nc_full);
     P->nc_last = totc - (P->nblk - 1) * P->nc_full;
@@ -2422,16 +2444,20 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
             int best_cyc = 1 << 30;
             for (int pad = 0; pad < 16; ++pad) {
                 int cyc = 0;
-                (void)pair_chunks(KS, P->nc_full, sigma, P->TWH * sigma + pad, &cyc);
+                (void)pair_chunks(KS, P->nc_full, sigma, P->TWH * sigma + pad, &cyc, P->pairc2);
                 if (cyc < best_cyc) { best_cyc = cyc; pitch_pad = pad; }
             }
         }
     }
+    if (P->pairc2) {
+        if (sigma != 3) return fail(PSEG_EUNSUPPORTED, "paired half chunks need the dense 48-byte pixel (sigma 3, got %d)", sigma);
+        pitch_pad = (WS_ROWP - P->TWH * sigma * 16) / 16;     // the row pitch conv12_ws_kernel is compiled for
+    }
     if (P->NW != 4 && sigma != 6) return fail(PSEG_EUNSUPPORTED, "6/8-wave plan needs the sigma = 6 tile (got %d)", sigma);
     P->PS2 = sigma * 16;
     P->row_pitch = (P->TWH * sigma + pitch_pad) * 16;
-    const auto ord_full = pair_chunks(KS, P->nc_full, sigma, P->row_pitch / 16);
-    const auto ord_last = pair_chunks(KS, P->nc_last, sigma, P->row_pitch / 16);
+    const auto ord_full = pair_chunks(KS, P->nc_full, sigma, P->row_pitch / 16, nullptr, P->pairc2);
+    const auto ord_last = pair_chunks(KS, P->nc_last, sigma, P->row_pitch / 16, nullptr, P->pairc2);
     P->ks_full = (int)ord_full.size() / 4;
     P->ks_last = (int)ord_last.size() / 4;
     if ((int)ord_full.size() > MAX_TAB) return fail(PSEG_EUNSUPPORTED, "k-chunk table too large");
@@ -2521,6 +2547,13 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
                     const int kq = (kstep0 + s) / GK, ksg = (kstep0 + s) % GK, nbk = t / NT, tl = t % NT;
                     uint16_t* o = &pk[(((((size_t)kq * P->nblocks_n + nbk) * GK + ksg) * NT + tl) * 64 + l) * 8];
                     for (int j = 0; j < 8; ++j) {
+                        if (P->pairc2 && c.cc == P->nc_full - 1) {
+                            // elements 0-3: channels 16-19 under tap kx, elements 4-7: channels 16-19 under tap kx + 1 (the tile
+                            // holds the right neighbour's four channels there); kx = 4 has no right tap
+                            const int tap = c.tap + (j >> 2), ci = c.cc * 8 + (j & 3);
+                            if ((c.tap % KS) + (j >> 2) < KS) o[j] = f2bf(wval(tap, ci, n));
+                            continue;
+                        }
                         const int ci = true_ci((b * P->nc_full + c.cc) * 8 + j);
                         if (ci >= 0) o[j] = f2bf(wval(c.tap, ci, n));
                     }
@@ -2992,23 +3025,28 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         const int TB = round_up(P->THH * P->row_pitch, 16);
         w.lds_w_off = TB;                                   // the kernel's tile stride
         w.ntiles = (int)grid.x;
-        const int lds = 2 * TB + P->ks_full * P->NT * 1024 + round_up(P->ks_full * 16, 16) + 4 * (2 * 9 * 96 + 16);
+        const int lds = WS_TILE0 + 2 * TB + P->ks_full * P->NT * 1024 + round_up(P->ks_full * 16, 16) + 4 * (2 * 9 * 96 + 16);
         if (const char* pr = PSEG_KNOB("PSEG_WS_PRIO")) w.dbg |= (atoi(pr) & 3) << 8;
-        if (lds <= 160 * 1024 && P->GK >= P->ks_full && P->row_pitch == WS_ROWP && P->ks_full == WS_KSTEPS) {
+        if (lds <= 160 * 1024 && P->GK >= P->ks_full && P->row_pitch == WS_ROWP && P->ks_full == (P->pairc2 ? WS_KSTEPS_PAIR : WS_KSTEPS)) {
             const unsigned gx = std::min<unsigned>(grid.x, (unsigned)cus_ws);
-            static bool attr_ws[64][2] = {{false}};
-            const int sk = op.skiplog >= 0 ? 1 : 0;
-            if (!attr_ws[dev & 63][sk]) {
-                if (sk) PSEG_HIP(hipFuncSetAttribute((const void*)conv12_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                else PSEG_HIP(hipFuncSetAttribute((const void*)conv12_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_ws[dev & 63][sk] = true;
+            const int sk = op.skiplog >= 0 ? 1 : 0, variant = sk * 2 + (P->pairc2 ? 1 : 0);
+            const void* fn = variant == 3 ? (const void*)conv12_ws_kernel<true, true> : variant == 2 ? (const void*)conv12_ws_kernel<true, false>
+                           : variant == 1 ? (const void*)conv12_ws_kernel<false, true> : (const void*)conv12_ws_kernel<false, false>;
+            static bool attr_ws[64][4] = {{false}};
+            if (!attr_ws[dev & 63][variant]) {
+                PSEG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_ws[dev & 63][variant] = true;
             }
             if (ws_trace) {
                 PSEG_HIP(hipMalloc((void**)&w.trace, (size_t)gx * 8 * 4 * 8));
                 PSEG_HIP(hipMemset(w.trace, 0, (size_t)gx * 8 * 4 * 8));
             }
-            if (sk) conv12_ws_kernel<true><<<dim3(gx), 512, lds, st>>>(w);
-            else conv12_ws_kernel<false><<<dim3(gx), 512, lds, st>>>(w);
+            switch (variant) {
+                case 3: conv12_ws_kernel<true, true><<<dim3(gx), 512, lds, st>>>(w); break;
+                case 2: conv12_ws_kernel<true, false><<<dim3(gx), 512, lds, st>>>(w); break;
+                case 1: conv12_ws_kernel<false, true><<<dim3(gx), 512, lds, st>>>(w); break;
+                default: conv12_ws_kernel<false, false><<<dim3(gx), 512, lds, st>>>(w); break;
+            }
             if (ws_trace) {
                 PSEG_HIP(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hbuf((size_t)gx * 8 * 4);
@@ -3019,6 +3057,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
             return PSEG_OK;
         }
     }
+    if (P->pairc2) return fail(PSEG_EUNSUPPORTED, "layer %s is packed for conv12_ws_kernel (paired half chunks), which cannot take this launch", op.layer.c_str());
     if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && !PSEG_KNOB("PSEG_NO_PERSIST") && !PSEG_KNOB("PSEG_GENERIC")) {
         static int cus = 0;   // one device model per process
         if (!cus) {

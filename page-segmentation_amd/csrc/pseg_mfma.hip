@@ -90,7 +90,8 @@ struct MConv {
     int nb_loop, nb_total;
     int ntiles;          // FL_PERSIST: tiles of the layer (a workgroup walks tile blockIdx.x, + gridDim.x, ...)
     // fused first layer (FL_FUSE1): conv1 is recomputed on the halo tile from the uint8 page
-    const uint8_t* f1_img; int f1_H, f1_W; const uint16_t* f1_wpk; const float* f1_bias; int f1_relu, lds_f1_off;   // N blocks walked inside one workgroup / N blocks of the layer
+    const uint8_t* f1_img; int f1_H, f1_W; const uint16_t* f1_wpk; const float* f1_bias; int f1_relu, lds_f1_off;
+    const uint16_t* f1_wpk32;  // first-layer kernel as 32x32x16 A fragments [k-step 3][lane][8] (conv12_ws_kernel), or null   // N blocks walked inside one workgroup / N blocks of the layer
     // fused tail (deconv5 -> crop -> logits 1x1 -> softmax/argmax), see tail_epilogue()
     int tail, tail_C, H0, W0, nch_skip;
     const uint16_t* skip;      // full-resolution skip tensor (conv2), or null
@@ -1009,6 +1010,9 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
 // Arithmetic and summation order per output are those of the fused kernel (same k-chunk order, same packing): the two
 // produce identical bits (tests/test_bf16_gpu.py).
 // ---------------------------------------------------------------------------------------------
+#ifndef PSEG_WS_EPI_VALU
+#define PSEG_WS_EPI_VALU 2      // epilogue VALU instructions issued behind each MFMA of the consumers' k-loop
+#endif
 constexpr int WS_ROWP = 1744;     // row pitch of the dense sigma = 3 tile ((36 * 3 + 1) slots, pair_chunks' choice)
 constexpr int WS_KSTEPS = 19;     // 25 taps x 3 chunks = 75 k-chunks + 1 dummy
 constexpr int WS_KSTEPS_PAIR = 17; // 25 taps x 2 chunks + 15 paired half chunks = 65 k-chunks + 3 dummies
@@ -1063,6 +1067,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float4 b1a = *(const float4*)(a.f1_bias + 4 * g), b1b = *(const float4*)(a.f1_bias + 16 + 4 * g);
         const f32x4 zb0 = f32x4{b1a.x, b1a.y, b1a.z, b1a.w}, zb1 = f32x4{b1b.x, b1b.y, b1b.z, b1b.w};
         const uint32_t floor2 = a.f1_relu ? 0u : 0x80008000u;
+        typedef float f32x16_t __attribute__((ext_vector_type(16)));
+        bf16x8 w3[3];
+        f32x16_t zb32;
+        {
+            const uint16_t* wp = a.f1_wpk32 ? a.f1_wpk32 : a.f1_wpk;       // (the 16x16x32 path never reads w3 / zb32)
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) w3[s3] = *(const bf16x8*)(wp + ((size_t)s3 * 64 + lane) * 8);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 bq = *(const float4*)(a.f1_bias + 8 * v + 4 * (lane >> 5));
+                zb32[4 * v] = bq.x; zb32[4 * v + 1] = bq.y; zb32[4 * v + 2] = bq.z; zb32[4 * v + 3] = bq.w;
+            }
+        }
+        // 32x32x16 path, per-lane constants of its two tile types (0: full tile, halo columns 0-31 of row j = immediate; 1: the four
+        // remainder columns, row = lane / 4 of the low half, surplus lanes redo row 4): copy offsets of the three k-steps
+        // (kernel row 2 s + half; row 5 does not exist: zero weights, any finite data), the slot of the pixel, and where the
+        // third / fourth store of the lane goes (half 1 under PAIRC2: the row's padding bytes)
+        int c32_src[2][3], c32_d12[2], c32_d3[2], c32_d4[2], c32_hx[2], c32_j[2];
+        {
+            const int n32 = lane & 31, hh = lane >> 5;
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty) {
+                const int hx = ty ? 32 + (n32 & 3) : n32, j = ty ? min(n32 >> 2, 4) : 0;
+                const int c = (hx & 1) * (PR * UCB) + (hx & ~1) * 2 + j * UCB;
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) c32_src[ty][s3] = c + min(2 * s3 + hh, 4) * UCB;
+                const int d = hx * PS2 + (5 * pw + j) * ROWP, pad = (5 * pw + j) * ROWP + HC * PS2 + 8;
+                c32_d12[ty] = d + 8 * hh;
+                c32_d3[ty] = PAIRC2 ? (hh == 0 ? d + 32 : pad) : d + 32 + 8 * hh;
+                c32_d4[ty] = hh == 0 ? d - 8 : pad;
+                c32_hx[ty] = hx; c32_j[ty] = j;
+            }
+        }
         const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc((void*)a.f1_img, 0, (unsigned)((size_t)a.f1_H * a.f1_W), 0x00020000);
         // the wave's 12 first-layer tiles: five rows x two full 16-pixel column tiles (ct = 0, 1), the four remainder
         // columns of rows 0-3 in one tile (type 2) and of row 4 in another (type 3: its surplus lanes redo row 4).
@@ -1189,8 +1226,70 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
             };
-            if (interior) batches(std::false_type{});
-            else batches(std::true_type{});
+            // The same first layer on v_mfma_f32_32x32x16_bf16 (default): a 32-pixel tile needs 3 MFMAs of 32 cycles (kernel rows
+            // 2 s + half per k-step) instead of 2 x 4 of 16, three fragment reads instead of four, and its 32 x 32 result holds a
+            // pixel's 24 channel slots in twelve registers of the two lane halves -- six roundings per lane instead of eight.
+            // The wave's band = five full tiles (row j, halo columns 0-31) + one tile of the four remainder columns of all rows.
+            auto batches32 = [&](auto border_tag) {
+                constexpr bool BORDER = decltype(border_tag)::value;
+                typedef float f32x16 __attribute__((ext_vector_type(16)));
+                // this fill's store addresses: the per-kernel lane constants + the tile buffer's offset (rows ride in immediates)
+                int d12[2], d3[2], d4[2];
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty) { d12[ty] = c32_d12[ty] + bufoff; d3[ty] = c32_d3[ty] + bufoff; d4[ty] = c32_d4[ty] + bufoff; }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    uint4 x3[3][3];
+                    bool inc[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int k = b * 3 + q;                           // tiles 0-4: full, row k; 5: remainder columns
+                        const int ty = k == 5 ? 1 : 0, jimm = k == 5 ? 0 : k;
+#pragma unroll
+                        for (int s3 = 0; s3 < 3; ++s3) {
+                            const uint32_t* r = (const uint32_t*)(priv + c32_src[ty][s3] + jimm * UCB);
+                            x3[q][s3] = make_uint4(r[0], r[1], r[2], r[3]);
+                        }
+                        inc[q] = true;
+                        if constexpr (BORDER) {
+                            const int gx = ox0 - 2 + c32_hx[ty], gy = oy0 - 2 + 5 * pw + c32_j[ty] + jimm;
+                            inc[q] = gx >= 0 && gx < a.Win && gy >= 0 && gy < a.Hin;
+                        }
+                    }
+                    f32x16 z[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) z[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3[0], __builtin_bit_cast(bf16x8, x3[q][0]), zb32, 0, 0, 0);
+#pragma unroll
+                    for (int s3 = 1; s3 < 3; ++s3)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) z[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3[s3], __builtin_bit_cast(bf16x8, x3[q][s3]), z[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int k = b * 3 + q, ty = k == 5 ? 1 : 0, ro = (k == 5 ? 0 : k) * ROWP;
+                        // registers 4 v .. 4 v + 3 = couts 8 v + 4 half .. + 3: bytes 16 v + 8 half of the pixel's slot
+                        uint32_t pk[3][2];
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) {
+                            pk[v][0] = relu_pk_bf16(pk_bf16(z[q][4 * v], z[q][4 * v + 1]), floor2);
+                            pk[v][1] = relu_pk_bf16(pk_bf16(z[q][4 * v + 2], z[q][4 * v + 3]), floor2);
+                            if constexpr (BORDER) { pk[v][0] = inc[q] ? pk[v][0] : 0u; pk[v][1] = inc[q] ? pk[v][1] : 0u; }
+                        }
+                        *(uint2*)(smem + d12[ty] + ro) = make_uint2(pk[0][0], pk[0][1]);               // couts 0-3 / 4-7
+                        *(uint2*)(smem + d12[ty] + ro + 16) = make_uint2(pk[1][0], pk[1][1]);          // couts 8-11 / 12-15
+                        // couts 16-19 (lane half 0): the own slot [PAIRC2: and the left neighbour's right half]; lane half 1 holds
+                        // the zero pad 20-23 [PAIRC2: nothing -- its stores land in the row's 16 padding bytes]
+                        *(uint2*)(smem + d3[ty] + ro) = make_uint2(pk[2][0], pk[2][1]);
+                        if constexpr (PAIRC2) *(uint2*)(smem + d4[ty] + ro) = make_uint2(pk[2][0], pk[2][1]);
+                    }
+                }
+            };
+            if (a.f1_wpk32) {
+                if (interior) batches32(std::false_type{});
+                else batches32(std::true_type{});
+            } else {
+                if (interior) batches(std::false_type{});
+                else batches(std::true_type{});
+            }
         };
         tile_origin(0, noy, nox);
         load_u8(noy, nox);
@@ -1329,7 +1428,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 8; ++r) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (r < 6 && s2 + 1 < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, PSEG_WS_EPI_VALU, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2030,6 +2129,7 @@ struct MfmaPlan {
     float* d_bias = nullptr;
     float* d_wf = nullptr;   // conv1 / logits: f32 (bf16-rounded) weights
     float* d_lut = nullptr;  // conv1: bf16-rounded x/255 table
+    uint16_t* d_wpk32 = nullptr;   // conv1 (k5, <= 32 couts): 32x32x16 A fragments for conv12_ws_kernel's producers
     uint16_t* d_tail_wa = nullptr;
     uint16_t* d_tail_wb = nullptr;
     float* d_tail_bias = nullptr;
@@ -2062,7 +2162,7 @@ void mfma_free_op(Op& op) {
     auto* p = (MfmaPlan*)op.plan;
     if (!p) return;
     (void)hipFree(p->d_tab_full); (void)hipFree(p->d_tab_last); (void)hipFree(p->d_wpk);
-    (void)hipFree(p->d_bias); (void)hipFree(p->d_wf); (void)hipFree(p->d_lut);
+    (void)hipFree(p->d_bias); (void)hipFree(p->d_wf); (void)hipFree(p->d_lut); (void)hipFree(p->d_wpk32);
     (void)hipFree(p->d_tail_wa); (void)hipFree(p->d_tail_wb); (void)hipFree(p->d_tail_bias);
     (void)hipFree(p->d_tc_wA1); (void)hipFree(p->d_tc_wA2); (void)hipFree(p->d_tc_beta);
     upsplit_free(p->upsplit);
@@ -2323,9 +2423,21 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
                         apk[(((size_t)sidx * nt + q) * 64 + l) * 8 + j] = f2bf(w[((size_t)ky * k + j) * Cout + co]);
                 }
         PSEG_TRY(upload(&P->d_wpk, apk));
-        std::vector<float> bb((size_t)nt * 16, 0.0f);
+        std::vector<float> bb((size_t)std::max(nt * 16, 32), 0.0f);
         for (int c = 0; c < Cout; ++c) bb[c] = bias[c];
         PSEG_TRY(upload(&P->d_bias, bb));
+        if (k == 5 && Cout <= 32) {
+            // v_mfma_f32_32x32x16_bf16 form: A fragment of k-step s, lane l = (cout l % 32, half l / 32): kernel row 2 s + half,
+            // element j = kernel column (rows / columns past the 5 x 5 kernel carry zeros)
+            std::vector<uint16_t> a32((size_t)3 * 64 * 8, 0);
+            for (int sidx = 0; sidx < 3; ++sidx)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = l & 31, ky = 2 * sidx + (l >> 5);
+                    if (co >= Cout || ky >= k) continue;
+                    for (int j = 0; j < k; ++j) a32[((size_t)sidx * 64 + l) * 8 + j] = f2bf(w[((size_t)ky * k + j) * Cout + co]);
+                }
+            PSEG_TRY(upload(&P->d_wpk32, a32));
+        }
         return PSEG_OK;
     }
     if (op.type == OP_LOGITS) {
@@ -3001,6 +3113,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         a.f1_H = e.H;
         a.f1_W = e.W;
         a.f1_wpk = P1->d_wpk;
+        a.f1_wpk32 = PSEG_KNOB("PSEG_NO_C32") ? nullptr : P1->d_wpk32;
         a.f1_bias = P1->d_bias;
         a.f1_relu = c1.relu;
         a.lds_f1_off = P->lds_f1_off;

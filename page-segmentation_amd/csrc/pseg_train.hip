@@ -555,7 +555,9 @@ __global__ void bias_grad_kernel(const float* dY, const float* maskY, size_t npi
     if (threadIdx.x < 128) sh[threadIdx.x] = 0.0f;
     __syncthreads();
     const size_t n = npix * Cout;
-    float s = 0.0f;
+    // a bias gradient is a plain sum of a signed map over up to 3.1 M pixels, and it cancels heavily: the thread's running
+    // sum is kept in float64 (a few hundred terms per thread; the kernel is HBM-bound either way)
+    double s = 0.0;
     // each thread keeps one channel: stride is a multiple of Cout
     const size_t stride = (size_t)gridDim.x * blockDim.x / Cout * Cout;
     const size_t start = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -563,9 +565,9 @@ __global__ void bias_grad_kernel(const float* dY, const float* maskY, size_t npi
         for (size_t i = start; i < n; i += stride) {
             float v = dY[i];
             if (maskY && !(maskY[i] > 0.0f)) v = 0.0f;
-            s += v;
+            s += (double)v;
         }
-    if (start < stride) atomicAdd(&sh[start % Cout], s);
+    if (start < stride) atomicAdd(&sh[start % Cout], (float)s);
     __syncthreads();
     if ((int)threadIdx.x < Cout && sh[threadIdx.x] != 0.0f) atomicAdd(&dB[threadIdx.x], sh[threadIdx.x]);
 }

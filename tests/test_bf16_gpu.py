@@ -155,6 +155,7 @@ def test_bf16_conv1_fusion_is_bit_identical_to_unfused(gpu, oracle_mod, monkeypa
     Wt = oracle_mod.init_weights("fcn_skip", 3, seed=8, gain=1.5, bias_scale=0.05)
     monkeypatch.setenv("PSEG_NO_SKIPLOG", "1")        # keep conv2's tensor in memory: it is compared below
     monkeypatch.setenv("PSEG_NO_PAIRC2", "1")         # the k-chunk order of the unfused kernel (the default fused order: next test)
+    monkeypatch.setenv("PSEG_NO_C32", "1")            # ... and its 16x16x32 first layer (the default 32x32x16 form sums in another order)
     outs = []
     for fuse in (True, False):
         if not fuse:
@@ -274,17 +275,19 @@ def test_bf16_wave_specialised_conv12_is_bit_identical_to_the_fused_instance(gpu
                 res.append((z, l, eng.activation("max_pooling2d")))
             eng.close()
             return res
-        paired = run_all()                                    # default: 17 k-steps (paired half chunks)
+        paired = run_all()                                    # default: 17 k-steps (paired half chunks), 32x32x16 first layer
         monkeypatch.setenv("PSEG_NO_PAIRC2", "1")
-        plain = run_all()                                     # the fused instance's 19-step order
+        monkeypatch.setenv("PSEG_NO_C32", "1")
+        plain = run_all()                                     # the fused instance's 19-step order and 16x16x32 first layer
         monkeypatch.setenv("PSEG_NO_WS", "1")
         ref = run_all()
         monkeypatch.delenv("PSEG_NO_WS")
         monkeypatch.delenv("PSEG_NO_PAIRC2")
+        monkeypatch.delenv("PSEG_NO_C32")
         for im, (z1, l1, p1), (z0, l0, p0), (zp, lp, pp) in zip(imgs, plain, ref, paired):
             assert np.array_equal(p1, p0) and np.array_equal(z1, z0) and np.array_equal(l1, l0), im.shape
             # paired half chunks: the same products in another float32 summation order -- a conv2 output may round to the
             # neighbouring bf16 value here and there, nothing more
             assert np.all(np.abs(pp - p0) <= np.abs(p0) * 2.0 ** -7 + 1e-6), im.shape
             assert (pp != p0).mean() < 0.02, im.shape
-            assert np.abs(zp - z0).max() <= 5e-3 * max(1.0, float(np.abs(z0).max())), im.shape
+            assert np.abs(zp - z0).max() <= 1e-2 * max(1.0, float(np.abs(z0).max())), im.shape

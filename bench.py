@@ -65,14 +65,41 @@ def spawn_ranks(args):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
+    # A rank that dies (no such GPU, RCCL refusal, ...) must not leave the others waiting in the rendezvous: poll, and when one
+    # has exited with an error stop the rest -- by their own PIDs -- and fail loudly.
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad
+            break
+        if all(c is not None for c in codes):
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: rank(s) failed %r (rank, exit code); the other ranks were stopped.  --gpus %d needs %d visible GPUs.\n"
+                         % (failed, args.gpus, args.gpus))
+        return 1
+    reader.join(timeout=10)
     line = None
-    for ln in (out0 or b"").decode("utf-8", "replace").splitlines():
+    for ln in (buf[0] if buf else b"").decode("utf-8", "replace").splitlines():
         if ln.startswith("{"):
             line = ln
-    if any(rcs) or line is None:
-        sys.stderr.write("bench.py: rank exit codes %r, rank 0 JSON line %s\n" % (rcs, "present" if line else "missing"))
+    if line is None:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
         return 1
     print(line)
     return 0
@@ -254,12 +281,16 @@ def run_rank(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        if torch.cuda.device_count() <= local_rank:
+            sys.stderr.write("bench.py: rank %d needs cuda:%d but only %d device(s) are visible\n" % (rank, local_rank, torch.cuda.device_count()))
+            return 3
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180),
                                     device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     else:
         dist = None
         torch.cuda.set_device(local_rank)

@@ -7,13 +7,16 @@ from collections import OrderedDict
 import numpy as np
 
 
-def fcn_loss_and_grads(arch, Wt, image_u8, mask_u8, loss_kind="categorical_crossentropy"):
+def fcn_loss_and_grads(arch, Wt, image_u8, mask_u8, loss_kind="categorical_crossentropy", float64=False):
     """-> (loss, acc, jaccard, dice, grads dict in Keras layouts).  loss_kind: a value of the reference's
-    Loss enum (lib/metrics.py:116-121); Keras reduces the tensor a loss function returns by a plain mean."""
+    Loss enum (lib/metrics.py:116-121); Keras reduces the tensor a loss function returns by a plain mean.
+    float64=True evaluates the same graph in double precision (full-size pages: a float32 bias gradient is a cancelling sum
+    over 3.1 M pixels, and torch's own float32 reduction is then off by ~1 % -- the referee for the engine must not be)."""
     import torch
     import torch.nn.functional as F
     skip = arch == "fcn_skip"
-    T = OrderedDict((k, torch.tensor(v, dtype=torch.float32, requires_grad=True)) for k, v in Wt.items())
+    dt = torch.float64 if float64 else torch.float32
+    T = OrderedDict((k, torch.tensor(v, dtype=dt, requires_grad=True)) for k, v in Wt.items())
     H, W = image_u8.shape
     ph, pw = (32 - H % 32) % 32, (32 - W % 32) % 32
 
@@ -28,7 +31,7 @@ def fcn_loss_and_grads(arch, Wt, image_u8, mask_u8, loss_kind="categorical_cross
         y = F.conv_transpose2d(x, T[n + "/kernel"].permute(3, 2, 0, 1), T[n + "/bias"], stride=2)
         return F.relu(y) if relu else y
 
-    x = torch.from_numpy(image_u8.astype(np.float32) / np.float32(255.0))[None, None]
+    x = torch.from_numpy(image_u8.astype(np.float32) / np.float32(255.0))[None, None].to(dt)
     x = F.pad(x, (0, pw, 0, ph))
     c1 = conv(x, "conv2d", True); c2 = conv(c1, "conv2d_1", False)
     c3 = conv(F.max_pool2d(c2, 2), "conv2d_2", True); c4 = conv(c3, "conv2d_3", False)
@@ -50,7 +53,7 @@ def fcn_loss_and_grads(arch, Wt, image_u8, mask_u8, loss_kind="categorical_cross
     if loss_kind == "categorical_crossentropy":
         loss = F.cross_entropy(z.reshape(-1, C), y.reshape(-1))                  # lib/metrics.py:8-9
     else:
-        oh_l = F.one_hot(y, C).float()
+        oh_l = F.one_hot(y, C).to(dt)
         if loss_kind in ("dice", "jaccard", "dice_and_crossentropy"):            # :60-85,107-109
             p_l = torch.softmax(z, -1)
             I = (oh_l * p_l).abs().sum((0, 1))
@@ -72,12 +75,12 @@ def fcn_loss_and_grads(arch, Wt, image_u8, mask_u8, loss_kind="categorical_cross
     with torch.no_grad():
         acc = (z.argmax(-1) == y).float().mean().item()                          # :12-17
         p = torch.softmax(z, -1)
-        oh = F.one_hot(y, C).float()
+        oh = F.one_hot(y, C).to(dt)
         inter = (oh * p).abs().sum((0, 1))
         s = (oh + p).abs().sum((0, 1))
         jac = ((inter + 100) / (s - inter + 100)).mean().item()                  # :60-69
         dice = ((2.0 * inter + 100) / (s + 100)).mean().item()                   # :76-85
-    grads = OrderedDict((k, t.grad.numpy().copy()) for k, t in T.items())
+    grads = OrderedDict((k, t.grad.numpy().astype(np.float32)) for k, t in T.items())
     return float(loss.item()), acc, jac, dice, grads
 
 

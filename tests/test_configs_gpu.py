@@ -69,16 +69,18 @@ def test_config3_full_size_train_step_matches_torch_autograd(gpu):
     eng.set_weights(Wt)
     eng.train_init(clipnorm=1.0)
     loss, acc, jac, dice = eng.train_forward_backward(img, mask)
-    rl, ra, rj, rd, rgrads = train_ref.fcn_loss_and_grads("fcn_skip", Wt, img, mask)
+    # the referee runs in float64: torch's own float32 bias-gradient reduction over 3.1 M cancelling terms is off by ~1 %
+    rl, ra, rj, rd, rgrads = train_ref.fcn_loss_and_grads("fcn_skip", Wt, img, mask, float64=True)
     assert abs(loss - rl) <= 1e-4 * abs(rl), (loss, rl)               # north_star: loss within 1e-4 relative
     assert abs(acc - ra) <= 1e-5 and abs(jac - rj) <= 1e-4 * abs(rj) and abs(dice - rd) <= 1e-4 * abs(rd)
     g = eng.gradients()
     for k, want in rgrads.items():
         scale = float(np.abs(want).max()) + 1e-12
-        # float32 sums over up to 3.1 M pixels in another order (bias gradients are plain sums of a signed map)
+        # float32 products and partial sums over up to 3.1 M pixels against a float64 referee
         assert float(np.abs(g[k] - want).max()) <= 2e-3 * scale, k
     # >= 20 further steps (Adam lr 1e-4 is lib/network.py:23's default; 1e-3 here so that 20 steps move the loss):
-    # two engines fed the same pages stay bit-identical, the loss goes down
+    # two engines fed the same pages stay together (the weight-gradient kernels accumulate with float atomics, so the order
+    # of their partial sums -- not the sums' terms -- varies from run to run: ~1e-7 relative per step), the loss goes down
     eng2 = gpu.Engine("fcn_skip", C, mode=gpu.MODE_F32_EXACT)
     eng2.set_weights(Wt)
     eng2.train_init(clipnorm=1.0)
@@ -91,13 +93,13 @@ def test_config3_full_size_train_step_matches_torch_autograd(gpu):
         im, mk = pages[it % len(pages)]
         l1 = eng.train_forward_backward(im, mk)[0]
         l2 = eng2.train_forward_backward(im, mk)[0]
-        assert l1 == l2
+        assert abs(l1 - l2) <= 2e-3 * abs(l1), (it, l1, l2)          # the tiny differences compound through Adam
         eng.train_apply(1e-3)
         eng2.train_apply(1e-3)
         losses.append(l1)
     assert np.isfinite(losses).all() and np.mean(losses[-3:]) < 0.8 * np.mean(losses[:3]), losses
     w1, w2 = eng.get_weights(), eng2.get_weights()
-    assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+    assert all(np.abs(w1[k] - w2[k]).max() <= 5e-3 for k in w1)      # 22 Adam steps of <= 1e-3 each
     eng.close()
     eng2.close()
 
@@ -186,3 +188,29 @@ def test_config3_data_parallel_two_ranks_real_network_path(gpu, tmp_path):
     for k, v in ws.items():
         assert np.abs(v - w0[k.replace("/", "__")]).max() <= 2e-5, k
     eng.close()
+
+
+def test_bench_self_launch_two_ranks(gpu):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its two rank processes itself and prints one JSON line with
+    n_gpus = 2 (the driver's command form).  Rehearsed on this one-GPU box with the gloo rendezvous and both ranks on cuda:0
+    (PSEG_BENCH_BACKEND / PSEG_BENCH_ONE_GPU); a missing GPU makes the launcher fail fast instead of hanging."""
+    import json
+    env = dict(os.environ, PSEG_BENCH_BACKEND="gloo", PSEG_BENCH_ONE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extra",
+                        "--no-cpu-baseline", "--height", "512", "--width", "384"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 3
+    assert d["metric"] == "Mpixels/s classified (512x384, 3-class)"
+    # without the rehearsal knobs rank 1 has no GPU here: non-zero exit within seconds, no hang
+    env2 = dict(os.environ)
+    env2.pop("WORLD_SIZE", None)
+    env2.pop("RANK", None)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extra",
+                         "--no-cpu-baseline", "--height", "64", "--width", "64"], env=env2, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r2.returncode != 0 and "rank" in r2.stderr

@@ -1314,11 +1314,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // =============================== CONSUMERS ===============================
     // A wave owns four rows x 32 pixels of the tile = eight 16-pixel tiles m (row m >> 1, column tile m & 1) x two cout tiles.
-    // The tile is computed in TWO PHASES of four pixel tiles each (rows 0-1, then rows 2-3): while a phase's 19 k-steps
-    // accumulate one half, the epilogue of the half finished just before -- bias is already in, fused 2x2 max-pool (its row
-    // pairs lie inside a half), bf16 rounding, the skip-logits MFMAs, all stores -- is issued in pieces between that phase's
-    // MFMAs.  A wave alone on its SIMD's matrix pipe therefore never leaves it to run an epilogue: only the very last half of
-    // the workgroup's last tile drains on its own.  (Cost: the A fragments are read once per phase, +20 % LDS reads.)
+    // Two forms of the tile loop (bit-identical results): the default runs ONE k-loop over all eight pixel tiles and then the
+    // epilogue; PSEG_WS_2PHASE computes the tile in two phases of four pixel tiles (rows 0-1, then rows 2-3) and issues the
+    // epilogue of the half finished just before -- fused 2x2 max-pool (its row pairs lie inside a half), bf16 rounding, the
+    // skip-logits MFMAs, all stores -- in pieces between the current phase's MFMAs.
     // B fragment of pixel tile m for k-step s: one ds_read_b128 at (tile + lane pixel + chunk offset of (s, g)) + an
     // immediate ((m >> 1) rows, (m & 1) * 16 pixels); A fragment (s, t): weights + lane * 16 + an immediate.  The 19 chunk
     // offsets of this lane group stay in registers for the whole kernel.
@@ -1436,6 +1435,78 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     long long tk = 0, te = 0, tw = 0;
     int poy = 0, pox = 0;
+    if (a.dbg & 0x400) {
+        // Default form: the whole tile in ONE k-loop (eight pixel tiles per A fragment) and the epilogue after it; the producer
+        // on the same SIMD gets the matrix pipe and most issue slots meanwhile.  The two-phase form below (PSEG_WS_2PHASE) hides
+        // the epilogue behind the consumer's own MFMAs but reads every A fragment twice (+17 % LDS reads): 99.5 vs 94.5 us.
+        for (int i = 0; i < n_my; ++i) {
+            const long long c0 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            const char* in_t = smem + (i & 1) * TB;
+            const int t = xcd_tile((int)blockIdx.x + i * (int)gridDim.x);
+            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+            const int oy0 = ty * TH, ox0 = tx * TW;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                accA[m][0] = accB[m][0] = f32x4{bias0.x, bias0.y, bias0.z, bias0.w};
+                accA[m][1] = accB[m][1] = f32x4{bias1.x, bias1.y, bias1.z, bias1.w};
+            }
+            {
+                bf16x8 xs[2][MT], ws2[2][NT];
+#define WS_LOAD8(SET, S)                                                                              \
+                {                                                                                     \
+                    const char* va_ = in_t + offv[S];                                                 \
+                    ws2[SET][0] = *(const bf16x8*)(wb + ((S) * NT) * 1024);                           \
+                    _Pragma("unroll") for (int m = 0; m < MT; ++m)                                    \
+                        xs[SET][m] = *(const bf16x8*)(va_ + (m >> 1) * ROWP + (m & 1) * 16 * PS2);    \
+                    ws2[SET][1] = *(const bf16x8*)(wb + ((S) * NT + 1) * 1024);                       \
+                }
+                WS_LOAD8(0, 0)
+#pragma unroll
+                for (int s2 = 0; s2 < KSTEPS; ++s2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s2 + 1 < KSTEPS) WS_LOAD8((s2 + 1) & 1, s2 + 1)
+#pragma unroll
+                    for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            f32x4& ac = m < 4 ? accA[m][t2] : accB[m - 4][t2];
+                            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws2[s2 & 1][t2], xs[s2 & 1][m], ac, 0, 0, 0);
+                        }
+                    if (s2 + 1 < KSTEPS) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+#pragma unroll
+                        for (int r = 0; r < 10; ++r) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#undef WS_LOAD8
+            }
+            const long long c1 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                f32x4 (&hacc)[4][NT] = hb == 0 ? accA : accB;
+                piece_P(hacc, hb, oy0, ox0, true, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                piece_P(hacc, hb, oy0, ox0, true, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+                piece_S(hb, oy0, ox0, true, std::integral_constant<int, 0>{});
+                piece_P(hacc, hb, oy0, ox0, true, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                piece_P(hacc, hb, oy0, ox0, true, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                piece_S(hb, oy0, ox0, true, std::integral_constant<int, 1>{});
+            }
+            const long long c2 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            lds_barrier();
+            if (a.trace) { tk += c1 - c0; te += c2 - c1; tw += (long long)__builtin_amdgcn_s_memtime() - c2; }
+        }
+        if (a.trace && lane == 0) {
+            unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 4;
+            o[0] = (unsigned long long)tk; o[1] = (unsigned long long)te; o[2] = (unsigned long long)tw; o[3] = (unsigned long long)n_my;
+        }
+        return;
+    }
     for (int i = 0; i < n_my; ++i) {
         const long long c0 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const char* in_t = smem + (i & 1) * TB;
@@ -3140,6 +3211,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         w.ntiles = (int)grid.x;
         const int lds = WS_TILE0 + 2 * TB + P->ks_full * P->NT * 1024 + round_up(P->ks_full * 16, 16) + 4 * (2 * 9 * 96 + 16);
         if (const char* pr = PSEG_KNOB("PSEG_WS_PRIO")) w.dbg |= (atoi(pr) & 3) << 8;
+        if (!PSEG_KNOB("PSEG_WS_2PHASE")) w.dbg |= 0x400;      // default: one k-loop per tile (measured 5 % faster than the two-phase form)
         if (lds <= 160 * 1024 && P->GK >= P->ks_full && P->row_pitch == WS_ROWP && P->ks_full == (P->pairc2 ? WS_KSTEPS_PAIR : WS_KSTEPS)) {
             const unsigned gx = std::min<unsigned>(grid.x, (unsigned)cus_ws);
             const int sk = op.skiplog >= 0 ? 1 : 0, variant = sk * 2 + (P->pairc2 ? 1 : 0);

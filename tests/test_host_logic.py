@@ -142,3 +142,108 @@ def test_synthetic_weights_agree_with_oracle_init(oracle_mod):
     img, binary, mask = synth.synth_page(3, 128, 96, 6)
     assert img.shape == (128, 96) and img.dtype == np.uint8 and set(np.unique(binary)) <= {0, 1}
     assert mask.max() <= 5 and np.array_equal(synth.synth_page(3, 128, 96, 6)[0], img)
+
+
+# ---- round 2: model files decide the graph; Keras layer order; lazy probabilities (no GPU needed) ----------------------------
+class _FakeEngine:
+    def __init__(self, specs):
+        self._specs, self.got = specs, None
+
+    def weight_specs(self):
+        return self._specs
+
+    def set_weights(self, w):
+        self.got = w
+
+
+def _res_unet_specs(C=3):
+    """res_unet weight table in the engine's (Keras creation) order: stem (k3, k3, k1), 8 residual blocks (conv_a, conv_b,
+    shortcut), 2 bridge convs, logits."""
+    f = [32, 64, 128, 256, 512]
+    specs, n = [], [0]
+
+    def conv(cin, cout, k=3):
+        name = "conv2d" if n[0] == 0 else "conv2d_%d" % n[0]
+        n[0] += 1
+        specs.append((name + "/kernel", (k, k, cin, cout)))
+        specs.append((name + "/bias", (cout,)))
+    conv(1, f[0]); conv(f[0], f[0]); conv(1, f[0], 1)
+    cin = f[0]
+    for l in range(1, 5):
+        conv(cin, f[l]); conv(f[l], f[l]); conv(cin, f[l]); cin = f[l]
+    conv(f[4], f[4]); conv(f[4], f[4])
+    for l, skip in ((4, f[3]), (3, f[2]), (2, f[1]), (1, f[0])):
+        c2 = cin + skip
+        conv(c2, f[l]); conv(f[l], f[l]); conv(c2, f[l]); cin = f[l]
+    specs.append(("logits/kernel", (1, 1, f[1], C)))
+    specs.append(("logits/bias", (C,)))
+    return specs
+
+
+def test_network_reads_graph_and_classes_from_the_model_file(tmp_path):
+    from ocr4all_pixel_classifier.lib.network import Network
+    rng = np.random.default_rng(0)
+    mk = lambda sh: rng.standard_normal(sh).astype(np.float32)
+    skip = [("conv2d/kernel:0", mk((5, 5, 1, 20))), ("conv2d_transpose/kernel:0", mk((5, 5, 80, 80))),
+            ("conv2d_transpose_2/kernel:0", mk((5, 5, 40, 120))), ("logits/kernel:0", mk((1, 1, 50, 6)))]
+    assert Network._graph_of_file("m.npz", skip) == ("fcn_skip", 6, 1)
+    plain = [("conv2d/kernel:0", mk((5, 5, 3, 20))), ("conv2d_transpose/kernel:0", mk((5, 5, 80, 80))),
+             ("conv2d_transpose_2/kernel:0", mk((5, 5, 40, 60))), ("logits/kernel:0", mk((1, 1, 20, 3)))]
+    assert Network._graph_of_file("m.npz", plain) == ("fcn", 3, 3)
+    assert Network._graph_of_file("m.npz", [("conv2d/kernel:0", mk((3, 3, 1, 64))), ("logits/kernel:0", mk((1, 1, 64, 4)))]) == ("unet", 4, 1)
+    assert Network._graph_of_file("m.npz", [("conv2d/kernel:0", mk((3, 3, 1, 32))), ("logits/kernel:0", mk((1, 1, 64, 2)))]) == ("res_unet", 2, 1)
+    # a full-model Keras file names its model: the golden fixture's is Keras' default 'model' -> the shapes decide
+    from pseg_amd import h5lite
+    full = os.path.join(os.path.dirname(__file__), "golden", "keras_full_model.h5")
+    assert h5lite.read_keras_model_name(full) == "model"
+    assert h5lite.read_keras_model_name(os.path.join(os.path.dirname(__file__), "golden", "keras_weights.h5")) is None
+
+
+def test_res_unet_files_are_matched_in_keras_layer_order(tmp_path):
+    """Keras lists a residual block as (conv_a, shortcut, conv_b) -- depth order, ties by traversal from Add([shortcut, res]) --
+    while the engine's table is creation order (conv_a, conv_b, shortcut): loading goes by the numeric name suffix per layer
+    class, whatever offset the per-process counters carry; saving emits Keras' order."""
+    from ocr4all_pixel_classifier.lib.network import Network
+    from pseg_amd import h5lite
+    specs = _res_unet_specs()
+    rng = np.random.default_rng(1)
+    want = {n: rng.standard_normal(sh).astype(np.float32) * 0.01 for n, sh in specs}
+    net = Network.__new__(Network)
+    net.architecture = "res_unet"
+    net.model = _FakeEngine(specs)
+    layers = []
+    for n, _ in specs:
+        ln = n.split("/")[0]
+        if not layers or layers[-1] != ln:
+            layers.append(ln)
+    keras = net._keras_layer_order(layers)
+    assert keras[:6] == ["conv2d", "conv2d_1", "conv2d_2", "conv2d_3", "conv2d_5", "conv2d_4"] and keras[-1] == "logits"
+    assert sorted(keras) == sorted(layers)
+    # a "trained" file: Keras order, counters offset by 14
+    def shifted(ln):
+        if ln == "logits":
+            return ln
+        base, _, suf = ln.rpartition("_")
+        k = int(suf) if suf.isdigit() else 0
+        return "conv2d_%d" % (k + 14)
+    file_layers = [("input_1", [])] + [(shifted(ln), [(shifted(ln) + "/kernel:0", want[ln + "/kernel"]), (shifted(ln) + "/bias:0", want[ln + "/bias"])])
+                                       for ln in keras]
+    path = str(tmp_path / "res_unet.h5")
+    h5lite.write_keras_weights(path, file_layers)
+    file_w = Network._read_weight_file(path)
+    assert Network._graph_of_file(path, file_w)[0] == "res_unet"
+    net._set_file_weights(path, file_w)
+    assert set(net.model.got) == set(want) and all(np.array_equal(net.model.got[k], want[k]) for k in want)
+    # positional matching (round 1) would have put the shortcut kernel where conv_b's belongs: shapes differ there
+    assert want["conv2d_4/kernel"].shape != want["conv2d_5/kernel"].shape
+
+
+def test_prediction_probabilities_can_be_lazy():
+    from ocr4all_pixel_classifier.lib.predictor_data import LazyArray, Prediction
+    calls = []
+    p = Prediction(np.zeros((2, 2), np.int64), LazyArray(lambda: calls.append(1) or np.ones((2, 2, 3), np.float32)), "data")
+    assert calls == []
+    labels, prob, data = p
+    assert prob.shape == (2, 2, 3) and p.probabilities is prob and p[1] is prob and calls == [1] and data == "data"
+    q = Prediction(labels, prob, data)
+    assert q.probabilities is prob and len(q) == 3 and q._fields == ("labels", "probabilities", "data")

@@ -1020,7 +1020,10 @@ constexpr int WS_TILE0 = 16;      // the tiles start 16 bytes into LDS: a pixel'
 
 // PAIRC2: channels 16-19 of a pixel are written twice -- into bytes 32-39 of its own 48-byte slot and into bytes 40-47 of its
 // LEFT neighbour's slot -- so that the k-chunk "third chunk under tap kx" also carries tap kx + 1 (see pair_chunks): 17 k-steps.
-template <bool SKIPLOG, bool PAIRC2>
+// FORM: the consumers' tile loop -- 0: one k-loop per tile, epilogue after it (default); 1: two phases of four pixel tiles, the
+// epilogue of the previous half between the MFMAs (PSEG_WS_FORM=1); 2: one k-loop per tile with the epilogue of the PREVIOUS
+// tile between its MFMAs, two accumulator sets (PSEG_WS_FORM=2).  All three produce the same bits.
+template <bool SKIPLOG, bool PAIRC2, int FORM = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv12_ws_kernel(MConv a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* const smem = smem_raw + WS_TILE0;
@@ -1315,7 +1318,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // =============================== CONSUMERS ===============================
     // A wave owns four rows x 32 pixels of the tile = eight 16-pixel tiles m (row m >> 1, column tile m & 1) x two cout tiles.
     // Two forms of the tile loop (bit-identical results): the default runs ONE k-loop over all eight pixel tiles and then the
-    // epilogue; PSEG_WS_2PHASE computes the tile in two phases of four pixel tiles (rows 0-1, then rows 2-3) and issues the
+    // epilogue; PSEG_WS_FORM=1 computes the tile in two phases of four pixel tiles (rows 0-1, then rows 2-3) and issues the
     // epilogue of the half finished just before -- fused 2x2 max-pool (its row pairs lie inside a half), bf16 rounding, the
     // skip-logits MFMAs, all stores -- in pieces between the current phase's MFMAs.
     // B fragment of pixel tile m for k-step s: one ds_read_b128 at (tile + lane pixel + chunk offset of (s, g)) + an
@@ -1356,7 +1359,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int h = 0; h < 2; ++h) {
             const f32x4 v = acc[c + 2 * h][t2];
             const uint2 pk = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
-            if constexpr (SKIPLOG) pks[t2][c + 2 * h] = pk;
+            if constexpr (SKIPLOG) { if constexpr (FORM != 2) pks[t2][c + 2 * h] = pk; }
             else {
                 const int y = doy + wave * (MT / 2) + 2 * hb + h, x = dox + c * 16 + p16;
                 const unsigned o = (valid && y < a.Hout && x < a.Wout && noff != OOBS) ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) + noff : OOBS;
@@ -1371,14 +1374,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rp, o, 0, 0);
     };
     // S(c): the skip-logits products of local tiles c and c + 2 (both cout tiles rounded by then)
-    auto piece_S = [&](int hb, int doy, int dox, bool valid, auto cc) {
+    auto piece_S = [&](int hb, int doy, int dox, bool valid, auto cc, f32x4 (*sacc)[NT] = nullptr) {
         constexpr int c = decltype(cc)::value;
         if constexpr (SKIPLOG) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int lm = c + 2 * h;
                 f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, __builtin_bit_cast(bf16x8, make_uint4(pks[0][lm].x, pks[0][lm].y, pks[1][lm].x, pks[1][lm].y)), z, 0, 0, 0);
+                uint4 bq;
+                if constexpr (FORM == 2) {   // no registers for the pairs piece_P rounded: round them again from the accumulators
+                    const f32x4 v0 = sacc[lm][0], v1 = sacc[lm][1];
+                    bq = make_uint4(pk_bf16(v0[0], v0[1]), pk_bf16(v0[2], v0[3]), pk_bf16(v1[0], v1[1]), pk_bf16(v1[2], v1[3]));
+                } else {
+                    bq = make_uint4(pks[0][lm].x, pks[0][lm].y, pks[1][lm].x, pks[1][lm].y);
+                }
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, __builtin_bit_cast(bf16x8, bq), z, 0, 0, 0);
                 const int y = doy + wave * (MT / 2) + 2 * hb + h, x = dox + c * 16 + p16;
                 const unsigned o = (valid && y < a.Hout && x < a.Wout && 4 * g < a.skip_CP) ? ((unsigned)(y * a.Wout + x) * (unsigned)a.skip_CP + 4u * g) * 4u : OOBS;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, z), rs, o, 0, 0);
@@ -1435,9 +1445,142 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     long long tk = 0, te = 0, tw = 0;
     int poy = 0, pox = 0;
-    if (a.dbg & 0x400) {
+    if constexpr (FORM == 2) {
+        // One k-loop per tile (every A fragment serves eight pixel tiles) AND no epilogue phase: the finished tile's accumulators
+        // stay in a second register set and drain in twelve pieces between the MFMAs of the next tile's k-loop.
+        f32x4 accC[4][NT], accD[4][NT];                         // second accumulator set (halves as accA / accB)
+        auto tile_pass = [&](const char* in_t, f32x4 (&cA)[4][NT], f32x4 (&cB)[4][NT], f32x4 (&dA)[4][NT], f32x4 (&dB)[4][NT],
+                             int doy, int dox, bool valid) {
+            {   // (the bias is re-read per tile: eight registers that would otherwise live through the k-loop)
+                const float4 bb0 = *(const float4*)(a.bias + 4 * g), bb1 = *(const float4*)(a.bias + 16 + 4 * g);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    cA[m][0] = cB[m][0] = f32x4{bb0.x, bb0.y, bb0.z, bb0.w};
+                    cA[m][1] = cB[m][1] = f32x4{bb1.x, bb1.y, bb1.z, bb1.w};
+                }
+            }
+            // Registers are the limit of this form (two accumulator sets): ONE set of pixel fragments -- the MFMAs of a k-step run
+            // pixel tile by pixel tile (both cout tiles of tile m back to back), and the next step's fragment of tile m is read
+            // into the same registers right behind them, 14 MFMAs before its first use -- two sets of kernel fragments, and the 17
+            // chunk offsets come from the LDS table one k-step ahead instead of living in registers.
+            bf16x8 xs[MT], ws2[2][NT];
+            const char* const bt = in_t + (wave * (MT / 2)) * ROWP + p16 * PS2;
+            const int* const tbl = tab_l + g;
+            int toff[2];
+            toff[0] = tbl[0];
+            toff[1] = tbl[4];
+            {
+                const char* va_ = bt + toff[0];
+                ws2[0][0] = *(const bf16x8*)(wb);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xs[m] = *(const bf16x8*)(va_ + (m >> 1) * ROWP + (m & 1) * 16 * PS2);
+                ws2[0][1] = *(const bf16x8*)(wb + 1024);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < KSTEPS; ++s2) {
+                __builtin_amdgcn_sched_barrier(0);
+                const bool more = s2 + 1 < KSTEPS;
+                const char* va_ = bt + toff[(s2 + 1) & 1];
+                if (more) {
+                    ws2[(s2 + 1) & 1][0] = *(const bf16x8*)(wb + ((s2 + 1) * NT) * 1024);
+                    ws2[(s2 + 1) & 1][1] = *(const bf16x8*)(wb + ((s2 + 1) * NT + 1) * 1024);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x4& a0_ = m < 4 ? cA[m][0] : cB[m - 4][0];
+                    f32x4& a1_ = m < 4 ? cA[m][1] : cB[m - 4][1];
+                    a0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws2[s2 & 1][0], xs[m], a0_, 0, 0, 0);
+                    a1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws2[s2 & 1][1], xs[m], a1_, 0, 0, 0);
+                    if (more) xs[m] = *(const bf16x8*)(va_ + (m >> 1) * ROWP + (m & 1) * 16 * PS2);
+                }
+                if (s2 + 2 < KSTEPS) toff[s2 & 1] = tbl[(s2 + 2) * 4];        // slot s2 & 1 was consumed by the previous region's reads
+                // the previous tile's epilogue: half 0 in k-steps 1-6, half 1 in k-steps 7-12
+                if (s2 >= 1 && s2 <= 12) {
+                    const int hb = s2 <= 6 ? 0 : 1, pc = (s2 - 1) % 6;
+                    f32x4 (&hacc)[4][NT] = s2 <= 6 ? dA : dB;
+                    if (pc == 0) piece_P(hacc, hb, doy, dox, valid, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                    if (pc == 1) piece_P(hacc, hb, doy, dox, valid, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+                    if (pc == 2) piece_S(hb, doy, dox, valid, std::integral_constant<int, 0>{}, hacc);
+                    if (pc == 3) piece_P(hacc, hb, doy, dox, valid, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                    if (pc == 4) piece_P(hacc, hb, doy, dox, valid, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                    if (pc == 5) piece_S(hb, doy, dox, valid, std::integral_constant<int, 1>{}, hacc);
+                }
+                // issue order: the address add and the two kernel-fragment reads, then per pixel tile its two MFMAs, the read of its
+                // next fragment and two epilogue VALU instructions
+                if (more) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (more) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // two tiles per trip: the accumulator sets keep their roles (A/B accumulate even tiles, C/D odd ones), so no register
+        // moves at the loop edge
+        auto origin = [&](int i, int& oy, int& ox) {
+            const int t = xcd_tile((int)blockIdx.x + i * (int)gridDim.x);
+            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+            oy = ty * TH; ox = tx * TW;
+        };
+        for (int i = 0; i < n_my; i += 2) {
+            long long c0 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            int oy0, ox0;
+            origin(i, oy0, ox0);
+            tile_pass(smem, accA, accB, accC, accD, poy, pox, i > 0);              // even tile: buffer 0
+            poy = oy0; pox = ox0;
+            long long c2 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            lds_barrier();
+            if (a.trace) { tk += c2 - c0; tw += (long long)__builtin_amdgcn_s_memtime() - c2; }
+            if (i + 1 < n_my) {
+                c0 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+                origin(i + 1, oy0, ox0);
+                tile_pass(smem + TB, accC, accD, accA, accB, poy, pox, true);      // odd tile: buffer 1
+                poy = oy0; pox = ox0;
+                c2 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+                lds_barrier();
+                if (a.trace) { tk += c2 - c0; tw += (long long)__builtin_amdgcn_s_memtime() - c2; }
+            }
+        }
+        {   // the last tile drains on its own
+            const long long c1 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+            const bool odd = (n_my & 1) == 0;                     // the last tile (n_my - 1) used set C/D when its index is odd
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                if (odd) {
+                    f32x4 (&hacc)[4][NT] = hb == 0 ? accC : accD;
+                    piece_P(hacc, hb, poy, pox, n_my > 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                    piece_P(hacc, hb, poy, pox, n_my > 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+                    piece_S(hb, poy, pox, n_my > 0, std::integral_constant<int, 0>{}, hacc);
+                    piece_P(hacc, hb, poy, pox, n_my > 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                    piece_P(hacc, hb, poy, pox, n_my > 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                    piece_S(hb, poy, pox, n_my > 0, std::integral_constant<int, 1>{}, hacc);
+                } else {
+                    f32x4 (&hacc)[4][NT] = hb == 0 ? accA : accB;
+                    piece_P(hacc, hb, poy, pox, n_my > 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                    piece_P(hacc, hb, poy, pox, n_my > 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+                    piece_S(hb, poy, pox, n_my > 0, std::integral_constant<int, 0>{}, hacc);
+                    piece_P(hacc, hb, poy, pox, n_my > 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                    piece_P(hacc, hb, poy, pox, n_my > 0, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                    piece_S(hb, poy, pox, n_my > 0, std::integral_constant<int, 1>{}, hacc);
+                }
+            }
+            if (a.trace) te += (long long)__builtin_amdgcn_s_memtime() - c1;
+        }
+        if (a.trace && lane == 0) {
+            unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 4;
+            o[0] = (unsigned long long)tk; o[1] = (unsigned long long)te; o[2] = (unsigned long long)tw; o[3] = (unsigned long long)n_my;
+        }
+        return;
+    }
+    if constexpr (FORM == 0) {
         // Default form: the whole tile in ONE k-loop (eight pixel tiles per A fragment) and the epilogue after it; the producer
-        // on the same SIMD gets the matrix pipe and most issue slots meanwhile.  The two-phase form below (PSEG_WS_2PHASE) hides
+        // on the same SIMD gets the matrix pipe and most issue slots meanwhile.  The two-phase form below (PSEG_WS_FORM=1) hides
         // the epilogue behind the consumer's own MFMAs but reads every A fragment twice (+17 % LDS reads): 99.5 vs 94.5 us.
         for (int i = 0; i < n_my; ++i) {
             const long long c0 = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -3211,13 +3354,16 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         w.ntiles = (int)grid.x;
         const int lds = WS_TILE0 + 2 * TB + P->ks_full * P->NT * 1024 + round_up(P->ks_full * 16, 16) + 4 * (2 * 9 * 96 + 16);
         if (const char* pr = PSEG_KNOB("PSEG_WS_PRIO")) w.dbg |= (atoi(pr) & 3) << 8;
-        if (!PSEG_KNOB("PSEG_WS_2PHASE")) w.dbg |= 0x400;      // default: one k-loop per tile (measured 5 % faster than the two-phase form)
+        const int form = PSEG_KNOB("PSEG_WS_FORM") ? atoi(PSEG_KNOB("PSEG_WS_FORM")) : 0;
         if (lds <= 160 * 1024 && P->GK >= P->ks_full && P->row_pitch == WS_ROWP && P->ks_full == (P->pairc2 ? WS_KSTEPS_PAIR : WS_KSTEPS)) {
             const unsigned gx = std::min<unsigned>(grid.x, (unsigned)cus_ws);
-            const int sk = op.skiplog >= 0 ? 1 : 0, variant = sk * 2 + (P->pairc2 ? 1 : 0);
-            const void* fn = variant == 3 ? (const void*)conv12_ws_kernel<true, true> : variant == 2 ? (const void*)conv12_ws_kernel<true, false>
-                           : variant == 1 ? (const void*)conv12_ws_kernel<false, true> : (const void*)conv12_ws_kernel<false, false>;
-            static bool attr_ws[64][4] = {{false}};
+            const int sk = op.skiplog >= 0 ? 1 : 0;
+            int variant = sk * 2 + (P->pairc2 ? 1 : 0);
+            if (variant == 3 && (form == 1 || form == 2)) variant = 3 + form;       // the alternative tile loops exist for the default packing only
+            const void* fn = variant == 5 ? (const void*)conv12_ws_kernel<true, true, 2> : variant == 4 ? (const void*)conv12_ws_kernel<true, true, 1>
+                           : variant == 3 ? (const void*)conv12_ws_kernel<true, true, 0> : variant == 2 ? (const void*)conv12_ws_kernel<true, false, 0>
+                           : variant == 1 ? (const void*)conv12_ws_kernel<false, true, 0> : (const void*)conv12_ws_kernel<false, false, 0>;
+            static bool attr_ws[64][6] = {{false}};
             if (!attr_ws[dev & 63][variant]) {
                 PSEG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr_ws[dev & 63][variant] = true;
@@ -3227,10 +3373,12 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
                 PSEG_HIP(hipMemset(w.trace, 0, (size_t)gx * 8 * 4 * 8));
             }
             switch (variant) {
-                case 3: conv12_ws_kernel<true, true><<<dim3(gx), 512, lds, st>>>(w); break;
-                case 2: conv12_ws_kernel<true, false><<<dim3(gx), 512, lds, st>>>(w); break;
-                case 1: conv12_ws_kernel<false, true><<<dim3(gx), 512, lds, st>>>(w); break;
-                default: conv12_ws_kernel<false, false><<<dim3(gx), 512, lds, st>>>(w); break;
+                case 5: conv12_ws_kernel<true, true, 2><<<dim3(gx), 512, lds, st>>>(w); break;
+                case 4: conv12_ws_kernel<true, true, 1><<<dim3(gx), 512, lds, st>>>(w); break;
+                case 3: conv12_ws_kernel<true, true, 0><<<dim3(gx), 512, lds, st>>>(w); break;
+                case 2: conv12_ws_kernel<true, false, 0><<<dim3(gx), 512, lds, st>>>(w); break;
+                case 1: conv12_ws_kernel<false, true, 0><<<dim3(gx), 512, lds, st>>>(w); break;
+                default: conv12_ws_kernel<false, false, 0><<<dim3(gx), 512, lds, st>>>(w); break;
             }
             if (ws_trace) {
                 PSEG_HIP(hipStreamSynchronize(st));

@@ -276,11 +276,12 @@ def test_bf16_wave_specialised_conv12_is_bit_identical_to_the_fused_instance(gpu
             eng.close()
             return res
         paired = run_all()                                    # default: 17 k-steps (paired half chunks), 32x32x16 first layer
-        monkeypatch.setenv("PSEG_WS_2PHASE", "1")
-        two_phase = run_all()                                 # the consumers' two-phase tile loop: same sums, same bits
-        monkeypatch.delenv("PSEG_WS_2PHASE")
-        for (z1, l1, p1), (z2, l2, p2) in zip(paired, two_phase):
-            assert np.array_equal(p1, p2) and np.array_equal(z1, z2) and np.array_equal(l1, l2)
+        for form in ("1", "2"):                               # the consumers' other tile loops: same sums, same bits
+            monkeypatch.setenv("PSEG_WS_FORM", form)
+            other = run_all()
+            monkeypatch.delenv("PSEG_WS_FORM")
+            for (z1, l1, p1), (z2, l2, p2) in zip(paired, other):
+                assert np.array_equal(p1, p2) and np.array_equal(z1, z2) and np.array_equal(l1, l2), form
         monkeypatch.setenv("PSEG_NO_PAIRC2", "1")
         monkeypatch.setenv("PSEG_NO_C32", "1")
         plain = run_all()                                     # the fused instance's 19-step order and 16x16x32 first layer

@@ -57,6 +57,17 @@ int pseg_device_count(void);
  * lib/model.py:45 (fcn_skip), :206 (fcn), :151 (unet), :237 (res_unet). */
 int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
                 pseg_engine** out);
+/* ... with graph options.  PSEG_FLAG_BATCHNORM: tf.keras.layers.BatchNormalization (defaults: epsilon 1e-3, momentum
+ * 0.99) at the sites the reference's constructors provide for it -- res_unet's bn_act (lib/model.py:265-271: in front
+ * of every pre-activation ReLU and behind every shortcut convolution; the reference hard-wires its switch to False)
+ * -- the same placement as conv_block_simple's Conv2D -> BatchNormalization -> ReLU (lib/model.py:310-317) behind the
+ * shortcut convolutions.  Adds "batch_normalization[_N]/gamma|beta|moving_mean|moving_variance" to the weight table
+ * (Keras order).  Prediction and pseg_eval_step use the moving statistics; pseg_train_forward_backward normalises with
+ * the page's batch statistics, updates the moving ones and back-propagates through the layer.  Only
+ * PSEG_ARCH_RES_UNET has such sites (PSEG_EUNSUPPORTED otherwise).  flags = 0 is pseg_create. */
+enum { PSEG_FLAG_BATCHNORM = 1 };
+int pseg_create_ex(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
+                   pseg_engine** out);
 int pseg_destroy(pseg_engine* e);
 
 /* Weight table in Keras creation order; names are Keras' default layer names plus

@@ -31,11 +31,20 @@ class _Namer:
         return base if i == 0 else "%s_%d" % (base, i)
 
 
-def weight_specs(arch, n_classes, in_ch=1):
+BN_EPS = np.float32(1e-3)     # tf.keras.layers.BatchNormalization defaults (lib/model.py:268 passes none)
+BN_MOMENTUM = np.float32(0.99)
+
+
+def weight_specs(arch, n_classes, in_ch=1, batch_norm=False):
     """[(layer_name, kind, kernel_shape_keras, cout)] in Keras creation order.
-    kind: 'conv' | 'tconv' (Conv2DTranspose)."""
+    kind: 'conv' | 'tconv' (Conv2DTranspose) | 'bn' (BatchNormalization over `cout` channels; only with batch_norm=True,
+    at res_unet's bn_act sites, lib/model.py:265-271)."""
     nm = _Namer()
     S = []
+
+    def bn(c):
+        if batch_norm:
+            S.append((nm("batch_normalization"), "bn", (c,), c))
 
     def conv(cin, cout, k, name=None):
         S.append((name or nm("conv2d"), "conv", (k, k, cin, cout), cout))
@@ -70,16 +79,21 @@ def weight_specs(arch, n_classes, in_ch=1):
         # lib/model.py:237-307, f = [32,64,128,256,512]
         f = [32, 64, 128, 256, 512]
         conv(in_ch, f[0], 3)       # stem conv            :252
+        bn(f[0])
         conv(f[0], f[0], 3)        # stem conv_block      :253
         conv(in_ch, f[0], 1)       # stem shortcut k1     :254
+        bn(f[0])                   # bn_act(shortcut, act=False) :255
 
         def res(cin, cout):
+            bn(cin)
             conv(cin, cout, 3)     # conv_block 1 (stride s)   :244
+            bn(cout)
             conv(cout, cout, 3)    # conv_block 2              :245
             conv(cin, cout, 3)     # shortcut (stride s)       :246
+            bn(cout)               # bn_act(shortcut, act=False) :247
 
         res(f[0], f[1]); res(f[1], f[2]); res(f[2], f[3]); res(f[3], f[4])   # :281-284
-        conv(f[4], f[4], 3); conv(f[4], f[4], 3)                              # bridge :287-288
+        bn(f[4]); conv(f[4], f[4], 3); bn(f[4]); conv(f[4], f[4], 3)         # bridge :287-288
         res(f[4] + f[3], f[4])     # d1 :291-292
         res(f[4] + f[2], f[3])     # d2 :294-295
         res(f[3] + f[1], f[2])     # d3 :297-298
@@ -90,13 +104,20 @@ def weight_specs(arch, n_classes, in_ch=1):
     return S
 
 
-def init_weights(arch, n_classes, seed=42, in_ch=1, gain=1.0, bias_scale=0.0):
+def init_weights(arch, n_classes, seed=42, in_ch=1, gain=1.0, bias_scale=0.0, batch_norm=False):
     """Synthetic weights: Keras glorot_uniform limits, numpy default_rng(seed) in
     layer order; biases zero unless bias_scale>0 (then U(-bias_scale, bias_scale), so that the
     pad-to-32 region and bias paths are exercised)."""
     rng = np.random.default_rng(seed)
     Wt = OrderedDict()
-    for name, kind, shp, cout in weight_specs(arch, n_classes, in_ch):
+    for name, kind, shp, cout in weight_specs(arch, n_classes, in_ch, batch_norm):
+        if kind == "bn":   # Keras: ones / zeros / zeros / ones; perturbed when bias_scale > 0 so that every term is exercised
+            j = bias_scale > 0
+            Wt[name + "/gamma"] = (1.0 + j * rng.uniform(-0.3, 0.3, size=shp)).astype(np.float32)
+            Wt[name + "/beta"] = (j * rng.uniform(-bias_scale, bias_scale, size=shp)).astype(np.float32)
+            Wt[name + "/moving_mean"] = (j * rng.uniform(-bias_scale, bias_scale, size=shp)).astype(np.float32)
+            Wt[name + "/moving_variance"] = (1.0 + j * rng.uniform(-0.3, 0.3, size=shp)).astype(np.float32)
+            continue
         rf = shp[0] * shp[1]
         limit = np.sqrt(6.0 / (rf * shp[2] + rf * shp[3])) * gain
         Wt[name + "/kernel"] = rng.uniform(-limit, limit, size=shp).astype(np.float32)
@@ -135,6 +156,7 @@ class _Ctx:
     def __init__(self, Wt, mode):
         self.W = to_bf16_weights(Wt) if mode == "bf16" else Wt
         self.q = core.round_bf16 if mode == "bf16" else (lambda a: a)
+        self.bf16 = mode == "bf16"
         self.nm = _Namer()
         self.acts = OrderedDict()
 
@@ -151,6 +173,23 @@ class _Ctx:
         if name != "logits":
             y = self.q(y)
         self.acts[keep or name] = y
+        return y
+
+    def bn(self, x, name, relu=False):
+        """BatchNormalization at inference (moving statistics), then bn_act's optional ReLU (lib/model.py:265-271).
+        f32: y = (x - mean) * (gamma / sqrt(var + eps)) + beta; bf16 engine: per-channel scale / shift in float32 on
+        the bf16 tensor."""
+        g, b = self.W[name + "/gamma"], self.W[name + "/beta"]
+        m, v = self.W[name + "/moving_mean"], self.W[name + "/moving_variance"]
+        scale = (g / np.sqrt(v + BN_EPS)).astype(np.float32)
+        if self.bf16:
+            y = x * scale + (b - m * scale).astype(np.float32)
+        else:
+            y = (x - m) * scale + b
+        if relu:
+            y = np.maximum(y, 0)
+        y = self.q(y.astype(np.float32))
+        self.acts[name] = y
         return y
 
     def tconv5(self, x, relu=False):
@@ -222,30 +261,46 @@ def _unet(c, x):
     return c.conv(t, name="logits")
 
 
-def _res_unet(c, x):
-    """lib/model.py:237-307 (BatchNorm flag hard-wired off, :265)."""
+def _res_unet(c, x, bn=False):
+    """lib/model.py:237-307.  bn=False is the reference as shipped (BatchNorm flag hard-wired off, :265); bn=True places
+    BatchNormalization where bn_act would, names in Keras creation order."""
     x, pads = _pad32(x)
+    bnn = (lambda: c.nm("batch_normalization")) if bn else (lambda: None)
+
+    def pre(t, name):
+        """bn_act(t): [BatchNormalization,] ReLU -- returns (tensor, whether the conv still has to apply the ReLU)"""
+        return (c.bn(t, name, relu=True), False) if bn else (t, True)
 
     def residual(t, stride=1):
-        r = c.conv(t, stride=stride, in_relu=True)          # conv_block 1
-        sc_name = None
-        # Keras creation order: res conv1, res conv2, shortcut -- allocate names in that order
+        a, ir = pre(t, bnn())
+        r = c.conv(a, stride=stride, in_relu=ir)            # conv_block 1
+        # Keras creation order: [bn] res conv1, [bn] res conv2, shortcut [bn] -- allocate names in that order
+        bn2 = bnn()
         n2 = c.nm("conv2d")
         sc_name = c.nm("conv2d")
         sc = c.conv(t, stride=stride, name=sc_name)         # shortcut, no activation
-        return c.conv(r, in_relu=True, name=n2, add=sc)     # Add()([shortcut, res])
+        if bn:
+            sc = c.bn(sc, bnn())
+        a2, ir2 = pre(r, bn2)
+        return c.conv(a2, in_relu=ir2, name=n2, add=sc)     # Add()([shortcut, res])
 
     # stem :251-257
     s = c.conv(x)
+    bn0 = bnn()
     n2 = c.nm("conv2d")
     sc = c.conv(x, name=c.nm("conv2d"))                     # k1 shortcut
-    e1 = c.conv(s, in_relu=True, name=n2, add=sc)
+    if bn:
+        sc = c.bn(sc, bnn())
+    a, ir = pre(s, bn0)
+    e1 = c.conv(a, in_relu=ir, name=n2, add=sc)
     e2 = residual(e1, 2)
     e3 = residual(e2, 2)
     e4 = residual(e3, 2)
     e5 = residual(e4, 2)
-    b0 = c.conv(e5, in_relu=True)
-    b1 = c.conv(b0, in_relu=True)
+    a, ir = pre(e5, bnn())
+    b0 = c.conv(a, in_relu=ir)
+    a, ir = pre(b0, bnn())
+    b1 = c.conv(a, in_relu=ir)
     d = b1
     for sk in (e4, e3, e2, e1):
         d = residual(_cat(_up2(d), sk))                     # [up, skip] order, :240
@@ -269,7 +324,7 @@ def forward(arch, Wt, image_u8, mode="f32", return_acts=False):
     elif arch == "unet":
         z = _unet(c, x)
     elif arch == "res_unet":
-        z = _res_unet(c, x)
+        z = _res_unet(c, x, bn="batch_normalization/gamma" in Wt)
     else:
         raise ValueError(arch)
     return (z, c.acts) if return_acts else z

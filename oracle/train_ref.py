@@ -100,14 +100,21 @@ def dropout_key(seed, step, op_index):
     return (base + 0x85EBCA77 * op_index) & 0xFFFFFFFF
 
 
-def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None):
+def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None, float64=False, bn_stats=None):
     """unet (lib/model.py:151-203) and res_unet (:237-307) in torch with the reference's cross-entropy (lib/metrics.py:8-9);
     `drop` = (seed, step) enables unet's two Dropout(0.5) layers with the engine's masks (op indices 10 and 13 of the
     engine's op list; masks are laid out over the (H/8, W/8, 512) and (H/16, W/16, 1024) canvases).
+    A weight table holding "batch_normalization/gamma" selects res_unet with BatchNormalization at its bn_act sites
+    (lib/model.py:265-271) in TRAINING form: batch statistics (biased variance, eps 1e-3); `bn_stats` (a dict), when
+    given, receives name -> (batch mean, biased batch variance, samples seen) for the moving-statistics update
+    moving -= (moving - batch) * (1 - 0.99), the variance with Bessel's correction.
     -> (loss, grads dict in Keras layouts, logits (H,W,C))."""
     import torch
     import torch.nn.functional as F
-    T = OrderedDict((k, torch.tensor(v, dtype=torch.float32, requires_grad=True)) for k, v in Wt.items())
+    dt = torch.float64 if float64 else torch.float32
+    T = OrderedDict((k, torch.tensor(v, dtype=dt, requires_grad=True)) for k, v in Wt.items())
+    use_bn = "batch_normalization/gamma" in Wt
+    bn_names = iter(["batch_normalization"] + ["batch_normalization_%d" % i for i in range(1, 64)])
     H, W = image_u8.shape
     ph, pw = (32 - H % 32) % 32, (32 - W % 32) % 32
     names = iter(["conv2d"] + ["conv2d_%d" % i for i in range(1, 64)])
@@ -130,7 +137,14 @@ def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None):
         m = torch.from_numpy(np.ascontiguousarray(keep.transpose(2, 0, 1)[None]).astype(np.float32))
         return x * m * 2.0
 
-    x = torch.from_numpy(image_u8.astype(np.float32) / np.float32(255.0))[None, None]
+    def bn(x, n, relu):
+        if bn_stats is not None:
+            xd = x.detach().double()
+            bn_stats[n] = (xd.mean((0, 2, 3)).numpy(), xd.var((0, 2, 3), unbiased=False).numpy(), x.shape[0] * x.shape[2] * x.shape[3])
+        y = F.batch_norm(x, None, None, T[n + "/gamma"], T[n + "/beta"], training=True, eps=1e-3)
+        return F.relu(y) if relu else y
+
+    x = torch.from_numpy(image_u8.astype(np.float32) / np.float32(255.0)).to(dt)[None, None]
     x = F.pad(x, (0, pw, 0, ph))
     up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
     if arch == "unet":
@@ -148,6 +162,26 @@ def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None):
             u = conv(up(t), next(names), 2, True)
             t = conv(torch.cat([skips[l], u], 1), next(names), 3, True)
             t = conv(t, next(names), 3, True)
+    elif arch == "res_unet" and use_bn:
+        def cblock(t, n, stride=1):                      # conv_block: bn_act -> Conv2D (creation order: BN, conv)
+            return conv(bn(t, next(bn_names), True), n, 3, stride=stride)
+
+        def residual(t, stride):
+            b1_, b2_ = next(bn_names), next(bn_names)    # conv_block 1, conv_block 2, then the shortcut's
+            n1, n2, n3 = next(names), next(names), next(names)
+            r = conv(bn(t, b1_, True), n1, 3, stride=stride)
+            r = conv(bn(r, b2_, True), n2, 3)
+            return bn(conv(t, n3, 3, stride=stride), next(bn_names), False) + r
+        n1 = next(names)
+        b0_ = next(bn_names)
+        n2, n3 = next(names), next(names)
+        e1 = conv(bn(conv(x, n1, 3), b0_, True), n2, 3) + bn(conv(x, n3, 1), next(bn_names), False)
+        e2 = residual(e1, 2); e3 = residual(e2, 2); e4 = residual(e3, 2); e5 = residual(e4, 2)
+        b0 = cblock(e5, next(names))
+        b1 = cblock(b0, next(names))
+        t = b1
+        for sk in (e4, e3, e2, e1):
+            t = residual(torch.cat([up(t), sk], 1), 1)
     elif arch == "res_unet":
         def residual(t, stride):
             n1, n2, n3 = next(names), next(names), next(names)
@@ -169,8 +203,8 @@ def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None):
     y = torch.from_numpy(mask_u8.astype(np.int64))
     loss = F.cross_entropy(z.reshape(-1, z.shape[-1]), y.reshape(-1))
     loss.backward()
-    grads = OrderedDict((k, (t_.grad.numpy().copy() if t_.grad is not None else np.zeros_like(Wt[k]))) for k, t_ in T.items())
-    return float(loss.item()), grads, z.detach().numpy()
+    grads = OrderedDict((k, (t_.grad.numpy().astype(np.float32) if t_.grad is not None else np.zeros_like(Wt[k]))) for k, t_ in T.items())
+    return float(loss.item()), grads, z.detach().numpy().astype(np.float32)
 
 
 class KerasAdam:

@@ -64,7 +64,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
 // ---- graph description ---------------------------------------------------------------------
-enum OpType { OP_CONV = 0, OP_DECONV2 = 1, OP_POOL = 2, OP_LOGITS = 3 };
+enum OpType { OP_CONV = 0, OP_DECONV2 = 1, OP_POOL = 2, OP_LOGITS = 3, OP_BN = 4 };
 
 struct Tensor {
     std::string name;   // producing Keras layer name ("input", "conv2d", "max_pooling2d", ...)
@@ -95,11 +95,14 @@ struct Op {
     int add = -1;             // residual addend tensor (Add()), applied after bias
     int dst = -1;
     int pool_dst = -1;        // bf16 mode: fused 2x2 max-pool output
-    int kparam = -1, bparam = -1;
+    int kparam = -1, bparam = -1;   // OP_BN: gamma / beta of the BatchNormalization layer
+    int mmparam = -1, mvparam = -1; // OP_BN: moving_mean / moving_variance
+    int bn_c0 = 0;                  // OP_BN: first channel of this op's slice of the layer's vectors (a BN over a
+                                    // Concatenate runs as one op per source tensor)
     int Cin = 0, Cout = 0;
     // device weights
-    float* d_w = nullptr;     // f32 correlation form [KH][KW][Cin][Cout] (+slack) / [2][2][Cin][Cout]
-    float* d_b = nullptr;     // f32 bias
+    float* d_w = nullptr;     // f32 correlation form [KH][KW][Cin][Cout] (+slack) / [2][2][Cin][Cout]; OP_BN: [gamma|beta|mean|var][C]
+    float* d_b = nullptr;     // f32 bias; OP_BN: [batch mean | 1/sqrt(var+eps)][C] of the last training forward, then 4*C doubles of reduction scratch
     void* plan = nullptr;     // bf16 mode: MfmaPlan (pseg_mfma.hip), owned by the op
     bool fused_away = false;  // bf16 mode: op folded into a neighbour (pool -> conv epilogue, logits -> deconv tail)
     int fuse1 = -1;           // bf16 mode: OP_CONV that recomputes this first-layer op on its halo tile
@@ -137,6 +140,8 @@ struct TimingSlot {
 
 struct Engine {
     int arch = 0, n_classes = 0, in_ch = 1, device = 0, mode = 0;
+    unsigned flags = 0;            // PSEG_FLAG_* of pseg_create_ex
+    bool bn_training = false;      // float32 engine, while a TRAINING forward runs: BatchNormalization layers use batch statistics and update their moving ones
     hipStream_t stream = nullptr;
     std::vector<Tensor> tensors;
     std::vector<Param> params;
@@ -202,6 +207,15 @@ struct UpSplit;
 int upsplit_create(UpSplit** out, const std::vector<float>& w, const std::vector<float>& bias, int Cin, int Cs0, int Cout, int CoS);
 void upsplit_free(UpSplit* u);
 int upsplit_launch(UpSplit* u, const uint16_t* src, int Hs, int Ws, uint16_t* dst, int relu, hipStream_t st);
+// BatchNormalization (pseg_bn.hip), NHWC float32 tensors of npx pixels x C channels; `par` = [gamma|beta|moving_mean|moving_var][C]
+constexpr float PSEG_BN_EPS = 1e-3f;        // tf.keras.layers.BatchNormalization defaults (lib/model.py:268,315 pass none)
+constexpr float PSEG_BN_MOMENTUM = 0.99f;
+int bn_infer(const float* x, float* y, size_t npx, int C, const float* par, float* saved, int relu, hipStream_t st);
+int bn_train_forward(const float* x, float* y, size_t npx, int C, float* par, float* saved, int relu, int up, hipStream_t st);
+int bn_backward(const float* x, const float* y_mask, const float* dy, float* dx_accum, size_t npx, int C, const float* par,
+                float* saved, float* dgamma, float* dbeta, hipStream_t st);
+int bn_infer_bf16(const uint16_t* x, uint16_t* y, size_t npx, int Cs, const float* scale_shift, int relu, hipStream_t st);
+size_t bn_saved_bytes(int C);
 // Dropout mask of element i under `key`: keep iff hash(i, key) >= rate (inverted dropout, kept values * 1/(1-rate))
 void launch_dropout(float* x, size_t n, uint32_t key, float rate, hipStream_t st);
 int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hipStream_t st);   // pseg_post.hip

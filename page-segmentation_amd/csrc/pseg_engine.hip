@@ -345,11 +345,44 @@ int launch_conv_exact(const ConvArgs& a, hipStream_t st) {
     return PSEG_OK;
 }
 
+// OP_BN: this op's channel slice of the layer's four vectors; bf16 mode: folded to per-channel scale / shift over the
+// storage channels (zero on the pad channels, so they stay zero)
+static int upload_bn(Engine& e, Op& op) {
+    const int C = op.Cin, c0 = op.bn_c0;
+    const int pidx[4] = {op.kparam, op.bparam, op.mmparam, op.mvparam};
+    std::vector<float> par((size_t)4 * C);
+    for (int j = 0; j < 4; ++j)
+        for (int c = 0; c < C; ++c) par[(size_t)j * C + c] = e.params[pidx[j]].host[(size_t)c0 + c];
+    free_dev((void*&)op.d_w);
+    free_dev((void*&)op.d_b);
+    if (e.mode == PSEG_MODE_BF16) {
+        const int Cs = e.tensors[op.src0].Cs;
+        std::vector<float> ss((size_t)2 * Cs, 0.0f);
+        for (int c = 0; c < C; ++c) {
+            const float scale = par[c] / std::sqrt(par[(size_t)3 * C + c] + PSEG_BN_EPS);
+            ss[c] = scale;
+            ss[(size_t)Cs + c] = par[(size_t)C + c] - par[(size_t)2 * C + c] * scale;
+        }
+        PSEG_HIP(hipMalloc((void**)&op.d_w, ss.size() * sizeof(float)));
+        PSEG_HIP(hipMemcpy(op.d_w, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
+        return PSEG_OK;
+    }
+    PSEG_HIP(hipMalloc((void**)&op.d_w, par.size() * sizeof(float)));
+    PSEG_HIP(hipMemcpy(op.d_w, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice));
+    PSEG_HIP(hipMalloc((void**)&op.d_b, bn_saved_bytes(C)));
+    PSEG_HIP(hipMemset(op.d_b, 0, bn_saved_bytes(C)));
+    return PSEG_OK;
+}
+
 int upload_weights(Engine& e) {
     // the copies below are ordered on the null stream only: earlier asynchronous predicts must have finished
     PSEG_HIP(hipDeviceSynchronize());
     for (auto& op : e.ops) {
         if (op.kparam < 0) continue;
+        if (op.type == OP_BN) {
+            PSEG_TRY(upload_bn(e, op));
+            continue;
+        }
         const Param& kp = e.params[op.kparam];
         const Param& bp = e.params[op.bparam];
         const int k = op.k, Cin = op.Cin, Cout = op.Cout;
@@ -508,6 +541,11 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
                 a.dst = (float*)d.d;
                 PSEG_TRY(launch_conv_exact(a, st));
             }
+        } else if (op.type == OP_BN) {
+            const size_t npx = (size_t)e.tH(s0) * e.tW(s0);
+            float* y = (float*)e.tensors[op.dst].d;
+            if (e.bn_training) PSEG_TRY(bn_train_forward((const float*)s0.d, y, npx, op.Cin, op.d_w, op.d_b, op.relu, op.up0, st));
+            else PSEG_TRY(bn_infer((const float*)s0.d, y, npx, op.Cin, op.d_w, op.d_b, op.relu, st));
         } else if (op.type == OP_DECONV2) {
             // Conv2DTranspose k2 s2 on the matrix cores: one 1x1 GEMM over n = (sub-pixel, cout), same chain
             // order over ci as deconv2_exact_kernel; the scalar kernel if the all-channel tile does not fit
@@ -588,6 +626,12 @@ static int run_bf16(Engine& e, const uint8_t* d_img, float* d_logits, float* d_p
             case OP_CONV: PSEG_TRY(mfma_launch_conv(e, op, st)); break;
             case OP_DECONV2: PSEG_TRY(mfma_launch_deconv2(e, op, st)); break;
             case OP_POOL: PSEG_TRY(mfma_launch_pool(e, op, st)); break;
+            case OP_BN: {
+                const Tensor& s0 = e.tensors[op.src0];
+                PSEG_TRY(bn_infer_bf16((const uint16_t*)s0.d, (uint16_t*)e.tensors[op.dst].d, (size_t)e.tH(s0) * e.tW(s0), s0.Cs,
+                                       op.d_w, op.relu, st));
+                break;
+            }
             case OP_LOGITS:
                 PSEG_TRY(mfma_launch_logits(e, op, d_logits, d_probs, d_labels, d_labels_u8, st));
                 break;
@@ -801,7 +845,13 @@ int pseg_device_count(void) {
 
 int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
                 pseg_engine** out) {
+    return pseg_create_ex(arch, n_classes, in_channels, device, mode, 0u, out);
+}
+
+int pseg_create_ex(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
+                   pseg_engine** out) {
     if (!out) return fail(PSEG_EINVAL, "out is NULL");
+    if (flags & ~(unsigned)PSEG_FLAG_BATCHNORM) return fail(PSEG_EINVAL, "unknown flag bits 0x%x", flags);
     *out = nullptr;
     if (n_classes < 1 || n_classes > 256) return fail(PSEG_EINVAL, "n_classes %d out of range", n_classes);
     if (in_channels != 1 && in_channels != 3) return fail(PSEG_EINVAL, "in_channels must be 1 or 3");
@@ -819,6 +869,7 @@ int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
     e.in_ch = in_channels;
     e.device = device;
     e.mode = mode;
+    e.flags = flags;
     int rc = build_graph(e);
     if (rc == PSEG_OK && mode == PSEG_MODE_BF16) rc = mfma_plan_graph(e);
     if (rc != PSEG_OK) { delete h; return rc; }

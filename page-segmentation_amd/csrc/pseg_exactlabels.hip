@@ -123,7 +123,7 @@ __global__ void widen_u8_kernel(const uint8_t* in, int64_t* out, size_t n) {
 
 static int sync_weights(Engine& e, ExactState& x) {
     if (!x.f32) {
-        PSEG_TRY(pseg_create(e.arch, e.n_classes, e.in_ch, e.device, PSEG_MODE_F32_EXACT, &x.f32));
+        PSEG_TRY(pseg_create_ex(e.arch, e.n_classes, e.in_ch, e.device, PSEG_MODE_F32_EXACT, e.flags, &x.f32));
         e.exact_dirty = true;
     }
     if (!e.exact_dirty) return PSEG_OK;

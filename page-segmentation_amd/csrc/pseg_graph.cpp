@@ -60,6 +60,35 @@ struct Builder {
         p.host.assign((size_t)n, 0.0f);
         return idx;
     }
+    // BatchNormalization layer: weight-table slots in Keras order (gamma, beta, moving_mean, moving_variance)
+    std::string reserve_bn() {
+        std::string name = nm("batch_normalization");
+        for (const char* suf : {"/gamma", "/beta", "/moving_mean", "/moving_variance"}) {
+            Param p;
+            p.name = name + suf;
+            e.params.push_back(p);
+        }
+        return name;
+    }
+    // ... applied to one source tensor (channels [c0, c0 + C) of a layer over `ctot` channels), optionally followed
+    // by the Activation('relu') of bn_act (lib/model.py:265-271)
+    int bn(int src, const std::string& layer, int c0, int ctot, bool relu, int up = 0) {
+        Op op;
+        op.type = OP_BN;
+        op.up0 = up;   // the layer sees this tensor through UpSampling2D(2)^up: same batch statistics, 4^up times the sample count
+        op.layer = c0 == 0 ? layer : layer + "+" + std::to_string(c0);
+        op.src0 = src;
+        op.relu = relu;
+        op.bn_c0 = c0;
+        op.Cin = op.Cout = e.tensors[src].C;
+        op.kparam = param(layer + "/gamma", {ctot});
+        op.bparam = param(layer + "/beta", {ctot});
+        op.mmparam = param(layer + "/moving_mean", {ctot});
+        op.mvparam = param(layer + "/moving_variance", {ctot});
+        op.dst = tensor(op.layer, e.tensors[src].s, op.Cin);
+        e.ops.push_back(op);
+        return op.dst;
+    }
     int cin_of(int src0, int src1) const {
         return e.tensors[src0].C + (src1 >= 0 ? e.tensors[src1].C : 0);
     }
@@ -208,31 +237,53 @@ void build_unet(Engine& e) {
     b.logits(t, -1);
 }
 
-// lib/model.py:237-307 (BatchNorm never instantiated: flag hard-wired False at :265).
+// lib/model.py:237-307.  The reference hard-wires bn_act's BatchNormalization flag to False (:265); with
+// PSEG_FLAG_BATCHNORM the builder places the layer where bn_act would (in front of every pre-activation ReLU and behind
+// every shortcut convolution), in Keras creation order.
 void build_res_unet(Engine& e) {
     Builder b(e);
+    const bool bnf = (e.flags & PSEG_FLAG_BATCHNORM) != 0;
     const int f[5] = {32, 64, 128, 256, 512};
     int x = b.tensor("input", 0, e.in_ch);
     e.input_tensor = x;
+    // bn_act(x) of conv_block over the (virtual) concat [s0, s1]: one op per source, the ReLU inside the op
+    struct Pre { int s0, s1, in_relu; };
+    auto pre_act = [&](int s0, int s1, const std::string& layer, int up0 = 0) -> Pre {
+        if (!bnf) return Pre{s0, s1, 1};
+        const int ctot = b.cin_of(s0, s1);
+        const int n0 = b.bn(s0, layer, 0, ctot, true, up0);
+        const int n1 = s1 >= 0 ? b.bn(s1, layer, e.tensors[s0].C, ctot, true) : -1;
+        return Pre{n0, n1, 0};
+    };
+    auto shortcut_bn = [&](int sc, const std::string& layer) { return bnf ? b.bn(sc, layer, 0, e.tensors[sc].C, false) : sc; };
     // residual_block: names allocated in Keras creation order (conv_block1, conv_block2, shortcut)
     auto residual = [&](int s0, int s1, int up0, int filters, int stride) {
-        int r = b.conv(s0, s1, filters, 3, false, stride, "", /*in_relu=*/true, -1, up0, 0);
+        const Pre p1 = pre_act(s0, s1, bnf ? b.reserve_bn() : "", up0);
+        int r = b.conv(p1.s0, p1.s1, filters, 3, false, stride, "", /*in_relu=*/p1.in_relu, -1, up0, 0);
+        const std::string bn2 = bnf ? b.reserve_bn() : "";
         std::string n2 = b.reserve("conv2d");
         std::string nsc = b.reserve("conv2d");
-        int sc = b.conv(s0, s1, filters, 3, false, stride, nsc, false, -1, up0, 0);
-        return b.conv(r, -1, filters, 3, false, 1, n2, /*in_relu=*/true, /*add=*/sc);
+        const std::string bnsc = bnf ? b.reserve_bn() : "";
+        int sc = shortcut_bn(b.conv(s0, s1, filters, 3, false, stride, nsc, false, -1, up0, 0), bnsc);
+        const Pre p2 = pre_act(r, -1, bn2);
+        return b.conv(p2.s0, -1, filters, 3, false, 1, n2, /*in_relu=*/p2.in_relu, /*add=*/sc);
     };
     // stem :251-257
     int s = b.conv(x, -1, f[0], 3, false);
+    const std::string bn0 = bnf ? b.reserve_bn() : "";
     std::string n2 = b.reserve("conv2d");
     int sc = b.conv(x, -1, f[0], 1, false, 1, b.reserve("conv2d"));
-    int e1 = b.conv(s, -1, f[0], 3, false, 1, n2, true, sc);
+    sc = shortcut_bn(sc, bnf ? b.reserve_bn() : "");
+    const Pre ps = pre_act(s, -1, bn0);
+    int e1 = b.conv(ps.s0, -1, f[0], 3, false, 1, n2, ps.in_relu, sc);
     int e2 = residual(e1, -1, 0, f[1], 2);
     int e3 = residual(e2, -1, 0, f[2], 2);
     int e4 = residual(e3, -1, 0, f[3], 2);
     int e5 = residual(e4, -1, 0, f[4], 2);
-    int b0 = b.conv(e5, -1, f[4], 3, false, 1, "", true);
-    int b1 = b.conv(b0, -1, f[4], 3, false, 1, "", true);
+    const Pre pb0 = pre_act(e5, -1, bnf ? b.reserve_bn() : "");
+    int b0 = b.conv(pb0.s0, -1, f[4], 3, false, 1, "", pb0.in_relu);
+    const Pre pb1 = pre_act(b0, -1, bnf ? b.reserve_bn() : "");
+    int b1 = b.conv(pb1.s0, -1, f[4], 3, false, 1, "", pb1.in_relu);
     int d1 = residual(b1, e4, 1, f[4], 1);   // [up, skip] :240
     int d2 = residual(d1, e3, 1, f[3], 1);
     int d3 = residual(d2, e2, 1, f[2], 1);
@@ -250,6 +301,8 @@ int build_graph(Engine& e) {
         case PSEG_ARCH_RES_UNET: build_res_unet(e); break;
         default: return fail(PSEG_EINVAL, "unknown architecture id %d", e.arch);
     }
+    if ((e.flags & PSEG_FLAG_BATCHNORM) && e.arch != PSEG_ARCH_RES_UNET)
+        return fail(PSEG_EUNSUPPORTED, "PSEG_FLAG_BATCHNORM: only the residual U-Net has BatchNormalization sites (lib/model.py:265-271)");
     // one timing slot per op
     for (auto& op : e.ops) {
         TimingSlot ts;

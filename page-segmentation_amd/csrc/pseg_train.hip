@@ -726,9 +726,11 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     const uint32_t drop_key = backward ? (t->drop_seed * 0x632BE5ABu + (uint32_t)t->fwd_count * 0x9E3779B9u) | 1u : 0u;
     if (backward) ++t->fwd_count;
     e.drop_key = drop_key;
+    e.bn_training = backward;   // Keras fit: BatchNormalization layers normalise with the batch statistics; evaluate / predict with the moving ones
     e.relaxed_f32 = PSEG_KNOB("PSEG_TRAIN_STRICT") ? 0 : 1;   // wide layers: channel-blocked matrix-core kernel (summation order differs from predict)
     const int rc_fwd = run_exact(e, t->d_img, t->d_logits, nullptr, nullptr, nullptr, st);
     e.drop_key = 0;
+    e.bn_training = false;
     e.relaxed_f32 = 0;
     e.cur_img_f32 = nullptr;
     PSEG_TRY(rc_fwd);
@@ -892,6 +894,12 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 }
                 PSEG_HIP(hipGetLastError());
             }
+        } else if (op.type == OP_BN) {
+            // dgamma / dbeta into this op's channel slice of the layer's gradient vectors, dx accumulated into the source
+            const float* Y = (const float*)e.tensors[op.dst].d;
+            PSEG_TRY(bn_backward((const float*)s0.d, op.relu ? Y : nullptr, t->tgrad[op.dst],
+                                 op.src0 == e.input_tensor ? nullptr : t->tgrad[op.src0], (size_t)e.tH(s0) * e.tW(s0), op.Cin, op.d_w,
+                                 op.d_b, gw + op.bn_c0, gb + op.bn_c0, st));
         } else if (op.type == OP_POOL) {
             const size_t n = (size_t)(e.tH(s0) / 2) * (e.tW(s0) / 2) * s0.C;
             pool_bwd_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(
@@ -942,7 +950,8 @@ static int train_apply(Engine& e, float lr, float gscale) {
     PSEG_HIP(hipSetDevice(e.device));
     hipStream_t st = e.stream;
     t->step += 1;
-    OptScalars o{};
+    OptScalars o_{};
+    OptScalars& o = o_;
     o.lr = lr; o.b1 = t->beta1; o.b2 = t->beta2; o.eps = t->eps;
     const double b1t = std::pow((double)t->beta1, (double)t->step), b2t = std::pow((double)t->beta2, (double)t->step);
     if (t->optimizer == PSEG_OPT_ADAM) o.lr = (float)(lr * std::sqrt(1.0 - b2t) / (1.0 - b1t));
@@ -964,18 +973,25 @@ static int train_apply(Engine& e, float lr, float gscale) {
         t->state_init = true;
     }
     PSEG_HIP(hipMemsetAsync(t->d_norm, 0, e.params.size() * 4, st));
-    // parameter -> device buffer (kernels: op.d_w in correlation layout; biases: op.d_b)
-    for (auto& op : e.ops) {
-        if (op.kparam < 0) continue;
-        for (int which = 0; which < 2; ++which) {
-            const int pi = which == 0 ? op.kparam : op.bparam;
-            const int64_t n = (int64_t)e.params[pi].host.size();
-            float* g = t->d_grad + t->off[pi];
-            float* p = which == 0 ? op.d_w : op.d_b;
-            const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
-            if (t->clipnorm > 0.0f) sumsq_kernel<<<grid, 256, 0, st>>>(g, n, gscale, t->d_norm + pi);
-            opt_kernel<<<grid, 256, 0, st>>>(t->optimizer, p, g, t->d_m + t->off[pi], t->d_v + t->off[pi], n, gscale,
-                                            t->d_norm + pi, t->clipnorm, t->clipvalue, o);
+    // parameter -> device buffer (kernels: op.d_w in correlation layout; biases: op.d_b; BatchNormalization: gamma and
+    // beta slices at the head of op.d_w -- the moving statistics are not trained).  All norms first: the slices of one
+    // BatchNormalization tensor spread over two ops share a clip_by_norm.
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 0 && !(t->clipnorm > 0.0f)) continue;
+        for (auto& op : e.ops) {
+            if (op.kparam < 0) continue;
+            const bool bn = op.type == OP_BN;
+            for (int which = 0; which < 2; ++which) {
+                const int pi = which == 0 ? op.kparam : op.bparam;
+                const int64_t n = bn ? op.Cin : (int64_t)e.params[pi].host.size();
+                const int64_t o = t->off[pi] + (bn ? op.bn_c0 : 0);
+                float* g = t->d_grad + o;
+                float* p = bn ? op.d_w + which * op.Cin : (which == 0 ? op.d_w : op.d_b);
+                const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
+                if (pass == 0) sumsq_kernel<<<grid, 256, 0, st>>>(g, n, gscale, t->d_norm + pi);
+                else opt_kernel<<<grid, 256, 0, st>>>(t->optimizer, p, g, t->d_m + o, t->d_v + o, n, gscale,
+                                                     t->d_norm + pi, t->clipnorm, t->clipvalue, o_);
+            }
         }
     }
     PSEG_HIP(hipGetLastError());
@@ -1003,6 +1019,12 @@ int train_sync_weights_to_host(Engine& e) {
     PSEG_HIP(hipStreamSynchronize(e.stream));
     for (auto& op : e.ops) {
         if (op.kparam < 0 || !op.d_w) continue;
+        if (op.type == OP_BN) {
+            const int pidx[4] = {op.kparam, op.bparam, op.mmparam, op.mvparam};
+            for (int j = 0; j < 4; ++j)
+                PSEG_HIP(hipMemcpy(e.params[pidx[j]].host.data() + op.bn_c0, op.d_w + (size_t)j * op.Cin, (size_t)op.Cin * 4, hipMemcpyDeviceToHost));
+            continue;
+        }
         Param& kp = e.params[op.kparam];
         Param& bp = e.params[op.bparam];
         std::vector<float> w(kp.host.size());
@@ -1115,7 +1137,7 @@ int pseg_train_get_gradient(pseg_engine* h, const char* name, float* out, int64_
         std::vector<float> g((size_t)n);
         PSEG_HIP(hipMemcpy(g.data(), t->d_grad + t->off[pi], (size_t)n * 4, hipMemcpyDeviceToHost));
         for (auto& op : e.ops)
-            if (op.kparam == (int)pi) {
+            if (op.kparam == (int)pi && op.type != OP_BN) {
                 std::vector<float> k((size_t)n);
                 to_keras(op, g, k);
                 std::copy(k.begin(), k.end(), out);

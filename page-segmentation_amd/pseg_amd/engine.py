@@ -10,10 +10,11 @@ _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ARCH_IDS = {"fcn_skip": 0, "fcn": 1, "unet": 2, "res_unet": 3}
 MODE_F32_EXACT = 0
 MODE_BF16 = 1
+FLAG_BATCHNORM = 1
 
 # every symbol include/pseg.h declares (tests check that the library exports each one)
 EXPORTED_SYMBOLS = (
-    "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_destroy",
+    "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_create_ex", "pseg_destroy",
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
     "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
     "pseg_host_alloc", "pseg_host_free", "pseg_host_register", "pseg_host_unregister",
@@ -55,6 +56,7 @@ def lib():
     vp, i, i64 = c.c_void_p, c.c_int, c.c_int64
     L.pseg_last_error.restype = c.c_char_p
     L.pseg_create.argtypes = [i, i, i, i, i, c.POINTER(vp)]
+    L.pseg_create_ex.argtypes = [i, i, i, i, i, c.c_uint, c.POINTER(vp)]
     L.pseg_destroy.argtypes = [vp]
     L.pseg_num_weights.argtypes = [vp]
     L.pseg_weight_info.argtypes = [vp, i, c.c_char_p, c.c_size_t, c.POINTER(i64), c.POINTER(i)]
@@ -168,14 +170,16 @@ def pinned_copy(a):
 class Engine:
     """Opaque pseg_engine handle: one FCN graph + its weights resident on one GPU."""
 
-    def __init__(self, arch="fcn_skip", n_classes=3, in_channels=1, device=0, mode=MODE_BF16):
+    def __init__(self, arch="fcn_skip", n_classes=3, in_channels=1, device=0, mode=MODE_BF16, batch_norm=False):
+        """batch_norm: BatchNormalization at res_unet's bn_act sites (lib/model.py:265-271; PSEG_FLAG_BATCHNORM)."""
         self._h = None
         L = lib()
         arch_id = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
         h = ctypes.c_void_p()
-        _check(L.pseg_create(arch_id, int(n_classes), int(in_channels), int(device), int(mode),
-                             ctypes.byref(h)))
+        _check(L.pseg_create_ex(arch_id, int(n_classes), int(in_channels), int(device), int(mode),
+                                FLAG_BATCHNORM if batch_norm else 0, ctypes.byref(h)))
         self._h = h
+        self.batch_norm = bool(batch_norm)
         self.arch = arch
         self.n_classes = int(n_classes)
         self.in_channels = int(in_channels)

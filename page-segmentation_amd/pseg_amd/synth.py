@@ -82,6 +82,9 @@ def glorot_weights(specs, seed=42, gain=1.0, bias_scale=0.0):
             rf = shp[0] * shp[1]
             limit = np.sqrt(6.0 / (rf * shp[2] + rf * shp[3])) * gain
             out[name] = rng.uniform(-limit, limit, size=shp).astype(np.float32)
+        elif name.endswith(("/gamma", "/moving_variance")):
+            # BatchNormalization initialisers are ones / zeros; bias_scale > 0 perturbs them so that every term counts
+            out[name] = (1.0 + (rng.uniform(-0.3, 0.3, size=shp) if bias_scale > 0 else 0.0) * np.ones(shp)).astype(np.float32)
         else:
             if bias_scale > 0:
                 out[name] = rng.uniform(-bias_scale, bias_scale, size=shp).astype(np.float32)

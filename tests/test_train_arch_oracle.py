@@ -26,3 +26,30 @@ def test_dropout_mask_restatement():
     assert not np.array_equal(k, dropout_keep(1 << 16, dropout_key(7, 1, 10), 0.5))
     assert not np.array_equal(k, dropout_keep(1 << 16, dropout_key(7, 0, 13), 0.5))
     assert 0.28 < dropout_keep(1 << 16, 12345, 0.7).mean() < 0.32
+
+
+def test_batchnorm_restatements_agree(oracle_mod):
+    """res_unet with BatchNormalization (lib/model.py:265-271 switched on): the torch training graph, fed a table whose
+    moving statistics ARE the page's batch statistics, reproduces the NumPy inference forward -- the two restatements
+    place the 28 layers identically and share eps."""
+    from oracle.train_ref import graph_loss_and_grads
+    from pseg_amd import synth
+    img, _, mask = synth.synth_page(4, 96, 96, 3)
+    img, mask = np.ascontiguousarray(img[:40, :50]), np.ascontiguousarray(mask[:40, :50])
+    Wt = oracle_mod.init_weights("res_unet", 3, seed=2, gain=1.2, bias_scale=0.05, batch_norm=True)
+    names = [n for n, kind, _, _ in oracle_mod.models.weight_specs("res_unet", 3, batch_norm=True) if kind == "bn"]
+    assert len(names) == 28 and names[0] == "batch_normalization" and names[-1] == "batch_normalization_27"
+    stats = {}
+    loss, grads, z = graph_loss_and_grads("res_unet", Wt, img, mask, float64=True, bn_stats=stats)
+    assert sorted(stats) == sorted(names) and np.isfinite(loss) and list(grads) == list(Wt)
+    W2 = dict(Wt)
+    for n, (mean, var, cnt) in stats.items():
+        W2[n + "/moving_mean"] = mean.astype(np.float32)
+        W2[n + "/moving_variance"] = var.astype(np.float32)
+    z_np = oracle_mod.forward("res_unet", W2, img)
+    assert np.abs(z - z_np).max() <= 2e-4 * max(1.0, np.abs(z_np).max())
+    for n in names:
+        assert np.abs(grads[n + "/gamma"]).max() > 0 and np.abs(grads[n + "/beta"]).max() > 0
+        assert not np.any(grads[n + "/moving_mean"])
+    # without the layers the table and the logits differ
+    assert not any("batch_normalization" in k for k in oracle_mod.init_weights("res_unet", 3))

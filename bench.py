@@ -325,23 +325,14 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    # Order of the legs: the per-step spread pass and the per-kernel roofline pass run FIRST, then the W warm-up steps, then the
+    # K timed steps.  A cold MI355X needs about 25 pages (12 ms) of load before it holds its sustained clocks: with W = 5
+    # straight after process start the 20-step region measured 0.509 ms/page, with W = 50 or K = 200 0.457-0.461 ms/page
+    # (gpurun, round 2) -- the sustained rate is the one a page stream sees, and the one the roofline leg is priced at.
+    for _ in range(32):      # spin-up, untimed: every leg below (spread, roofline, the timed region) sees the sustained clocks
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    total_px = float(world) * args.pages * H * W * args.steps
-    value = total_px / dt / 1e6
-
-    # per-step spread (separate pass, events on the launch stream): the timed region above is a single sample
+    torch.cuda.synchronize(dev)
+    # per-step spread (separate pass, events on the launch stream): the timed region below is a single sample
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 10))]
     for a, b in evs:
         a.record()
@@ -362,6 +353,23 @@ def run_rank(args):
     torch.cuda.synchronize(dev)
     slots = [s for s in eng.timing() if s[2] > 0]
     eng.timing_enable(False)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_px = float(world) * args.pages * H * W * args.steps
+    value = total_px / dt / 1e6
+
     if slots:
         name, ms, n, flops = max(slots, key=lambda s: s[1])
         avg_ms = ms / n

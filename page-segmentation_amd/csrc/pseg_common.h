@@ -74,6 +74,7 @@ struct Tensor {
     void* d = nullptr;  // device buffer, NHWC, (Hp>>s) x (Wp>>s) x Cs
     size_t bytes = 0;
     bool fused = false; // bf16 mode: never written to HBM (lives only inside a fused kernel)
+    bool relu_stored = false;   // bf16 mode: stored after the pre-activation ReLU of its readers (mfma_plan_graph)
 };
 
 struct Param {

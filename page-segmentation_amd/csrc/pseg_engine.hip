@@ -1043,6 +1043,7 @@ int pseg_get_activation(pseg_engine* h, const char* layer, float* out, int64_t c
         if (t.name != layer) continue;
         if (!t.d || e.Hp == 0) return fail(PSEG_EINVAL, "no predict call has run yet");
         if (t.fused) return fail(PSEG_EUNSUPPORTED, "layer '%s' is fused into its consumer and never materialised", layer);
+        if (t.relu_stored) return fail(PSEG_EUNSUPPORTED, "layer '%s' is fused with its readers' pre-activation ReLU: stored as max(x, 0) (PSEG_NO_RELU_FWD=1 keeps the tensor)", layer);
         const int H = e.tH(t), W = e.tW(t);
         if (dims) { dims[0] = H; dims[1] = W; dims[2] = t.C; }
         const int64_t n = (int64_t)H * W * t.C;

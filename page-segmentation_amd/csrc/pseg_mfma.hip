@@ -281,7 +281,9 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = wave * (MT / 2) + (m >> 1), col = (m & 1) * 16 + p16;
-        pixbase[m] = row * c_stride * a.row_pitch + col * c_stride * c_PS2;
+        // stride 2: the tile is staged with its columns de-interleaved by parity (see the staging below), so consecutive
+        // lanes read consecutive pixel slots under every tap, as in a stride-1 layer
+        pixbase[m] = row * c_stride * a.row_pitch + col * (c_stride == 2 ? 1 : c_stride) * c_PS2;
     }
     const int W0 = a.Win >> c_up0, W1 = a.Win >> c_up1;
 
@@ -533,7 +535,11 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
                 const int sl = j * 64 + lane;
-                const int px = (int)(((unsigned)sl * inv) >> 16), cc = sl - px * c_sigma;
+                const int ps = (int)(((unsigned)sl * inv) >> 16), cc = sl - ps * c_sigma;   // pixel slot of the row, chunk
+                // stride 2: slots [0, ceil(TWH/2)) hold the even tile columns, the rest the odd ones -- under a tap kx the 16
+                // lanes of a fragment read then walk consecutive slots of plane kx & 1 instead of every other pixel (whose
+                // 2 * sigma * 16-byte pitch put four to eight lanes on the same banks)
+                const int px = c_stride == 2 ? (ps < ((c_TWH + 1) >> 1) ? 2 * ps : 2 * (ps - ((c_TWH + 1) >> 1)) + 1) : ps;
                 const int ix = ix0 + px, gc = c0 + cc;
                 const bool okc = cc < nc && ix >= 0 && ix < a.Win;
                 const bool is1 = okc && gc >= a.nch0;
@@ -587,7 +593,8 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
                         if (i < row_items) {
                             const int px = (int)(((unsigned)i * inv) >> 16), cc = i - px * nc;
                             const int ix = ix0 + px;
-                            dsto[u] = py * a.row_pitch + px * c_PS2 + cc * 16;
+                            const int ps = c_stride == 2 ? ((px & 1) ? ((c_TWH + 1) >> 1) + (px >> 1) : (px >> 1)) : px;   // de-interleaved slot
+                            dsto[u] = py * a.row_pitch + ps * c_PS2 + cc * 16;
                             if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
                                 const int gc = c0 + cc;
                                 const uint16_t* sp = gc < a.nch0
@@ -2394,6 +2401,42 @@ static int producer_of(const Engine& e, int tensor) {
 
 // Fold every MaxPooling2D into the epilogue of the conv that produces its input.
 int mfma_plan_graph(Engine& e) {
+    // Pre-activation ReLU moved into the producer (res_unet).  A conv output whose EVERY reader is a convolution that
+    // applies ReLU to its input first -- conv_block 1's output (read by conv_block 2 only), the stem's first conv, the
+    // bridge, e5 -- is stored ReLU'd by the conv that produces it (after the residual add, where it has one), and the
+    // readers stage it as it is: bf16(max(x, 0)) == max(bf16(x), 0), so every value the readers see is unchanged, and
+    // they no longer run the in-LDS ReLU pass over their halo tile (15-17 % of conv_block 2 at every level).
+    if (!PSEG_KNOB("PSEG_NO_RELU_FWD") && !PSEG_KNOB("PSEG_GENERIC")) {
+        std::vector<char> ok(e.tensors.size(), 0);
+        for (size_t t = 0; t < e.tensors.size(); ++t) {
+            const int pi = producer_of(e, (int)t);
+            ok[t] = pi >= 0 && e.ops[pi].type == OP_CONV && !e.ops[pi].transposed;
+        }
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (size_t t = 0; t < e.tensors.size(); ++t) {
+                if (!ok[t]) continue;
+                bool good = false;
+                for (auto& o : e.ops) {
+                    const bool reads = o.src0 == (int)t || o.src1 == (int)t;
+                    if (o.add == (int)t || (reads && (o.type != OP_CONV || !o.in_relu))) { good = false; break; }
+                    if (!reads) continue;
+                    good = true;
+                    // the reader's ReLU covers both of its sources: the other one has to move as well
+                    const int other = o.src0 == (int)t ? o.src1 : o.src0;
+                    if (other >= 0 && other != (int)t && !ok[other]) { good = false; break; }
+                }
+                if (!good) { ok[t] = 0; changed = true; }
+            }
+        }
+        for (size_t t = 0; t < e.tensors.size(); ++t) {
+            if (!ok[t]) continue;
+            e.ops[producer_of(e, (int)t)].relu = 1;
+            e.tensors[t].relu_stored = true;
+            for (auto& o : e.ops)
+                if (o.src0 == (int)t || o.src1 == (int)t) o.in_relu = 0;
+        }
+    }
     // deconv (k2 s2) feeding only the logits layer -> one fused tail kernel
     if (!PSEG_KNOB("PSEG_NO_TAIL_FUSION"))
         for (size_t li = 0; li < e.ops.size(); ++li) {
@@ -2420,7 +2463,7 @@ int mfma_plan_graph(Engine& e) {
             Op& cv = e.ops[pi];
             if (cv.type != OP_CONV || cv.Cout != 64 || cv.stride != 1 || cv.k != 3 || cv.up0 || cv.up1 ||
                 cv.transposed || cv.pool_dst >= 0) continue;
-            if ((cv.in_relu != 0) != (cv.add >= 0)) continue;    // plain conv (unet) or pre-activation + residual add (res_unet)
+            if (cv.in_relu && cv.add < 0) continue;    // plain conv (unet) or [pre-activation +] residual add (res_unet)
             int users = 0;
             for (auto& o : e.ops) users += (o.src0 == lg.src0) + (o.src1 == lg.src0) + (o.add == lg.src0);
             if (users != 1) continue;
@@ -2555,14 +2598,18 @@ static int pair_cost(int o0, int o1, int sigma) {
 // ordered chunks (padded with dummies to a multiple of 4) and the total modelled LDS cycles.
 // pairc2: the last chunk of a pixel holds four channels of that pixel and four of its right neighbour (conv12_ws_kernel's
 // tile): the k-chunk (tap (ky, kx), last chunk) with even kx covers taps kx and kx + 1, the odd-kx ones do not exist.
-static std::vector<Chunk> pair_chunks(int KS, int nc, int sigma, int pitch_slots, int* cycles_out = nullptr, bool pairc2 = false) {
+static std::vector<Chunk> pair_chunks(int KS, int nc, int sigma, int pitch_slots, int* cycles_out = nullptr, bool pairc2 = false, int plane_slots = 0) {
     std::vector<Chunk> all;
     for (int t = 0; t < KS * KS; ++t)
         for (int c = 0; c < nc; ++c) {
             if (pairc2 && c == nc - 1 && ((t % KS) & 1)) continue;
             all.push_back(Chunk{t, c});
         }
-    auto slot = [&](const Chunk& c) { return (c.tap / KS) * pitch_slots + (c.tap % KS) * sigma + c.cc; };
+    // plane_slots > 0: stride-2 tile with de-interleaved columns -- tap kx reads plane kx & 1 at pixel slot kx >> 1
+    auto slot = [&](const Chunk& c) {
+        const int kx = c.tap % KS;
+        return (c.tap / KS) * pitch_slots + (plane_slots ? (kx & 1) * plane_slots + (kx >> 1) * sigma : kx * sigma) + c.cc;
+    };
     std::vector<char> used(all.size(), 0);
     std::vector<Chunk> out;
     int cycles = 0;
@@ -2716,6 +2763,10 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->nblocks_n = cdiv(NTall, NT);
     P->NTtot = P->nblocks_n * NT;
     P->MT = (NT <= 2 && !deconv) ? 8 : 4;
+    // stride 2 (res_unet's encoder): the halo tile of an 8 x 32 output tile is 17 x 65 pixels -- 71 KB at 32 channels, one
+    // four-wave workgroup per CU beside its weights.  Four-row tiles (9 x 65 pixels) fit twice.
+    const bool deint = !deconv && op.stride == 2;
+    if (deint && NT == 4 && KS == 3 && !PSEG_KNOB("PSEG_NO_S2_MT2") && !PSEG_KNOB("PSEG_GENERIC")) P->MT = 2;
     // (the fused conv1+conv2 kernel was also tried with 8-row tiles -- 136 registers, 42 KB, three workgroups per
     // CU: 182 vs 164 us; the halo recompute of conv1 grows from 1.41x to 1.69x and the weights stream twice as often)
     if (PSEG_KNOB("PSEG_MT")) P->MT = atoi(PSEG_KNOB("PSEG_MT")) == 8 && NT <= 2 ? 8 : 4;
@@ -2765,12 +2816,14 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
                  (P->nc_full == 4 || P->nc_full == 5) && op.stride == 1 &&
                  (!op.up0 || KS == 2 || KS == 3) && !op.up1 && ((!op.in_relu && op.add < 0) || (KS == 3 && !PSEG_KNOB("PSEG_NO_WG3_RES"))) && op.fuse1 < 0 &&
                  !PSEG_KNOB("PSEG_GENERIC") && !PSEG_KNOB("PSEG_NO_WG3");
-        if (P->wg3 || (!PSEG_KNOB("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16))) {
+        // (stride 2: always the dense tile -- its columns are de-interleaved by parity at staging time, which makes the fragment
+        // reads those of a stride-1 layer, and the 4.3 input pixels per output pixel are the layer's LDS and DMA bill)
+        if (P->wg3 || (deint && P->nc_full >= 2) || (!PSEG_KNOB("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16))) {
             sigma = P->nc_full;
             int best_cyc = 1 << 30;
             for (int pad = 0; pad < 16; ++pad) {
                 int cyc = 0;
-                (void)pair_chunks(KS, P->nc_full, sigma, P->TWH * sigma + pad, &cyc, P->pairc2);
+                (void)pair_chunks(KS, P->nc_full, sigma, P->TWH * sigma + pad, &cyc, P->pairc2, deint ? ((P->TWH + 1) / 2) * sigma : 0);
                 if (cyc < best_cyc) { best_cyc = cyc; pitch_pad = pad; }
             }
         }
@@ -2782,8 +2835,9 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     if (P->NW != 4 && sigma != 6) return fail(PSEG_EUNSUPPORTED, "6/8-wave plan needs the sigma = 6 tile (got %d)", sigma);
     P->PS2 = sigma * 16;
     P->row_pitch = (P->TWH * sigma + pitch_pad) * 16;
-    const auto ord_full = pair_chunks(KS, P->nc_full, sigma, P->row_pitch / 16, nullptr, P->pairc2);
-    const auto ord_last = pair_chunks(KS, P->nc_last, sigma, P->row_pitch / 16, nullptr, P->pairc2);
+    const int plane_slots = deint ? ((P->TWH + 1) / 2) * sigma : 0;   // stride 2: first slot of the odd-column plane of a tile row
+    const auto ord_full = pair_chunks(KS, P->nc_full, sigma, P->row_pitch / 16, nullptr, P->pairc2, plane_slots);
+    const auto ord_last = pair_chunks(KS, P->nc_last, sigma, P->row_pitch / 16, nullptr, P->pairc2, plane_slots);
     P->ks_full = (int)ord_full.size() / 4;
     P->ks_last = (int)ord_last.size() / 4;
     if ((int)ord_full.size() > MAX_TAB) return fail(PSEG_EUNSUPPORTED, "k-chunk table too large");
@@ -2792,7 +2846,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         for (size_t i = 0; i < ord.size(); ++i) {
             const Chunk c = ord[i];
             if (c.cc < 0) { t[i] = 0; continue; }  // dummy: finite data, zero weights
-            t[i] = (c.tap / KS) * P->row_pitch + (c.tap % KS) * P->PS2 + c.cc * 16;
+            const int kx = c.tap % KS;
+            t[i] = (c.tap / KS) * P->row_pitch + (plane_slots ? ((kx & 1) * plane_slots + (kx >> 1) * sigma) * 16 : kx * P->PS2) + c.cc * 16;
         }
         return t;
     };
@@ -3133,14 +3188,20 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_UP0 | FL_INRELU)       // res_unet decoder: first conv of the block
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_INRELU | FL_ADD)       // res_unet: second conv + residual add
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_INRELU)                // res_unet bridge
+    PSEG_TRY_INST(8, 2, 3, 1, 4, MODE_CONV, FL_INRELU | FL_ADD)       // res_unet stem: second conv (32 -> 32 at full resolution) + shortcut add
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_ADD)                   // ... the same layers reading a tensor stored after its ReLU (mfma_plan_graph)
+    PSEG_TRY_INST(8, 2, 3, 1, 4, MODE_CONV, FL_ADD)
+    PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_ADD | FL_LOGITS)
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_LOGITS)    // unet: last conv + logits + argmax
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, FL_LOGITS)
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_INRELU | FL_ADD | FL_LOGITS)   // res_unet: last block + logits + argmax
     if (fl & FL_LOGITS) return fail(PSEG_EUNSUPPORTED, "conv + logits fusion has no kernel instance for this shape");
     if (fl & FL_SKIPLOG) return fail(PSEG_EUNSUPPORTED, "skip-logits fusion has no kernel instance for this shape");
     PSEG_TRY_INST(4, 4, 2, 1, 6, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv
-    PSEG_TRY_INST(4, 4, 3, 2, 6, MODE_CONV, 0)            // res_unet encoder: stride-2 shortcut conv
-    PSEG_TRY_INST(4, 4, 3, 2, 6, MODE_CONV, FL_INRELU)    // res_unet encoder: stride-2 first conv of the block
+    PSEG_TRY_INST(2, 4, 3, 2, 4, MODE_CONV, 0)            // res_unet encoder: stride-2 shortcut conv (four-row tiles, dense de-interleaved tile)
+    PSEG_TRY_INST(2, 4, 3, 2, 4, MODE_CONV, FL_INRELU)    // res_unet encoder: stride-2 first conv of the block
+    PSEG_TRY_INST(4, 4, 3, 2, 4, MODE_CONV, 0)            // (eight-row tiles: PSEG_NO_S2_MT2)
+    PSEG_TRY_INST(4, 4, 3, 2, 4, MODE_CONV, FL_INRELU)
     PSEG_TRY_INST(4, 5, 1, 1, 10, MODE_DECONV, 0)         // deconv2
     if (a.nb_loop == 2) { PSEG_TRY_INST(4, 4, 1, 1, 14, MODE_DECONV, 0) }   // deconv4 (fcn_skip): this instance walks two N blocks per workgroup (NBL = 2)
     PSEG_TRY_INST(4, 4, 1, 1, 6, MODE_DECONV, 0)          // deconv4 (fcn)
@@ -3151,6 +3212,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
 #undef PSEG_TRY_INST
     if (PSEG_KNOB("PSEG_LOG_GENERIC"))
         fprintf(stderr, "[pseg] generic instance: MT %d NT %d KS %d stride %d sigma %d mode %d flags %d\n", P.MT, P.NT, ks, P.stride, sg, mode, fl);
+    if (P.MT != 4 && P.MT != 8) return fail(PSEG_EUNSUPPORTED, "no runtime-generic kernel for %d pixel tiles per wave", P.MT);
     if (P.MT == 8) {
         if (P.NT == 1) return launch_inst<8, 1, -1, -1, -1, -1, -1>(a, P, grid, st);
         return launch_inst<8, 2, -1, -1, -1, -1, -1>(a, P, grid, st);

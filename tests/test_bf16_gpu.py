@@ -43,6 +43,7 @@ def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, monkeypatch, arch, C, shape):
     monkeypatch.setenv("PSEG_NO_POOL_ONLY", "1")
     monkeypatch.setenv("PSEG_NO_SKIPLOG", "1")
     monkeypatch.setenv("PSEG_NO_TAIL2", "1")
+    monkeypatch.setenv("PSEG_NO_RELU_FWD", "1")      # res_unet: tensors otherwise stored after their readers' pre-activation ReLU
     eng = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
     eng.set_weights(Wt)
     logit_k, _, pred_k = eng.predict(img)
@@ -297,3 +298,36 @@ def test_bf16_wave_specialised_conv12_is_bit_identical_to_the_fused_instance(gpu
             assert np.all(np.abs(pp - p0) <= np.abs(p0) * 2.0 ** -7 + 1e-6), im.shape
             assert (pp != p0).mean() < 0.02, im.shape
             assert np.abs(zp - z0).max() <= 1e-2 * max(1.0, float(np.abs(z0).max())), im.shape
+
+
+@pytest.mark.parametrize("shape", [(64, 96), (70, 50), (160, 224)])
+def test_bf16_res_unet_plan_variants_are_bit_identical(gpu, oracle_mod, monkeypatch, shape):
+    """res_unet's bf16 plan moves work without changing a value: (1) a conv output read only through pre-activation ReLUs
+    is stored ReLU'd by its producer (PSEG_NO_RELU_FWD keeps the raw tensor and the readers' in-LDS ReLU pass); (2) the
+    stride-2 encoder convs stage their halo tile with the columns de-interleaved by parity and run four-row tiles
+    (PSEG_NO_S2_MT2: eight-row tiles).  Same products in the same k order: the logits are the same bits."""
+    from pseg_amd import synth
+    C = 3
+    Wt = oracle_mod.init_weights("res_unet", C, seed=9, gain=1.5, bias_scale=0.05)
+    img = synth.synth_page(8, max(shape[0], 96), max(shape[1], 96), C)[0][:shape[0], :shape[1]].copy()
+
+    def run():
+        e = gpu.Engine("res_unet", C, mode=gpu.MODE_BF16)
+        e.set_weights(Wt)
+        z, _, l = e.predict(img, want_probs=False)
+        return e, z, l
+    e0, z0, l0 = run()
+    with pytest.raises(gpu.PsegError, match="fused"):
+        e0.activation("conv2d")          # the stem's first conv: stored after conv_block's ReLU
+    assert e0.activation("conv2d_2").shape[2] == 32          # the shortcut is not
+    e0.close()
+    for knob in ("PSEG_NO_RELU_FWD", "PSEG_NO_S2_MT2"):
+        monkeypatch.setenv(knob, "1")
+        e1, z1, l1 = run()
+        monkeypatch.delenv(knob)
+        assert np.array_equal(z1, z0) and np.array_equal(l1, l0), knob
+        if knob == "PSEG_NO_RELU_FWD":
+            assert e1.activation("conv2d").min() < 0
+        e1.close()
+    z_o = oracle_mod.forward("res_unet", Wt, img, "f32")
+    assert np.abs(z0 - z_o).max() <= 0.03 * max(1.0, np.abs(z_o).max())

@@ -96,6 +96,7 @@ struct Op {
     int add = -1;             // residual addend tensor (Add()), applied after bias
     int dst = -1;
     int pool_dst = -1;        // bf16 mode: fused 2x2 max-pool output
+    int relu_dst = -1;        // bf16 mode: second output tensor holding max(x, 0) for the pre-activation readers (mfma_plan_graph)
     int kparam = -1, bparam = -1;   // OP_BN: gamma / beta of the BatchNormalization layer
     int mmparam = -1, mvparam = -1; // OP_BN: moving_mean / moving_variance
     int bn_c0 = 0;                  // OP_BN: first channel of this op's slice of the layer's vectors (a BN over a

@@ -82,6 +82,7 @@ struct MConv {
     int PS2, row_pitch, THH, TWH, GK, NB, G, lds_w_off, lds_tab_off;
     // output
     uint16_t* dst;
+    uint16_t* dst2;       // second copy of the output stored as max(x, 0) (res_unet: read by the next block's pre-activation conv), or null
     int nch_out;
     uint16_t* pool_dst;
     const uint16_t* add;
@@ -911,6 +912,7 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     uint2 pks[2][c_skiplog ? MT : 1];
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, a.dst_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(c_pool ? a.pool_dst : a.dst), 0, c_pool ? a.pool_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst2 ? a.dst2 : a.dst), 0, a.dst2 ? a.dst_bytes : 0u, 0x00020000);
     unsigned pixoff[MT];   // byte offset of this lane's pixel in dst, or OOBS
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -948,7 +950,13 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             const uint2 pk = make_uint2(pk_bf16(v[m][0], v[m][1]),
                                         pk_bf16(v[m][2], v[m][3]));
             if constexpr (c_skiplog) pks[t < 2 ? t : 0][m] = pk;     // consumed by the logits MFMA below instead of memory
-            else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
+            else {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
+                if (a.dst2) {   // (wave-uniform) the ReLU'd copy the pre-activation readers stage as it is
+                    const uint2 pr = make_uint2(relu_pk_bf16(pk.x, 0u), relu_pk_bf16(pk.y, 0u));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pr), rd2, o, 0, 0);
+                }
+            }
         }
         if (c_pool) {
             const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
@@ -2437,6 +2445,43 @@ int mfma_plan_graph(Engine& e) {
                 if (o.src0 == (int)t || o.src1 == (int)t) o.in_relu = 0;
         }
     }
+    // ... and where a tensor has raw readers too (a block's input: the shortcut conv reads x, conv_block 1 reads max(x, 0);
+    // the encoder outputs also feed the decoder's concats), its producer stores a second, ReLU'd copy (MConv::dst2: 2 B per
+    // element more HBM traffic) that the pre-activation readers stage as it is, when ALL sources of such a reader have one.
+    // The second store costs the producer about three times its share of the HBM bandwidth (8-byte lane stores), so it
+    // pays only for the low-resolution tensors (<= 8 elements per canvas pixel: e3, e4, the bridge, d1 -- measured on a
+    // 2048x1536 page: producers +28 / +10 / +5 / +16 us, readers -105 / -76 us; e1 / e2 / d2 / d3: +253 us vs -198 us).
+    if (!PSEG_KNOB("PSEG_NO_RELU_FWD") && !PSEG_KNOB("PSEG_NO_RELU_COPY") && !PSEG_KNOB("PSEG_GENERIC")) {
+        auto can_copy = [&](int t) {
+            const int pi = producer_of(e, t);
+            if (pi < 0) return false;
+            const Op& p = e.ops[pi];
+            // producers that leave through conv_mfma_kernel's direct-store epilogue
+            const Tensor& tt = e.tensors[t];
+            return p.type == OP_CONV && !p.transposed && p.k == 3 && p.stride == 1 && !p.up0 && !p.up1 && p.Cin >= 8 &&
+                   ((tt.C >> (2 * tt.s)) <= 8 || PSEG_KNOB("PSEG_RELU_COPY_ALL"));
+        };
+        const size_t nops = e.ops.size();
+        for (size_t ri = 0; ri < nops; ++ri) {
+            Op& r = e.ops[ri];
+            if (r.type != OP_CONV || !r.in_relu) continue;
+            if (!can_copy(r.src0) || (r.src1 >= 0 && !can_copy(r.src1))) continue;
+            for (int* sp : {&r.src0, &r.src1}) {
+                if (*sp < 0) continue;
+                Op& p = e.ops[producer_of(e, *sp)];
+                if (p.relu_dst < 0) {
+                    Tensor c = e.tensors[*sp];
+                    c.name += "/relu";
+                    c.d = nullptr;
+                    c.bytes = 0;
+                    e.tensors.push_back(c);
+                    p.relu_dst = (int)e.tensors.size() - 1;
+                }
+                *sp = p.relu_dst;
+            }
+            r.in_relu = 0;
+        }
+    }
     // deconv (k2 s2) feeding only the logits layer -> one fused tail kernel
     if (!PSEG_KNOB("PSEG_NO_TAIL_FUSION"))
         for (size_t li = 0; li < e.ops.size(); ++li) {
@@ -3273,6 +3318,7 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.lds_w_off = P.lds_w_off; a.lds_tab_off = P.lds_tab_off;
     const Tensor& d = e.tensors[op.dst];
     a.dst = (uint16_t*)d.d;
+    a.dst2 = op.relu_dst >= 0 ? (uint16_t*)e.tensors[op.relu_dst].d : nullptr;
     a.nch_out = d.Cs / 8;
     a.dst_bytes = op.pool_only ? 0u : (unsigned)((size_t)e.tH(d) * e.tW(d) * d.Cs * 2);
     a.CoP = P.CoP;
@@ -3286,6 +3332,8 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     auto* P = (MfmaPlan*)op.plan;
     if (!P) return fail(PSEG_EINVAL, "layer %s has no bf16 plan", op.layer.c_str());
     const Tensor& d = e.tensors[op.dst];
+    if (op.relu_dst >= 0 && (P->kind != PLAN_GENERIC || op.pool_dst >= 0 || op.tail_logits >= 0 || op.skiplog >= 0 || op.fuse1 >= 0))
+        return fail(PSEG_EUNSUPPORTED, "layer %s: the ReLU'd second output exists only in the direct-store epilogue", op.layer.c_str());
     if (P->kind == PLAN_CONV1) {
         const uint8_t* img = e.cur_img;  // raw uint8 page (x/255 and pad-to-32 are fused)
         if ((P->KS == 3 && (op.Cout == 64 || op.Cout == 32)) && !PSEG_KNOB("PSEG_CONV1_MFMA") && !PSEG_KNOB("PSEG_CONV1_VALU")) {

@@ -321,7 +321,7 @@ def test_bf16_res_unet_plan_variants_are_bit_identical(gpu, oracle_mod, monkeypa
         e0.activation("conv2d")          # the stem's first conv: stored after conv_block's ReLU
     assert e0.activation("conv2d_2").shape[2] == 32          # the shortcut is not
     e0.close()
-    for knob in ("PSEG_NO_RELU_FWD", "PSEG_NO_S2_MT2"):
+    for knob in ("PSEG_NO_RELU_FWD", "PSEG_NO_RELU_COPY", "PSEG_NO_S2_MT2"):
         monkeypatch.setenv(knob, "1")
         e1, z1, l1 = run()
         monkeypatch.delenv(knob)

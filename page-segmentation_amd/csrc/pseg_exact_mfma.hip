@@ -106,6 +106,11 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
         const int ab = a.deconv4 ? n / a.Cout : 0;
         wcol[t] = n < Ntot ? ab * Cin * a.Cout + (n - ab * a.Cout) : -1;
     }
+    // Lanes without a weight to load (channel / cout padding, k past the layer) read the first float of the zero slack
+    // every weight buffer carries behind its last element: the load is unconditional and its result needs no select, so
+    // the loads of k-step s + 1 stay in flight under the MFMAs of k-step s (as a conditional load they compiled to
+    // branches with a full memory wait right behind them).
+    const int zoff = (a.deconv4 ? 4 : a.KH * a.KW) * Cin * a.Cout;
     float xa[MT], wa[NT], xb[MT], wb[NT];
 #define PSEG_XMMA(XF, WF)                                                                        \
     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                               \
@@ -115,7 +120,8 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
         const int nks = (cn + 3) >> 2;         // k-steps per tap
         for (int ky = 0; ky < a.KH; ++ky)
             for (int kx = 0; kx < a.KW; ++kx) {
-                const float* wt = a.w + (size_t)((ky * a.KW + kx) * Cin + cb) * a.Cout;
+                const int wbase = ((ky * a.KW + kx) * Cin + cb) * a.Cout;
+                const float* wt = a.w + wbase;
                 const int toff = (ky * TWH + kx) * Cp + g;
                 auto load = [&](float* xf, float* wf, int s) {
                     const int ci = 4 * s + g;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
                     for (int m = 0; m < MT; ++m) xf[m] = xt[pixoff[m] + toff + 4 * s];
                     const bool okc = ci < cn;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) wf[t] = (okc && wcol[t] >= 0) ? wt[(size_t)ci * a.Cout + wcol[t]] : 0.0f;
+                    for (int t = 0; t < NT; ++t) wf[t] = wt[(okc && wcol[t] >= 0) ? ci * a.Cout + wcol[t] : zoff - wbase];
                 };
                 load(xa, wa, 0);
                 int s = 0;
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
 #pragma unroll
             for (int m = 0; m < MT; ++m) xf[m] = xt[pixoff[m] + xo];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wf[t] = (okk && wcol[t] >= 0) ? a.w[(size_t)k_l * a.Cout + wcol[t]] : 0.0f;
+            for (int t = 0; t < NT; ++t) wf[t] = a.w[(okk && wcol[t] >= 0) ? k_l * a.Cout + wcol[t] : zoff];
             k_l += 4;
             ci_l += 4;
             wrap();

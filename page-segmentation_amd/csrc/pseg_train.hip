@@ -183,6 +183,8 @@ __global__ void wd_conv_kernel(const float* w, int KH, int KW, int Cin, int Cout
         const int ky = t / KW, kx = t % KW;
         wd[i] = w[(((size_t)(KH - 1 - ky) * KW + (KW - 1 - kx)) * Cin + c0 + ci) * Cout + co];
     }
+    // zero slack behind the kernel: where the matrix-core conv kernels point the lanes that have no weight to load
+    if (blockIdx.x == 0 && threadIdx.x < COT) wd[n + threadIdx.x] = 0.0f;
 }
 
 // deconv weights [ab][Cin][Cout] -> [ab][Cout][nc] for the channel range [c0, c0+nc)
@@ -192,6 +194,7 @@ __global__ void wd_deconv_kernel(const float* w, int Cin, int Cout, int c0, int 
         const int ci = i % nc, co = (i / nc) % Cout, ab = i / (nc * Cout);
         wd[i] = w[((size_t)ab * Cin + c0 + ci) * Cout + co];
     }
+    if (blockIdx.x == 0 && threadIdx.x < COT) wd[n + threadIdx.x] = 0.0f;   // zero slack (see wd_conv_kernel)
 }
 
 // dX[i,j,c] += sum_{ab,co} dY'[2i+a, 2j+b, co] * W[ab][c0+c][co]   (dY' = dY masked by Y > 0 for ReLU)
@@ -478,8 +481,292 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
     }
 }
 
+// LDS-staged form of wgrad_mfma_kernel for stride-1 convolutions (every fcn / fcn_skip layer, unet's convs): the same
+// MFMA formulation (k = pixel, A = X^T, B = dY), but a workgroup brings a 64-pixel piece of the X row (+ the KXN - 1
+// columns the kernel row reaches) and of the dY row into LDS with coalesced loads -- ReLU mask and pre-activation ReLU
+// applied on the way -- laid out [16-channel tile][pixel][16], so that a fragment is one conflict-free ds_read_b32 per lane
+// (lane (c, g) reads pixel q + g (+ kx), channel c).  The next piece is fetched into registers while the current one is
+// multiplied, which takes the global-memory latency off the MFMA path: the direct kernel issued twelve 4-byte gathers
+// per quad of pixels and ran the matrix pipe at a quarter of its rate.
+constexpr int WGL_CW = 64;   // pixels of a row per staged piece
+template <int TI, int TJ, int KXN>
+__global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradArgs a) {
+    constexpr int NXP = WGL_CW + KXN - 1;
+    constexpr int EX = (NXP * TI * 16 + 255) / 256, EY = (WGL_CW * TJ * 16 + 255) / 256;
+    __shared__ float Xs[TI * NXP * 16];
+    __shared__ float Ys[TJ * WGL_CW * 16];
+    __shared__ float red[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p16 = lane & 15, g = lane >> 4;
+    const int tap0 = blockIdx.x * KXN;
+    const int ky = tap0 / a.KW, kx0 = tap0 % a.KW;
+    const int r0 = blockIdx.y * a.strip_rows, r1 = min(r0 + a.strip_rows, a.Hy);
+    const int nbo = (a.Cout + TJ * 16 - 1) / (TJ * 16);
+    const int xc0 = ((int)blockIdx.z / nbo) * TI * 16, yc0 = ((int)blockIdx.z % nbo) * TJ * 16;
+    const int XCb = min(a.XC - xc0, TI * 16), COb = min(a.Cout - yc0, TJ * 16);
+    const int tiles_ci = (XCb + 15) >> 4, tiles_co = (COb + 15) >> 4;
+    const unsigned invx = (1u << 20) / (unsigned)XCb + 1u, invy = (1u << 20) / (unsigned)COb + 1u;
+    const int NX = NXP * XCb, NY = WGL_CW * COb;
+    wg_f32x4 acc[KXN][TI][TJ];
+#pragma unroll
+    for (int k = 0; k < KXN; ++k)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[k][i][j] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+    float bacc[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) bacc[j] = 0.0f;
+    const bool want_b = a.dB != nullptr && tap0 == 0 && xc0 == 0;
+    // zero the channel pad of the tiles once (staging only writes channels < XCb / COb)
+    for (int i = tid; i < TI * NXP * 16; i += 256) Xs[i] = 0.0f;
+    for (int i = tid; i < TJ * WGL_CW * 16; i += 256) Ys[i] = 0.0f;
+    const int cpr = (a.Wy + WGL_CW - 1) / WGL_CW;      // pieces per row
+    const int npieces = (r1 - r0) * cpr;
+    float xr[EX], yr[EY], ym[EY];
+    // element e = tid + 256 u of a piece is pixel e / channels, channel e % channels for every piece: taken apart once,
+    // kept packed (pixel << 8 | channel; 0xFFFF00 = past the piece)
+    int ex[EX], ey[EY];
+#pragma unroll
+    for (int u = 0; u < EX; ++u) {
+        const int e = tid + u * 256;
+        const int px = (int)(((unsigned)e * invx) >> 20), c = e - px * XCb;
+        ex[u] = e < NX ? (px << 8 | c) : 0xFFFF00;
+    }
+#pragma unroll
+    for (int u = 0; u < EY; ++u) {
+        const int e = tid + u * 256;
+        const int px = (int)(((unsigned)e * invy) >> 20), c = e - px * COb;
+        ey[u] = e < NY ? (px << 8 | c) : 0xFFFF00;
+    }
+    auto fetch = [&](int piece) {
+        const int row = piece / cpr, y = r0 + row, x0 = (piece - row * cpr) * WGL_CW;
+        const int sy = y + ky - a.pt, sxb = x0 + kx0 - a.pl;
+        const bool rowok = sy >= 0 && sy < a.Hx;
+        const float* xrow = a.X + ((size_t)(rowok ? sy : 0) * a.xpitch + sxb) * a.XC + xc0;   // (never dereferenced out of range)
+#pragma unroll
+        for (int u = 0; u < EX; ++u) {
+            const int px = ex[u] >> 8, c = ex[u] & 255;
+            // (nothing looks at a fetched value before commit(): a use right behind a load would put a full memory wait
+            // behind every one of them -- the first version of this kernel did, and ran six times under its MFMA time)
+            xr[u] = 0.0f;
+            if (rowok && (unsigned)(sxb + px) < (unsigned)a.Wx) xr[u] = xrow[px * a.XC + c];
+        }
+        const float* yrow = a.dY + ((size_t)y * a.ypitch + x0) * a.Cout + yc0;
+        const float* mrow = a.maskY ? a.maskY + ((size_t)y * a.ypitch + x0) * a.Cout + yc0 : nullptr;
+#pragma unroll
+        for (int u = 0; u < EY; ++u) {
+            const int px = ey[u] >> 8, c = ey[u] & 255;
+            yr[u] = 0.0f;
+            ym[u] = 1.0f;
+            if (x0 + px < a.Wy) {
+                yr[u] = yrow[px * a.Cout + c];
+                if (mrow) ym[u] = mrow[px * a.Cout + c];
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < EX; ++u) {
+            const int px = ex[u] >> 8, c = ex[u] & 255;
+            if (px < NXP) Xs[((c >> 4) * NXP + px) * 16 + (c & 15)] = (a.in_relu && !(xr[u] > 0.0f)) ? 0.0f : xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < EY; ++u) {
+            const int px = ey[u] >> 8, c = ey[u] & 255;
+            if (px < WGL_CW) Ys[((c >> 4) * WGL_CW + px) * 16 + (c & 15)] = ym[u] > 0.0f ? yr[u] : 0.0f;
+        }
+    };
+    if (npieces > 0) fetch(0);
+    __syncthreads();                                   // the zero fill is done
+    for (int piece = 0; piece < npieces; ++piece) {
+        commit();
+        __syncthreads();
+        if (piece + 1 < npieces) fetch(piece + 1);     // in flight under the MFMAs below
+#pragma unroll
+        for (int q4 = 0; q4 < WGL_CW / 16; ++q4) {
+            const int xq = (q4 * 4 + wave) * 4 + g;
+            float xa[KXN][TI], yb[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) yb[j] = Ys[(j * WGL_CW + xq) * 16 + p16];
+#pragma unroll
+            for (int k = 0; k < KXN; ++k)
+#pragma unroll
+                for (int i = 0; i < TI; ++i) xa[k][i] = Xs[(i * NXP + xq + k) * 16 + p16];
+#pragma unroll
+            for (int k = 0; k < KXN; ++k)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+                    if (i < tiles_ci)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j)
+                            if (j < tiles_co) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[k][i], yb[j], acc[k][i][j], 0, 0, 0);
+            if (want_b)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bacc[j] += yb[j];
+        }
+        __syncthreads();                               // every wave is done with this piece
+    }
+#pragma unroll
+    for (int k = 0; k < KXN; ++k)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+        if (i < tiles_ci)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                if (j < tiles_co) {
+                    for (int w = 0; w < 4; ++w) {
+                        if (wave == w) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float* qd = red + (4 * g + r) * 16 + p16;
+                                *qd = w == 0 ? acc[k][i][j][r] : *qd + acc[k][i][j][r];
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    {
+                        const int e = threadIdx.x, row = e >> 4, col = e & 15;
+                        const int ci = i * 16 + row, co = j * 16 + col;
+                        if (ci < XCb && co < COb)
+                            atomicAdd(&a.dW[((size_t)(tap0 + k) * a.Cin + a.ci0 + xc0 + ci) * a.Cout + yc0 + co], red[e]);
+                    }
+                    __syncthreads();
+                }
+    if (want_b) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            float v = bacc[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0 && j < tiles_co && j * 16 + p16 < COb) atomicAdd(&a.dB[yc0 + j * 16 + p16], v);
+        }
+    }
+}
+
+// Weight gradient of a ONE-channel input layer (the first conv: Cin = 1).  With the input channel as the MFMA row the
+// instance above fills one of its sixteen rows; here the rows are the KW x KW taps instead: A[tap][pixel] = X[pixel + tap]
+// (an im2col gather through L1, 4 bytes per lane), B[pixel][cout] = dY, so one 16x16x4 MFMA covers sixteen taps of four
+// pixels.  One workgroup = a strip of rows, every wave walks its own pixel quads; partial sums leave through the same
+// LDS reduction + one atomicAdd per element as wgrad_mfma_kernel.  (2048x1536, 1 -> 20, k5: 2.28 ms -> see DESIGN 5.)
+template <int TM, int TJ>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(WgradArgs a) {
+    __shared__ float red[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p16 = lane & 15, g = lane >> 4;
+    const int KK = a.KW * a.KW;
+    const int r0 = blockIdx.x * a.strip_rows, r1 = min(r0 + a.strip_rows, a.Hy);
+    const int tiles_co = (a.Cout + 15) >> 4;
+    int tky[TM], tkx[TM];
+    bool tok[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int tap = i * 16 + p16;
+        tok[i] = tap < KK;
+        tky[i] = (tok[i] ? tap / a.KW : 0) - a.pt;
+        tkx[i] = (tok[i] ? tap % a.KW : 0) - a.pl;
+    }
+    wg_f32x4 acc[TM][TJ];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+    float bacc[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) bacc[j] = 0.0f;
+    const bool want_b = a.dB != nullptr;
+    auto load = [&](int y, int xq, float* xa, float* yb) {
+        const int x = xq + g;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int sy = y + tky[i], sx = x + tkx[i];
+            const bool ok = tok[i] && x < a.Wy && sy >= 0 && sy < a.Hx && sx >= 0 && sx < a.Wx;
+            xa[i] = ok ? a.X[(size_t)sy * a.xpitch + sx] : 0.0f;
+        }
+        const size_t o = ((size_t)y * a.ypitch + x) * a.Cout + p16;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            float v = 0.0f;
+            if (j < tiles_co && x < a.Wy && j * 16 + p16 < a.Cout) {
+                v = a.dY[o + j * 16];
+                if (a.maskY && !(a.maskY[o + j * 16] > 0.0f)) v = 0.0f;
+            }
+            yb[j] = v;
+        }
+    };
+    const int qpr = (a.Wy + 15) >> 4;                  // quads per wave per row
+    const int nq = (r1 - r0) * qpr;
+    float xa[TM], yb[TJ], xn[TM], yn[TJ];
+    if (nq > 0) load(r0, wave * 4, xa, yb);
+    for (int q = 0; q < nq; ++q) {
+        if (q + 1 < nq) {
+            const int qn = q + 1, yr = qn / qpr, xc = qn - yr * qpr;
+            load(r0 + yr, (xc * 4 + wave) * 4, xn, yn);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                if (j < tiles_co) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+        if (want_b)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bacc[j] += yb[j];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[i] = xn[i];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) yb[j] = yn[j];
+    }
+    // D tile: lane holds rows (taps) 4g..4g+3, column (cout) p16.  Reduce the four waves through LDS.
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+            if (j < tiles_co) {
+                for (int w = 0; w < 4; ++w) {
+                    if (wave == w) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* qd = red + (4 * g + r) * 16 + p16;
+                            *qd = w == 0 ? acc[i][j][r] : *qd + acc[i][j][r];
+                        }
+                    }
+                    __syncthreads();
+                }
+                {
+                    const int e = threadIdx.x, row = e >> 4, col = e & 15;
+                    const int tap = i * 16 + row, co = j * 16 + col;
+                    if (tap < KK && co < a.Cout) atomicAdd(&a.dW[((size_t)tap * a.Cin + a.ci0) * a.Cout + co], red[e]);
+                }
+                __syncthreads();
+            }
+    if (want_b) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            float v = bacc[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0 && j < tiles_co && j * 16 + p16 < a.Cout) atomicAdd(&a.dB[j * 16 + p16], v);
+        }
+    }
+}
+
 static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     // grid = (strips, taps) for the scalar kernel; the matrix-core kernel takes (taps, strips)
+    if (a.XC == 1 && a.mode == 0 && a.stride == 1 && !a.xup && !a.in_relu && a.KW * a.KW <= 32 && a.Cout <= 64 && !PSEG_KNOB("PSEG_WGRAD_NO_C1") &&
+        !PSEG_KNOB("PSEG_WGRAD_SCALAR")) {
+        WgradArgs c = a;
+        c.strip_rows = std::max(1, cdiv(a.Hy, 1024));
+        const int nwg = cdiv(a.Hy, c.strip_rows), tj = cdiv(a.Cout, 16);
+        if (a.KW * a.KW <= 16) {
+            if (tj <= 2) wgrad_c1_kernel<1, 2><<<nwg, 256, 0, st>>>(c);
+            else wgrad_c1_kernel<1, 4><<<nwg, 256, 0, st>>>(c);
+        } else {
+            if (tj <= 2) wgrad_c1_kernel<2, 2><<<nwg, 256, 0, st>>>(c);
+            else wgrad_c1_kernel<2, 4><<<nwg, 256, 0, st>>>(c);
+        }
+        PSEG_HIP(hipGetLastError());
+        return PSEG_OK;
+    }
+    // stride-1 convolutions: the LDS-staged kernel (same instances, same grids)
+    const bool lds = a.mode == 0 && a.stride == 1 && !a.xup && !PSEG_KNOB("PSEG_WGRAD_NO_LDS");
     if (a.XC <= 16 * WGM_MAXT && a.Cout <= 16 * WGM_MAXT && !PSEG_KNOB("PSEG_WGRAD_SCALAR")) {
         const int ti = (a.XC + 15) / 16, tj = (a.Cout + 15) / 16;
         // a whole kernel row per workgroup for the small k5 layers (mode 0: taps of a row share dY)
@@ -487,19 +774,31 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
             WgradArgs a5 = a;                                  // five times fewer "taps": five times more strips
             a5.strip_rows = std::max(1, a.strip_rows / 5);
             const dim3 g5(grid.y / 5, cdiv(a.Hy, a5.strip_rows));
-#define PSEG_WG5(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) { wgrad_mfma_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a5); PSEG_HIP(hipGetLastError()); return PSEG_OK; }
+#define PSEG_WG5(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) {                                                   \
+                if (lds) wgrad_lds_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a5);                                      \
+                else wgrad_mfma_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a5);                                         \
+                PSEG_HIP(hipGetLastError()); return PSEG_OK; }
             PSEG_WG5(1, 2) PSEG_WG5(2, 2) PSEG_WG5(2, 3)
 #undef PSEG_WG5
+            // wider layers keep a whole kernel row per workgroup only on the LDS-staged kernel (the accumulators of five taps
+            // fill most of the register file: one wave per SIMD, fed from LDS)
+#define PSEG_WG5L(TI_, TJ_) if (lds && ti <= TI_ && tj <= TJ_) { wgrad_lds_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a5); PSEG_HIP(hipGetLastError()); return PSEG_OK; }
+            if (!PSEG_KNOB("PSEG_WGRAD_NO_ROW5")) { PSEG_WG5L(3, 3) PSEG_WG5L(3, 4) PSEG_WG5L(4, 3) }   // (4, 4): 512 registers + 41 spilled
+#undef PSEG_WG5L
         }
         const dim3 g2(grid.y, grid.x);
-#define PSEG_WG(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) { wgrad_mfma_kernel<TI_, TJ_, 1><<<g2, 256, 0, st>>>(a); PSEG_HIP(hipGetLastError()); return PSEG_OK; }
+#define PSEG_WG(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) {                                                    \
+            if (lds && PSEG_KNOB("PSEG_WGRAD_LDS_KX1")) wgrad_lds_kernel<TI_, TJ_, 1><<<g2, 256, 0, st>>>(a);           \
+            else wgrad_mfma_kernel<TI_, TJ_, 1><<<g2, 256, 0, st>>>(a);   /* one tap per workgroup: the direct kernel is faster */ \
+            PSEG_HIP(hipGetLastError()); return PSEG_OK; }
         PSEG_WG(1, 2) PSEG_WG(2, 2) PSEG_WG(2, 3) PSEG_WG(3, 3) PSEG_WG(3, 5) PSEG_WG(5, 3) PSEG_WG(5, 5)
 #undef PSEG_WG
         return fail(PSEG_EUNSUPPORTED, "no weight-gradient instance for %d x %d channels", a.XC, a.Cout);
     } else if (!PSEG_KNOB("PSEG_WGRAD_SCALAR")) {
         // wide layers (unet / res_unet): 64 x 64 channel blocks on blockIdx.z
         const dim3 g3(grid.y, grid.x, cdiv(a.XC, 64) * cdiv(a.Cout, 64));
-        wgrad_mfma_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
+        if (lds && PSEG_KNOB("PSEG_WGRAD_LDS_KX1")) wgrad_lds_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
+        else wgrad_mfma_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
     } else {
         const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
         if (a.stride != 1 || a.xup || a.in_relu || (XCp / 4) * (COp / 4) > 768)

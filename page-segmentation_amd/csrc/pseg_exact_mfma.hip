@@ -65,28 +65,45 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
     if (cb) __syncthreads();                         // every wave is done reading the previous block's tile
     // ---- stage the halo tile: the block's input channels, zeros outside the image and in the channel pad
     const int npx = THH * TWH;
-    for (int p = wave; p < npx; p += 4) {            // one pixel per wave trip, lanes over channels
-        const int r = p / TWH, c = p - r * TWH;
-        const int iy = iy0 + r, ix = ix0 + c;
-        const bool in = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        float* d = xt + (size_t)p * Cp;
-        const float* s0 = a.src0 + ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0;
-        const float* s1 = a.src1 ? a.src1 + ((size_t)(iy >> a.up1) * (a.Win >> a.up1) + (ix >> a.up1)) * a.C1 : nullptr;
-        const float* mk = a.mask ? a.mask + ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0 : nullptr;
-        for (int cl = lane; cl < Cp; cl += 64) {
-            const int ch = cb + cl;
-            float v = 0.0f;
-            if (in && cl < cn) {
-                if (ch < a.C0) {
-                    v = s0[ch];
-                    if (a.in_relu) v = v > 0.0f ? v : 0.0f;
-                    if (mk) v = mk[ch] > 0.0f ? v : 0.0f;
-                } else {
-                    v = s1[ch - a.C0];
-                    if (a.in_relu) v = v > 0.0f ? v : 0.0f;
+    // One item = (pixel, 64-channel slice): lanes over channels.  Eight items are fetched before the first one is used: a
+    // value looked at right behind its load (ReLU, mask, the store itself) costs a full memory latency per item, and a
+    // wave has ~110 of them per tile -- that chain, not the MFMAs, was most of this kernel's time on the thin layers.
+    {
+        constexpr int SU = 8;
+        const int nch = (Cp + 63) >> 6;                  // slices per pixel
+        const int nit = ((npx - wave + 3) >> 2) * nch;   // items of this wave
+        for (int it0 = 0; it0 < nit; it0 += SU) {
+            float v[SU], mv[SU];
+            int dsto[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int it = it0 + u;
+                const int pq = it / nch, sl = it - pq * nch;
+                const int p = wave + 4 * pq, cl = sl * 64 + lane;
+                const int r = p / TWH, c = p - r * TWH;
+                const int iy = iy0 + r, ix = ix0 + c;
+                const bool in = it < nit && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+                const int ch = cb + cl;
+                v[u] = 0.0f;
+                mv[u] = 1.0f;
+                dsto[u] = (it < nit && cl < Cp) ? p * Cp + cl : -1;
+                if (in && cl < cn) {
+                    if (ch < a.C0) {
+                        const size_t o = ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0 + ch;
+                        v[u] = a.src0[o];
+                        if (a.mask) mv[u] = a.mask[o];
+                    } else {
+                        v[u] = a.src1[((size_t)(iy >> a.up1) * (a.Win >> a.up1) + (ix >> a.up1)) * a.C1 + (ch - a.C0)];
+                    }
                 }
             }
-            d[cl] = v;
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                float x = v[u];
+                if (a.in_relu) x = x > 0.0f ? x : 0.0f;
+                x = mv[u] > 0.0f ? x : 0.0f;
+                if (dsto[u] >= 0) xt[dsto[u]] = x;
+            }
         }
     }
     __syncthreads();

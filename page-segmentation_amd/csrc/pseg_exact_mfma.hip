@@ -68,7 +68,52 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
     // One item = (pixel, 64-channel slice): lanes over channels.  Eight items are fetched before the first one is used: a
     // value looked at right behind its load (ReLU, mask, the store itself) costs a full memory latency per item, and a
     // wave has ~110 of them per tile -- that chain, not the MFMAs, was most of this kernel's time on the thin layers.
-    {
+    constexpr int FJ = 16;                               // 64-float pieces of a tile row the flat path keeps in flight
+    if (!a.src1 && !a.up0 && cn == Cin && TWH * Cin <= 64 * FJ) {
+        // Thin single-source layers (fewer than 32 channels: the full-resolution ones): a tile row is ONE contiguous run of
+        // TWH * Cin floats in memory -- lanes over that run (all 64 busy instead of Cin of them), every piece of the row
+        // requested before the first is used.
+        const int rowf = TWH * Cin, nj = (rowf + 63) >> 6;
+        const unsigned invc = (1u << 20) / (unsigned)Cin + 1u;
+        int dj[FJ];                                      // LDS offset of piece j's float inside a tile row, or -1
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int e = j * 64 + lane;
+            const int px = (int)(((unsigned)e * invc) >> 20), c = e - px * Cin;
+            dj[j] = e < rowf ? (px << 12 | (px * Cp + c)) : -1;   // (tile rows hold < 4096 floats: TWH * Cp)
+        }
+        for (int r = wave; r < THH; r += 4) {
+            const int iy = iy0 + r;
+            const bool rowok = iy >= 0 && iy < a.Hin;
+            const size_t ro = ((size_t)(rowok ? iy : 0) * a.Win) * a.C0;
+            const float* srow = a.src0 + ro + (ptrdiff_t)ix0 * a.C0;       // (lanes left of the image are masked below)
+            const float* mrow = a.mask ? a.mask + ro + (ptrdiff_t)ix0 * a.C0 : nullptr;
+            float v[FJ], mv[FJ];
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                v[j] = 0.0f;
+                mv[j] = 1.0f;
+                const int px = dj[j] >> 12;
+                if (j < nj && dj[j] >= 0 && rowok && (unsigned)(ix0 + px) < (unsigned)a.Win) {
+                    v[j] = srow[j * 64 + lane];
+                    if (mrow) mv[j] = mrow[j * 64 + lane];
+                }
+            }
+            float* drow = xt + (size_t)r * TWH * Cp;
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                float x = v[j];
+                if (a.in_relu) x = x > 0.0f ? x : 0.0f;
+                x = mv[j] > 0.0f ? x : 0.0f;
+                if (j < nj && dj[j] >= 0) drow[dj[j] & 4095] = x;
+            }
+        }
+        // the channel pad of every pixel (k-steps run over 4 * ceil(Cin / 4) channels)
+        for (int i = tid; i < npx * (Cp - Cin); i += 256) {
+            const int p = i / (Cp - Cin), c = Cin + i - p * (Cp - Cin);
+            xt[p * Cp + c] = 0.0f;
+        }
+    } else {
         constexpr int SU = 8;
         const int nch = (Cp + 63) >> 6;                  // slices per pixel
         const int nit = ((npx - wave + 3) >> 2) * nch;   // items of this wave

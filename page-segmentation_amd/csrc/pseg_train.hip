@@ -387,7 +387,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
     for (int j = 0; j < TJ; ++j) bacc[j] = 0.0f;
     const bool want_b = a.dB != nullptr && tap0 == 0 && xc0 == 0;
 
-    auto load = [&](int y, int xq, float (*xa)[TI], float* yb) {
+    // (fetched values are not looked at before the rotation at the end of the step: a ReLU or mask select right behind its
+    // load put a full memory wait behind every dY fragment -- five to six serial latencies per quad of pixels)
+    auto load = [&](int y, int xq, float (*xa)[TI], float* yb, float* ym) {
         const int x = xq + g;
 #pragma unroll
         for (int k = 0; k < KXN; ++k) {
@@ -397,9 +399,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
             const float* xp = a.X + ((size_t)(sy >> a.xup) * a.xpitch + (sx >> a.xup)) * a.XC + xc0 + p16;
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                float v = (i < tiles_ci && okx && i * 16 + p16 < XCb) ? xp[i * 16] : 0.0f;
-                if (a.in_relu) v = v > 0.0f ? v : 0.0f;
-                xa[k][i] = v;
+                xa[k][i] = 0.0f;
+                if (i < tiles_ci && okx && i * 16 + p16 < XCb) xa[k][i] = xp[i * 16];
             }
         }
         const int dy = a.mode == 0 ? y : 2 * y + (tap0 >> 1), dx = a.mode == 0 ? x : 2 * x + (tap0 & 1);
@@ -407,23 +408,31 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
         const bool oky = x < itW;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            float v = 0.0f;
+            yb[j] = 0.0f;
+            ym[j] = 1.0f;
             if (j < tiles_co && oky && j * 16 + p16 < COb) {
-                v = a.dY[o + j * 16];
-                if (a.maskY && !(a.maskY[o + j * 16] > 0.0f)) v = 0.0f;
+                yb[j] = a.dY[o + j * 16];
+                if (a.maskY) ym[j] = a.maskY[o + j * 16];
             }
-            yb[j] = v;
         }
     };
     // quads of this wave: (row y, columns 4*(wave + 4n) .. +3), walked as one sequence
     const int qpr = (itW + 15) >> 4;                   // quads per wave per row
     const int nq = (r1 - r0) * qpr;
-    float xa[KXN][TI], yb[TJ], xn[KXN][TI], yn[TJ];
-    if (nq > 0) load(r0, wave * 4, xa, yb);
+    float xa[KXN][TI], yb[TJ], xn[KXN][TI], yn[TJ], ymn[TJ];
+    auto rotate = [&]() {
+#pragma unroll
+        for (int k = 0; k < KXN; ++k)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) xa[k][i] = (a.in_relu && !(xn[k][i] > 0.0f)) ? 0.0f : xn[k][i];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) yb[j] = ymn[j] > 0.0f ? yn[j] : 0.0f;
+    };
+    if (nq > 0) { load(r0, wave * 4, xn, yn, ymn); rotate(); }
     for (int q = 0; q < nq; ++q) {
         if (q + 1 < nq) {
             const int qn = q + 1, yr = qn / qpr, xc = qn - yr * qpr;
-            load(r0 + yr, (xc * 4 + wave) * 4, xn, yn);
+            load(r0 + yr, (xc * 4 + wave) * 4, xn, yn, ymn);
         }
 #pragma unroll
         for (int k = 0; k < KXN; ++k)
@@ -436,12 +445,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
         if (want_b)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) bacc[j] += yb[j];
-#pragma unroll
-        for (int k = 0; k < KXN; ++k)
-#pragma unroll
-            for (int i = 0; i < TI; ++i) xa[k][i] = xn[k][i];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) yb[j] = yn[j];
+        if (q + 1 < nq) rotate();
     }
     // D tile: lane holds rows (ci) 4g..4g+3, column (co) p16.  Reduce the four waves through LDS.
 #pragma unroll
@@ -780,16 +784,12 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
                 PSEG_HIP(hipGetLastError()); return PSEG_OK; }
             PSEG_WG5(1, 2) PSEG_WG5(2, 2) PSEG_WG5(2, 3)
 #undef PSEG_WG5
-            // wider layers keep a whole kernel row per workgroup only on the LDS-staged kernel (the accumulators of five taps
-            // fill most of the register file: one wave per SIMD, fed from LDS)
-#define PSEG_WG5L(TI_, TJ_) if (lds && ti <= TI_ && tj <= TJ_) { wgrad_lds_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a5); PSEG_HIP(hipGetLastError()); return PSEG_OK; }
-            if (!PSEG_KNOB("PSEG_WGRAD_NO_ROW5")) { PSEG_WG5L(3, 3) PSEG_WG5L(3, 4) PSEG_WG5L(4, 3) }   // (4, 4): 512 registers + 41 spilled
-#undef PSEG_WG5L
+            // (a kernel row per workgroup for the wider layers -- <3,3,5>, <3,4,5>, <4,3,5> on the LDS-staged kernel, 384-497
+            // registers, one wave per SIMD -- was measured: 30.17 vs 29.97 ms per step against one tap per workgroup below)
         }
         const dim3 g2(grid.y, grid.x);
 #define PSEG_WG(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) {                                                    \
-            if (lds && PSEG_KNOB("PSEG_WGRAD_LDS_KX1")) wgrad_lds_kernel<TI_, TJ_, 1><<<g2, 256, 0, st>>>(a);           \
-            else wgrad_mfma_kernel<TI_, TJ_, 1><<<g2, 256, 0, st>>>(a);   /* one tap per workgroup: the direct kernel is faster */ \
+            wgrad_mfma_kernel<TI_, TJ_, 1><<<g2, 256, 0, st>>>(a);   /* one tap per workgroup: the direct kernel is faster than the LDS-staged one */ \
             PSEG_HIP(hipGetLastError()); return PSEG_OK; }
         PSEG_WG(1, 2) PSEG_WG(2, 2) PSEG_WG(2, 3) PSEG_WG(3, 3) PSEG_WG(3, 5) PSEG_WG(5, 3) PSEG_WG(5, 5)
 #undef PSEG_WG
@@ -797,8 +797,7 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     } else if (!PSEG_KNOB("PSEG_WGRAD_SCALAR")) {
         // wide layers (unet / res_unet): 64 x 64 channel blocks on blockIdx.z
         const dim3 g3(grid.y, grid.x, cdiv(a.XC, 64) * cdiv(a.Cout, 64));
-        if (lds && PSEG_KNOB("PSEG_WGRAD_LDS_KX1")) wgrad_lds_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
-        else wgrad_mfma_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
+        wgrad_mfma_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
     } else {
         const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
         if (a.stride != 1 || a.xup || a.in_relu || (XCp / 4) * (COp / 4) > 768)

@@ -133,6 +133,67 @@ __global__ __launch_bounds__(256) void conv_exact_kernel(ConvArgs a) {
     }
 }
 
+// 1x1 convolution with a handful of output channels (the logits layer: 50 -> n_classes at full resolution).  In
+// conv_exact_kernel a thread walks its pixel's channels in memory -- one cache line per lane and load; here a block takes
+// 256 consecutive pixels of a row, whose channels are one contiguous run per source, through LDS with coalesced loads
+// (pixel pitch Cin + 1 floats: conflict-free column reads), then runs the SAME chain per thread: ci ascending over
+// [src0, src1], fmaf, + bias -- the same bits.  HBM-bound (Cin * 4 B read per pixel): 0.83 ms -> see DESIGN 5.
+__global__ __launch_bounds__(256) void conv1x1_exact_kernel(ConvArgs a) {
+    extern __shared__ float xs[];   // [256][Cin + 1]
+    const int Cin = a.C0 + a.C1, P = Cin + 1;
+    const int y = blockIdx.y, x0 = blockIdx.x * 256;
+    const int npx = min(256, a.Wout - x0);
+    const int co0 = blockIdx.z * COT;
+    for (int srcsel = 0; srcsel < (a.C1 > 0 ? 2 : 1); ++srcsel) {
+        const int C = srcsel ? a.C1 : a.C0, cbase = srcsel ? a.C0 : 0;
+        const float* p = (srcsel ? a.src1 : a.src0) + ((size_t)y * a.Win + x0) * C;
+        const int n = npx * C;
+        const unsigned inv = (1u << 20) / (unsigned)C + 1u;     // n <= 256 * C: e * inv < 2^32 for C >= 1
+        for (int e0 = 0; e0 < n; e0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 256 + (int)threadIdx.x;
+                v[u] = e < n ? p[e] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 256 + (int)threadIdx.x;
+                const int px = (int)(((unsigned long long)(unsigned)e * inv) >> 20), c = e - px * C;
+                if (e < n) xs[px * P + cbase + c] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= npx) return;
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = 0.0f;
+    const float* wt = a.w + co0;
+    const float* xp = xs + t * P;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float xv = xp[ci];
+        const float* wr = wt + (size_t)ci * a.Cout;
+#pragma unroll
+        for (int j = 0; j < COT; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
+    }
+    const int x = x0 + t;
+    const size_t opix = a.dst_pitch ? (size_t)y * a.dst_pitch + x : (size_t)y * a.Wout + x;
+    float* o = a.dst + opix * a.Cout;
+    const float* ad = a.add ? a.add + opix * a.Cout : nullptr;
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+        const int co = co0 + j;
+        if (co < a.Cout) {
+            float v = a.bias ? acc[j] + a.bias[co] : acc[j];
+            if (ad) v = v + ad[co];
+            if (a.relu) v = v > 0.0f ? v : 0.0f;
+            o[co] = v;
+        }
+    }
+}
+
 struct DeconvArgs {
     const float* src0;
     const float* src1;
@@ -339,6 +400,21 @@ int launch_conv_exact(const ConvArgs& a, hipStream_t st) {
     // matrix-core path (same bits, see pseg_exact_mfma.hip) when the all-channel tile fits in LDS
     const int rc = launch_conv_exact_mfma(a, st);
     if (rc != 0) return rc < 0 ? rc : PSEG_OK;
+    const int Cin = a.C0 + a.C1;
+    if (a.KH == 1 && a.KW == 1 && a.stride == 1 && !a.pt && !a.pl && !a.up0 && !a.up1 && !a.in_relu && !a.mask && Cin <= 127 &&
+        !PSEG_KNOB("PSEG_EXACT_NO_1X1")) {
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        PSEG_HIP(hipGetDevice(&dev));
+        if (!attr_set[dev & 63]) {
+            PSEG_HIP(hipFuncSetAttribute((const void*)conv1x1_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[dev & 63] = true;
+        }
+        dim3 g1(cdiv(a.Wout, 256), a.Hout, cdiv(a.Cout, COT));
+        conv1x1_exact_kernel<<<g1, 256, (size_t)256 * (Cin + 1) * sizeof(float), st>>>(a);
+        PSEG_HIP(hipGetLastError());
+        return PSEG_OK;
+    }
     dim3 grid(cdiv(a.Hout * a.Wout, 256), cdiv(a.Cout, COT));
     conv_exact_kernel<<<grid, 256, 0, st>>>(a);
     PSEG_HIP(hipGetLastError());

@@ -68,19 +68,19 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
     // One item = (pixel, 64-channel slice): lanes over channels.  Eight items are fetched before the first one is used: a
     // value looked at right behind its load (ReLU, mask, the store itself) costs a full memory latency per item, and a
     // wave has ~110 of them per tile -- that chain, not the MFMAs, was most of this kernel's time on the thin layers.
-    constexpr int FJ = 16;                               // 64-float pieces of a tile row the flat path keeps in flight
-    if (!a.src1 && !a.up0 && cn == Cin && TWH * Cin <= 64 * FJ) {
-        // Thin single-source layers (fewer than 32 channels: the full-resolution ones): a tile row is ONE contiguous run of
-        // TWH * Cin floats in memory -- lanes over that run (all 64 busy instead of Cin of them), every piece of the row
-        // requested before the first is used.
+    constexpr int FJ = 16;                               // 64-float pieces of a tile row in flight per wave
+    if (!a.src1 && !a.up0 && cn == Cin && Cin < 64) {
+        // Thin single-source layers (fewer than 64 channels: every full- and half-resolution layer of the fcn graphs and
+        // their data gradients): a tile row is ONE contiguous run of TWH * Cin floats in memory -- lanes over that run
+        // (all 64 busy instead of Cin of them), sixteen pieces requested before the first is used.
         const int rowf = TWH * Cin, nj = (rowf + 63) >> 6;
-        const unsigned invc = (1u << 20) / (unsigned)Cin + 1u;
-        int dj[FJ];                                      // LDS offset of piece j's float inside a tile row, or -1
+        const unsigned invc = (1u << 20) / (unsigned)Cin + 1u;   // e < 36 * 64 (stride 1) ... 2 * 67 * 64: e * invc < 2^32
+        int dj0[FJ];                                     // the first sixteen pieces' (pixel, LDS offset), the same for every row
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
             const int e = j * 64 + lane;
             const int px = (int)(((unsigned)e * invc) >> 20), c = e - px * Cin;
-            dj[j] = e < rowf ? (px << 12 | (px * Cp + c)) : -1;   // (tile rows hold < 4096 floats: TWH * Cp)
+            dj0[j] = e < rowf ? (px << 16 | (px * Cp + c)) : -1;
         }
         for (int r = wave; r < THH; r += 4) {
             const int iy = iy0 + r;
@@ -88,24 +88,34 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
             const size_t ro = ((size_t)(rowok ? iy : 0) * a.Win) * a.C0;
             const float* srow = a.src0 + ro + (ptrdiff_t)ix0 * a.C0;       // (lanes left of the image are masked below)
             const float* mrow = a.mask ? a.mask + ro + (ptrdiff_t)ix0 * a.C0 : nullptr;
-            float v[FJ], mv[FJ];
-#pragma unroll
-            for (int j = 0; j < FJ; ++j) {
-                v[j] = 0.0f;
-                mv[j] = 1.0f;
-                const int px = dj[j] >> 12;
-                if (j < nj && dj[j] >= 0 && rowok && (unsigned)(ix0 + px) < (unsigned)a.Win) {
-                    v[j] = srow[j * 64 + lane];
-                    if (mrow) mv[j] = mrow[j * 64 + lane];
-                }
-            }
             float* drow = xt + (size_t)r * TWH * Cp;
+            for (int j0 = 0; j0 < nj; j0 += FJ) {
+                float v[FJ], mv[FJ];
+                int dj[FJ];                              // LDS offset of the piece's float inside the tile row, or -1
 #pragma unroll
-            for (int j = 0; j < FJ; ++j) {
-                float x = v[j];
-                if (a.in_relu) x = x > 0.0f ? x : 0.0f;
-                x = mv[j] > 0.0f ? x : 0.0f;
-                if (j < nj && dj[j] >= 0) drow[dj[j] & 4095] = x;
+                for (int j = 0; j < FJ; ++j) {
+                    const int e = (j0 + j) * 64 + lane;
+                    int pk = dj0[j];
+                    if (j0) {
+                        const int px_ = (int)(((unsigned)e * invc) >> 20), c = e - px_ * Cin;
+                        pk = e < rowf ? (px_ << 16 | (px_ * Cp + c)) : -1;
+                    }
+                    const int px = pk >> 16;
+                    dj[j] = pk < 0 ? -1 : (pk & 0xFFFF);
+                    v[j] = 0.0f;
+                    mv[j] = 1.0f;
+                    if (pk >= 0 && rowok && (unsigned)(ix0 + px) < (unsigned)a.Win) {
+                        v[j] = srow[e];
+                        if (mrow) mv[j] = mrow[e];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    float x = v[j];
+                    if (a.in_relu) x = x > 0.0f ? x : 0.0f;
+                    x = mv[j] > 0.0f ? x : 0.0f;
+                    if (dj[j] >= 0) drow[dj[j]] = x;
+                }
             }
         }
         // the channel pad of every pixel (k-steps run over 4 * ceil(Cin / 4) channels)

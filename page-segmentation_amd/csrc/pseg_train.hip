@@ -33,6 +33,10 @@ struct TrainState {
     float* d_m = nullptr;
     float* d_v = nullptr;
     float* d_norm = nullptr;     // per-parameter sum of squares
+    float* d_part = nullptr;     // [slice][SUMSQ_MAXB] per-block partial sums of sumsq_kernel
+    int* d_slice_nblk = nullptr; // per slice: blocks its sumsq_kernel ran / parameter index it belongs to
+    int* d_slice_pi = nullptr;
+    int nslices = 0;
     std::vector<int64_t> off;    // per param offset in the flat buffers
     int64_t nparam = 0, nflat = 0;
     std::vector<float*> tgrad;   // per tensor gradient (canvas dims), lazily sized
@@ -58,6 +62,7 @@ void train_free(Engine& e) {
     TrainState* t = TS(e);
     if (!t) return;
     (void)hipFree(t->d_grad); (void)hipFree(t->d_m); (void)hipFree(t->d_v); (void)hipFree(t->d_norm);
+    (void)hipFree(t->d_part); (void)hipFree(t->d_slice_nblk); (void)hipFree(t->d_slice_pi);
     for (auto p : t->tgrad) (void)hipFree(p);
     (void)hipFree(t->d_wd); (void)hipFree(t->d_logits); (void)hipFree(t->d_dlogits);
     (void)hipFree(t->d_mask); (void)hipFree(t->d_img); (void)hipFree(t->d_tmp); (void)hipFree(t->d_tmp2);
@@ -870,14 +875,38 @@ __global__ void bias_grad_kernel(const float* dY, const float* maskY, size_t npi
     if ((int)threadIdx.x < Cout && sh[threadIdx.x] != 0.0f) atomicAdd(&dB[threadIdx.x], sh[threadIdx.x]);
 }
 
-__global__ void sumsq_kernel(const float* g, int64_t n, float scale, float* out) {
+// Sum of squares of one parameter's (scaled) gradient, in a FIXED summation order: per-thread stripes, butterfly inside the
+// wave, the four waves in order through LDS, then the blocks' partial sums in order (sumsq_final_kernel).  Data-parallel
+// replicas clip by this norm: with float atomics its last bit depended on the arrival order and two ranks that hold the
+// same all-reduced gradient could step apart (tests/test_configs_gpu.py: replicas bit-identical).
+constexpr int SUMSQ_MAXB = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, float scale, float* part) {
+    __shared__ float ws[4];
     float s = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = g[i] * scale;
         s += v * v;
     }
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+}
+// one block per (parameter slice): its nblk partial sums, strided over the threads in order, tree-reduced in LDS; slices
+// of one tensor (a BatchNormalization vector spread over two ops: exactly two terms) meet in out[pi] -- a + b == b + a
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* part, const int* nblk, const int* pidx, float* out) {
+    __shared__ float sh[256];
+    const float* p = part + (size_t)blockIdx.x * SUMSQ_MAXB;
+    const int nb = nblk[blockIdx.x];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += p[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out + pidx[blockIdx.x], sh[0]);
 }
 
 // g <- g*scale; per-tensor clip_by_norm (t * clip / max(norm, clip)); optional clipvalue; then the update
@@ -1274,23 +1303,44 @@ static int train_apply(Engine& e, float lr, float gscale) {
     // parameter -> device buffer (kernels: op.d_w in correlation layout; biases: op.d_b; BatchNormalization: gamma and
     // beta slices at the head of op.d_w -- the moving statistics are not trained).  All norms first: the slices of one
     // BatchNormalization tensor spread over two ops share a clip_by_norm.
+    if (!t->d_part) {   // slices in op order: (op, kernel | bias) -- fixed for the life of the engine
+        std::vector<int> nblk, pidx;
+        for (auto& op : e.ops) {
+            if (op.kparam < 0) continue;
+            for (int which = 0; which < 2; ++which) {
+                const int pi = which == 0 ? op.kparam : op.bparam;
+                const int64_t n = op.type == OP_BN ? op.Cin : (int64_t)e.params[pi].host.size();
+                nblk.push_back((int)std::min<int64_t>((n + 255) / 256, SUMSQ_MAXB));
+                pidx.push_back(pi);
+            }
+        }
+        t->nslices = (int)nblk.size();
+        PSEG_HIP(hipMalloc((void**)&t->d_part, (size_t)t->nslices * SUMSQ_MAXB * 4));
+        PSEG_HIP(hipMalloc((void**)&t->d_slice_nblk, nblk.size() * 4));
+        PSEG_HIP(hipMalloc((void**)&t->d_slice_pi, pidx.size() * 4));
+        PSEG_HIP(hipMemcpy(t->d_slice_nblk, nblk.data(), nblk.size() * 4, hipMemcpyHostToDevice));
+        PSEG_HIP(hipMemcpy(t->d_slice_pi, pidx.data(), pidx.size() * 4, hipMemcpyHostToDevice));
+        PSEG_HIP(hipDeviceSynchronize());
+    }
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 0 && !(t->clipnorm > 0.0f)) continue;
+        int slice = 0;
         for (auto& op : e.ops) {
             if (op.kparam < 0) continue;
             const bool bn = op.type == OP_BN;
-            for (int which = 0; which < 2; ++which) {
+            for (int which = 0; which < 2; ++which, ++slice) {
                 const int pi = which == 0 ? op.kparam : op.bparam;
                 const int64_t n = bn ? op.Cin : (int64_t)e.params[pi].host.size();
                 const int64_t o = t->off[pi] + (bn ? op.bn_c0 : 0);
                 float* g = t->d_grad + o;
                 float* p = bn ? op.d_w + which * op.Cin : (which == 0 ? op.d_w : op.d_b);
-                const int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
-                if (pass == 0) sumsq_kernel<<<grid, 256, 0, st>>>(g, n, gscale, t->d_norm + pi);
+                const int grid = (int)std::min<int64_t>((n + 255) / 256, SUMSQ_MAXB);
+                if (pass == 0) sumsq_kernel<<<grid, 256, 0, st>>>(g, n, gscale, t->d_part + (size_t)slice * SUMSQ_MAXB);
                 else opt_kernel<<<grid, 256, 0, st>>>(t->optimizer, p, g, t->d_m + o, t->d_v + o, n, gscale,
                                                      t->d_norm + pi, t->clipnorm, t->clipvalue, o_);
             }
         }
+        if (pass == 0) sumsq_final_kernel<<<t->nslices, 256, 0, st>>>(t->d_part, t->d_slice_nblk, t->d_slice_pi, t->d_norm);
     }
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;

@@ -12,18 +12,17 @@ from pseg_amd import engine as E, synth
 arch = sys.argv[1] if len(sys.argv) > 1 else "fcn_skip"
 layers = sys.argv[2:] or ["conv2d_1", "conv2d_2", "conv2d_3", "conv2d_4", "conv2d_5", "conv2d_transpose_2", "conv2d_transpose_4"]
 H, W = 2048, 1536
-eng = E.Engine(arch, 3, device=0, mode=E.MODE_BF16)
-eng.set_weights(synth.glorot_weights(eng.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
 img = torch.from_numpy(synth.synth_page(1000, H, W, 3)[0]).cuda()
 lab = torch.empty((H, W), dtype=torch.uint8, device="cuda")
 os.makedirs("gpurun_out", exist_ok=True)
-for _ in range(3):
-    eng.predict_device(img.data_ptr(), H, W, d_labels_u8=lab.data_ptr())
-torch.cuda.synchronize()
 for ly in layers:
-    os.environ["PSEG_TRACE"] = ly
-    eng.predict_device(img.data_ptr(), H, W, d_labels_u8=lab.data_ptr())
+    os.environ["PSEG_TRACE"] = ly          # the PSEG_* knobs are read once per engine creation
+    eng = E.Engine(arch, 3, device=0, mode=E.MODE_BF16)
+    eng.set_weights(synth.glorot_weights(eng.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+    for _ in range(3):                     # (the last traced call's file is the one read below)
+        eng.predict_device(img.data_ptr(), H, W, d_labels_u8=lab.data_ptr())
     torch.cuda.synchronize()
+    eng.close()
     os.environ.pop("PSEG_TRACE")
     fn = "gpurun_out/trace_%s.bin" % ly
     if not os.path.exists(fn):

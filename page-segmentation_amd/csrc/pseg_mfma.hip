@@ -2341,6 +2341,227 @@ __global__ __launch_bounds__(256) void logits_bf16_kernel(const uint16_t* src0, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k5 stride-1 mid layers whose whole weight set fits LDS beside two input tiles (fcn / fcn_skip: conv3, conv4): a
+// persistent PING-PONG kernel.  In conv_mfma_kernel a workgroup's life is prologue -> k-loop -> epilogue and only the
+// k-loop feeds the matrix pipe; with three workgroups per CU the pipe is ~48 % busy (SQ_VALU_MFMA_BUSY_CYCLES), the
+// rest of a wave's time goes to issuing weight / tile DMAs (the 75-96 KB weight set is re-streamed for every 8 x 32
+// tile) and waiting for them.  Here ONE 768-thread workgroup per CU keeps the weights and the k-chunk table resident and
+// walks its tiles in phases separated by one s_barrier:
+//   * waves 8-11 (PRODUCERS) bring tile i + 1 into the other of two LDS tile buffers by LDS-DMA (zero fill outside the
+//     image comes from the buffer descriptor) -- they never touch the matrix pipe;
+//   * consumer team i & 1 (waves 0-3 or 4-7, one wave per SIMD each) runs the k-loop of tile i: the SIMD's matrix pipe
+//     belongs to that wave for the phase;
+//   * the other team stores the tile it accumulated in the previous phase (bias was the start value; fused 2x2 max-pool,
+//     bf16 rounding) from its registers.
+// A phase therefore lasts one k-loop; the epilogue and the DMA of the neighbouring tiles run beside it.
+// The cout tile that is half empty (40 couts = 2.5 tiles) keeps only its 8 real rows in LDS (512-byte pieces; lanes of
+// the empty rows read a zero slot): conv4's weights 96 -> 80 KB, which is what lets two 35 KB tiles fit.
+// Same products, same k order, same start value as conv_mfma_kernel: the same bits.
+// ---------------------------------------------------------------------------------------------
+template <int SG, bool POOL>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_pp_kernel(MConv a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 4, NT = 3, TH = 8, KS = 5, THH = TH + KS - 1, TWH = TW + KS - 1, PS2 = SG * 16;
+    constexpr int WSTEP = 2 * 1024 + 512;                 // LDS bytes of one k-step's A fragments (third tile: rows 0-7 only)
+    const int TB = a.lds_w_off;                           // bytes of one input tile (THH rows), 16-aligned (host)
+    const int ks = a.ks_full;
+    char* const w_t = smem + 2 * TB;
+    char* const zero16 = w_t + ks * WSTEP;                // 16 zero bytes: the A rows that do not exist
+    int* const tab_l = (int*)(zero16 + 16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, g = lane >> 4;
+    const int tiles_x = (a.Wout + TW - 1) / TW;
+    auto xcd_tile = [&](int t) {
+        if (a.xq < 0) return t;
+        const int x = t & 7, j = t >> 3;
+        return x * a.xq + min(x, a.xr) + j;
+    };
+    auto origin = [&](int i, int& oy, int& ox) {
+        const int t = xcd_tile((int)blockIdx.x + i * (int)gridDim.x);
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        oy = ty * TH; ox = tx * TW;
+    };
+    const int n_my = ((int)a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
+    // ---- resident weights + k-chunk table + clean tile buffers: once per workgroup ---------------------------------
+    for (int pc = wave; pc < ks * NT; pc += 12) {
+        const int s_ = pc / NT, t_ = pc - s_ * NT;
+        // packed A fragments: [k-step][cout tile][lane = (row p16, k-group g)][8]; tile 2 keeps lanes with p16 < 8 as slots g*8 + p16
+        const int sl = t_ == 2 ? (lane >> 3) * 16 + (lane & 7) : lane;
+        if (t_ < 2 || lane < 32)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wpk + (size_t)pc * 512 + sl * 8),
+                                             (__attribute__((address_space(3))) void*)(w_t + s_ * WSTEP + t_ * 1024), 16, 0, 0);
+    }
+    if (tid < ks * 4) tab_l[tid] = a.tab_full[tid];
+    if (tid < 4) ((int*)zero16)[tid] = 0;
+    for (int i = tid * 16; i < 2 * TB; i += 768 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();                                        // weights, table and the zeroed buffers are in place
+
+    if (wave >= 8) {
+        // =============================== PRODUCERS ===============================
+        const int pw = wave - 8;
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
+        constexpr unsigned OOB = 0xfffffff0u;
+        constexpr int ROW_SLOTS = TWH * SG, J = (ROW_SLOTS + 63) >> 6;
+        const unsigned inv = 65536u / (unsigned)SG + 1u;
+        auto stage = [&](int i) {
+            int oy0, ox0;
+            origin(i, oy0, ox0);
+            const int iy0 = oy0 - a.pt, ix0 = ox0 - a.pl;
+            char* const in_t = smem + (i & 1) * TB;
+            unsigned col[J];
+            bool live[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int sl = j * 64 + lane;
+                const int px = (int)(((unsigned)sl * inv) >> 16), cc = sl - px * SG;
+                const int ix = ix0 + px;
+                col[j] = (ix >= 0 && ix < a.Win) ? (unsigned)(ix * a.nch0 + cc) * 16u : OOB;
+                live[j] = sl < ROW_SLOTS;
+            }
+            for (int py = pw; py < THH; py += 4) {
+                const int iy = iy0 + py;
+                const bool rowv = iy >= 0 && iy < a.Hin;
+                const unsigned rb = rowv ? (unsigned)iy * (unsigned)a.Win * (unsigned)(a.nch0 * 16) : OOB;
+                char* drow = in_t + py * a.row_pitch;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const unsigned o = (col[j] == OOB || !rowv) ? OOB : rb + col[j];
+                    if (live[j])
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)(drow + j * 1024), 16, o, 0, 0, 0);
+                }
+            }
+        };
+        if (n_my > 0) stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                    // tile 0 is in buffer 0
+        for (int ph = 0; ph <= n_my; ++ph) {
+            if (ph + 1 < n_my) stage(ph + 1);             // its buffer was read in phase ph - 1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+        return;
+    }
+    // =============================== CONSUMERS ===============================
+    const int team = wave >> 2, wv = wave & 3;            // the team's waves own two tile rows each
+    float4 biasr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) biasr[t] = *(const float4*)(a.bias + t * 16 + 4 * g);
+    int pixbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pixbase[m] = (wv * 2 + (m >> 1)) * a.row_pitch + ((m & 1) * 16 + p16) * PS2;
+    const char* const wb0 = w_t + lane * 16;
+    const char* const wb2 = p16 < 8 ? w_t + 2048 + (g * 8 + p16) * 16 : zero16 - 0;   // third cout tile: rows 8-15 do not exist
+    const int w2step = p16 < 8 ? WSTEP : 0;
+    const int* const tb = tab_l + g;
+    const int CsO = a.nch_out * 8;
+    constexpr unsigned OOBS = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, a.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(POOL ? a.pool_dst : a.dst), 0, POOL ? a.pool_bytes : 0u, 0x00020000);
+    f32x4 acc[MT][NT];
+    int eoy = 0, eox = 0;                                 // origin of the tile held in acc
+    lds_barrier();                                        // (pairs with the producers' "tile 0 is in buffer 0")
+    for (int ph = 0; ph <= n_my; ++ph) {
+        if ((ph & 1) == team) {
+            if (ph < n_my) {
+                // ---- k-loop of tile ph on buffer ph & 1 ----
+                origin(ph, eoy, eox);
+                const char* const in_t = smem + (ph & 1) * TB;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{biasr[n].x, biasr[n].y, biasr[n].z, biasr[n].w};
+                bf16x8 xa[MT], wa[NT], xb[MT], wbq[NT];
+#define PP_LOAD(XF, WF, S, OFF)                                                                  \
+                {                                                                                \
+                    const int s_ = (S) < ks ? (S) : ks - 1;                                      \
+                    WF[0] = *(const bf16x8*)(wb0 + s_ * WSTEP);                                  \
+                    _Pragma("unroll") for (int m = 0; m < MT; ++m)                               \
+                        XF[m] = *(const bf16x8*)(in_t + pixbase[m] + OFF);                       \
+                    WF[1] = *(const bf16x8*)(wb0 + s_ * WSTEP + 1024);                           \
+                    WF[2] = *(const bf16x8*)(wb2 + s_ * w2step);                                 \
+                }
+#define PP_TAB(S) tb[((S) < ks ? (S) : ks - 1) * 4]
+#define PP_MMA(XF, WF)                                                                           \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                   \
+                    _Pragma("unroll") for (int m = 0; m < MT; ++m)                               \
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[t], XF[m], acc[m][t], 0, 0, 0);
+#define PP_INTERLEAVE                                                                            \
+                _Pragma("unroll") for (int q_ = 0; q_ < MT * NT; ++q_) {                          \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                            \
+                }
+                int offa = PP_TAB(0), offb = PP_TAB(1);
+                PP_LOAD(xa, wa, 0, offa)
+                int s = 0;
+                for (; s + 2 <= ks; s += 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    offa = PP_TAB(s + 2);
+                    PP_LOAD(xb, wbq, s + 1, offb)
+                    PP_MMA(xa, wa)
+                    PP_INTERLEAVE
+                    __builtin_amdgcn_sched_barrier(0);
+                    offb = PP_TAB(s + 3);
+                    PP_LOAD(xa, wa, s + 2, offa)
+                    PP_MMA(xb, wbq)
+                    PP_INTERLEAVE
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks & 1) { PP_MMA(xa, wa) }
+#undef PP_INTERLEAVE
+#undef PP_TAB
+#undef PP_LOAD
+#undef PP_MMA
+            }
+        } else if (ph >= 1) {
+            // ---- epilogue of tile ph - 1 (accumulated by this team in the previous phase) ----
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+            unsigned pixoff[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int y = eoy + wv * 2 + (m >> 1), x = eox + (m & 1) * 16 + p16;
+                pixoff[m] = (y < a.Hout && x < a.Wout) ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) : OOBS;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = t * 16 + 4 * g;
+                const unsigned noff = n < CsO ? (unsigned)n * 2u : OOBS;
+                float v[MT][4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    v[m][0] = acc[m][t][0]; v[m][1] = acc[m][t][1]; v[m][2] = acc[m][t][2]; v[m][3] = acc[m][t][3];
+                    const unsigned o = (pixoff[m] == OOBS || noff == OOBS) ? OOBS : pixoff[m] + noff;
+                    if (a.relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[m][r] = vmax(v[m][r], 0.0f);
+                    }
+                    const uint2 pk = make_uint2(pk_bf16(v[m][0], v[m][1]), pk_bf16(v[m][2], v[m][3]));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
+                }
+                if (POOL) {
+                    const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {             // pairs (m, m + 2): rows 2r and 2r + 1 of this wave
+                        float q[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) q[r] = vmax_xor1(vmax(v[m][r], v[m + 2][r]));
+                        const int y = (eoy >> 1) + wv;
+                        const int x = (eox >> 1) + ((m * 16 + p16) >> 1);
+                        const bool ok = !(p16 & 1) && y < Ho2 && x < Wo2 && noff != OOBS;
+                        const unsigned o = ok ? (unsigned)(y * Wo2 + x) * (unsigned)(CsO * 2) + noff : OOBS;
+                        const uint2 pk = make_uint2(pk_bf16(q[0], q[1]), pk_bf16(q[2], q[3]));
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rp, o, 0, 0);
+                    }
+                }
+            }
+        }
+        lds_barrier();
+    }
+}
+
 // =============================================================================================
 // host side: plans, packing, launches
 // =============================================================================================
@@ -3451,6 +3672,36 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     // mostly hidden by the co-resident workgroup); needs the per-trip opaque lane ids to keep two waves per SIMD.
     // wave-specialised persistent kernel (conv12_ws_kernel): one 512-thread workgroup per CU, two input tiles + the resident
     // weights in LDS.  PSEG_NO_WS=1 falls back to the every-wave-does-everything fused instance below.
+    // ping-pong persistent kernel (conv_pp_kernel) for the k5 mid layers whose weights fit LDS beside two tiles: conv3, conv4
+    if (P->wg3 && P->KS == 5 && P->NT == 3 && P->MT == 4 && P->NW == 4 && P->nblk == 1 && P->nblocks_n == 1 && op.Cout <= 40 && !op.transposed &&
+        op.src1 < 0 && !a.add && !a.in_relu && !a.up0 && op.fuse1 < 0 && op.tail_logits < 0 && op.skiplog < 0 && op.relu_dst < 0 &&
+        (a.sigma == 4 || a.sigma == 5) && a.sigma == P->nc_full && !a.trace && !PSEG_KNOB("PSEG_NO_PP") && !PSEG_KNOB("PSEG_GENERIC")) {
+        static int cus_pp = 0;
+        int dev = 0;
+        PSEG_HIP(hipGetDevice(&dev));
+        if (!cus_pp) PSEG_HIP(hipDeviceGetAttribute(&cus_pp, hipDeviceAttributeMultiprocessorCount, dev));
+        const int TB = round_up(P->THH * P->row_pitch, 16);
+        const int lds = 2 * TB + P->ks_full * 2560 + 16 + round_up(P->ks_full * 16, 16);
+        if (lds <= 160 * 1024 && (int)grid.x >= 2 * cus_pp) {
+            MConv w = a;
+            w.lds_w_off = TB;
+            w.ntiles = (int)grid.x;
+            const dim3 gp((unsigned)cus_pp);
+#define PSEG_PP(SG_, POOL_)                                                                                       \
+            if (a.sigma == SG_ && (a.pool_dst != nullptr) == POOL_) {                                             \
+                static bool attr_set[64] = {false};                                                               \
+                if (!attr_set[dev & 63]) {                                                                        \
+                    PSEG_HIP(hipFuncSetAttribute((const void*)conv_pp_kernel<SG_, POOL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                    attr_set[dev & 63] = true;                                                                    \
+                }                                                                                                 \
+                conv_pp_kernel<SG_, POOL_><<<gp, 768, lds, st>>>(w);                                              \
+                PSEG_HIP(hipGetLastError());                                                                      \
+                return PSEG_OK;                                                                                   \
+            }
+            PSEG_PP(4, false) PSEG_PP(4, true) PSEG_PP(5, false) PSEG_PP(5, true)
+#undef PSEG_PP
+        }
+    }
     if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && P->MT == 8 && P->NT == 2 && P->KS == 5 && a.sigma == 3 &&
         a.pool_dst && !a.add && !a.in_relu && !a.relu && !PSEG_KNOB("PSEG_NO_WS") && !PSEG_KNOB("PSEG_NO_PERSIST") && !PSEG_KNOB("PSEG_GENERIC") && !a.trace) {
         const bool ws_trace = PSEG_KNOB("PSEG_WS_TRACE") != nullptr;   // developer aid: per-wave phase cycles -> gpurun_out/ws_trace.bin

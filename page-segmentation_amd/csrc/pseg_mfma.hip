@@ -2418,7 +2418,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const int sl = j * 64 + lane;
                 const int px = (int)(((unsigned)sl * inv) >> 16), cc = sl - px * SG;
                 const int ix = ix0 + px;
-                col[j] = (ix >= 0 && ix < a.Win) ? (unsigned)(ix * a.nch0 + cc) * 16u : OOB;
+                col[j] = (ix >= 0 && ix < a.Win && cc < a.nc_full) ? (unsigned)(ix * a.nch0 + cc) * 16u : OOB;   // (pad slot of a pixel: zeros)
                 live[j] = sl < ROW_SLOTS;
             }
             for (int py = pw; py < THH; py += 4) {
@@ -2438,7 +2438,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();                                    // tile 0 is in buffer 0
         for (int ph = 0; ph <= n_my; ++ph) {
-            if (ph + 1 < n_my) stage(ph + 1);             // its buffer was read in phase ph - 1
+            if (ph + 1 < n_my && !((a.dbg & 0x800) && ph >= 1)) stage(ph + 1);   // its buffer was read in phase ph - 1   (0x800: timing experiment, wrong results)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
         }
@@ -2494,6 +2494,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
                     __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                            \
                 }
+                if (a.dbg & 0x400) __builtin_amdgcn_s_setprio(3);      // PSEG_PP_PRIO=1
                 int offa = PP_TAB(0), offb = PP_TAB(1);
                 PP_LOAD(xa, wa, 0, offa)
                 int s = 0;
@@ -2511,13 +2512,14 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks & 1) { PP_MMA(xa, wa) }
+                if (a.dbg & 0x400) __builtin_amdgcn_s_setprio(0);
 #undef PP_INTERLEAVE
 #undef PP_TAB
 #undef PP_LOAD
 #undef PP_MMA
             }
-        } else if (ph >= 1) {
-            // ---- epilogue of tile ph - 1 (accumulated by this team in the previous phase) ----
+        } else if (ph >= 1 && !(a.dbg & 0x1000)) {
+            // ---- epilogue of tile ph - 1 (accumulated by this team in the previous phase) ----   (0x1000: timing experiment)
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
             unsigned pixoff[MT];
 #pragma unroll
@@ -2569,6 +2571,7 @@ enum PlanKind { PLAN_GENERIC = 0, PLAN_CONV1 = 1, PLAN_LOGITS = 2, PLAN_UPSPLIT 
 
 struct MfmaPlan {
     int kind = PLAN_GENERIC;
+    bool pp = false;          // eligible for the persistent ping-pong kernel (conv_pp_kernel) when the page has enough tiles
     int MT = 4, NT = 2, KS = 1, stride = 1, NW = 4;
     int nblk = 1, nc_full = 1, nc_last = 1, ks_full = 1, ks_last = 1;
     int PS2 = 0, row_pitch = 0, THH = 0, TWH = 0, GK = 4, NB = 3, G = 1, lds_w_off = 0, lds_tab_off = 0, lds_bytes = 0;
@@ -3084,6 +3087,10 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
                  !PSEG_KNOB("PSEG_GENERIC") && !PSEG_KNOB("PSEG_NO_WG3");
         // (stride 2: always the dense tile -- its columns are de-interleaved by parity at staging time, which makes the fragment
         // reads those of a stride-1 layer, and the 4.3 input pixels per output pixel are the layer's LDS and DMA bill)
+        // conv_pp_kernel (conv3 / conv4: resident weights, two tile buffers).  (A 64-byte pixel pitch -- conv3's four chunks -- cannot be
+        // read without 2-way bank conflicts: the eight lanes of a 16-lane read group that share a chunk cover four distinct 16-byte
+        // windows.  An 80-byte pitch removes them and was measured in this kernel: 52.1 vs 52.0 us, so the dense tile stays.)
+        P->pp = P->wg3 && KS == 5 && NT == 3 && P->nblocks_n == 1 && op.Cout <= 40 && !op.transposed && op.src1 < 0 && !PSEG_KNOB("PSEG_NO_PP");
         if (P->wg3 || (deint && P->nc_full >= 2) || (!PSEG_KNOB("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16))) {
             sigma = P->nc_full;
             int best_cyc = 1 << 30;
@@ -3675,7 +3682,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     // ping-pong persistent kernel (conv_pp_kernel) for the k5 mid layers whose weights fit LDS beside two tiles: conv3, conv4
     if (P->wg3 && P->KS == 5 && P->NT == 3 && P->MT == 4 && P->NW == 4 && P->nblk == 1 && P->nblocks_n == 1 && op.Cout <= 40 && !op.transposed &&
         op.src1 < 0 && !a.add && !a.in_relu && !a.up0 && op.fuse1 < 0 && op.tail_logits < 0 && op.skiplog < 0 && op.relu_dst < 0 &&
-        (a.sigma == 4 || a.sigma == 5) && a.sigma == P->nc_full && !a.trace && !PSEG_KNOB("PSEG_NO_PP") && !PSEG_KNOB("PSEG_GENERIC")) {
+        P->pp && (a.sigma == 4 || a.sigma == 5) && !a.trace && !PSEG_KNOB("PSEG_NO_PP") && !PSEG_KNOB("PSEG_GENERIC")) {
         static int cus_pp = 0;
         int dev = 0;
         PSEG_HIP(hipGetDevice(&dev));
@@ -3686,6 +3693,9 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
             MConv w = a;
             w.lds_w_off = TB;
             w.ntiles = (int)grid.x;
+            if (PSEG_KNOB("PSEG_PP_PRIO")) w.dbg |= 0x400;
+            if (PSEG_KNOB("PSEG_PP_NODMA")) w.dbg |= 0x800;
+            if (PSEG_KNOB("PSEG_PP_NOEPI")) w.dbg |= 0x1000;
             const dim3 gp((unsigned)cus_pp);
 #define PSEG_PP(SG_, POOL_)                                                                                       \
             if (a.sigma == SG_ && (a.pool_dst != nullptr) == POOL_) {                                             \

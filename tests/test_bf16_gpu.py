@@ -331,3 +331,26 @@ def test_bf16_res_unet_plan_variants_are_bit_identical(gpu, oracle_mod, monkeypa
         e1.close()
     z_o = oracle_mod.forward("res_unet", Wt, img, "f32")
     assert np.abs(z0 - z_o).max() <= 0.03 * max(1.0, np.abs(z_o).max())
+
+
+@pytest.mark.parametrize("arch,shape", [("fcn_skip", (1024, 768)), ("fcn_skip", (1100, 1300)), ("fcn", (1056, 1000))])
+def test_bf16_ping_pong_mid_layer_kernel_is_bit_identical(gpu, monkeypatch, arch, shape):
+    """conv_pp_kernel (conv3 / conv4 on pages with >= 2 tiles per CU: resident weights, producer waves, two consumer teams
+    alternating k-loop and epilogue) against the three-workgroup instances of conv_mfma_kernel (PSEG_NO_PP): same packing,
+    same k order, same start value -- the same bits, also in the tensors the two layers write."""
+    from pseg_amd import synth
+    img = synth.synth_page(5, shape[0], shape[1], 3)[0]
+    res = []
+    for knob in (None, "PSEG_NO_PP"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        e = gpu.Engine(arch, 3, mode=gpu.MODE_BF16)
+        e.set_weights(synth.glorot_weights(e.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+        z, _, l = e.predict(img, want_probs=False)
+        res.append((z, l, e.activation("conv2d_2"), e.activation("max_pooling2d_1")))
+        e.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    assert np.abs(res[0][2]).max() > 0

@@ -408,6 +408,7 @@ def run_rank(args):
             for key, fn in (("host_path", lambda: leg_host_path(np, pseg_amd, eng, synth, H, W, C)),
                             ("label_exact", lambda: leg_label_exact(torch, np, pseg_amd, eng, pages[0], H, W, dev, synth, C, args.arch)),
                             ("unet", lambda: leg_arch(torch, pseg_amd, synth, "unet", H, W, C, dev)),
+                            ("res_unet", lambda: leg_arch(torch, pseg_amd, synth, "res_unet", H, W, C, dev)),
                             ("config5", lambda: leg_config5(torch, np, pseg_amd, synth, dev))):
                 try:
                     extra[key] = fn()

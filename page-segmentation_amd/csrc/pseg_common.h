@@ -200,6 +200,7 @@ struct ConvArgs {
     int dst_pitch;       // pixels per output row (0: Wout) -- crop / canvas-pitched outputs
     int out_sy, out_sx, out_oy, out_ox;   // MFMA kernel only: output pixel (y*sy + oy, x*sx + ox); 0 strides = 1
     int deconv4;         // MFMA kernel only: Conv2DTranspose k2 s2 as one GEMM, n = ab*Cout + co -> (2y + a, 2x + b)
+    int dbg;             // MFMA kernel only: timing experiments (PSEG_XM_DBG: 1 no staging loads, 2 no stores, 4 no k-loop) -- wrong results
     int relaxed;         // MFMA kernel only: the caller accepts a channel-blocked summation order (train step) for layers whose all-channel tile does not fit LDS
 };
 int launch_conv_exact(const ConvArgs& a, hipStream_t st);

@@ -69,25 +69,32 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
     // value looked at right behind its load (ReLU, mask, the store itself) costs a full memory latency per item, and a
     // wave has ~110 of them per tile -- that chain, not the MFMAs, was most of this kernel's time on the thin layers.
     constexpr int FJ = 16;                               // 64-float pieces of a tile row in flight per wave
-    if (!a.src1 && !a.up0 && cn == Cin && Cin < 64) {
-        // Thin single-source layers (fewer than 64 channels: every full- and half-resolution layer of the fcn graphs and
-        // their data gradients): a tile row is ONE contiguous run of TWH * Cin floats in memory -- lanes over that run
-        // (all 64 busy instead of Cin of them), sixteen pieces requested before the first is used.
-        const int rowf = TWH * Cin, nj = (rowf + 63) >> 6;
-        const unsigned invc = (1u << 20) / (unsigned)Cin + 1u;   // e < 36 * 64 (stride 1) ... 2 * 67 * 64: e * invc < 2^32
+    if (a.dbg & 1) {
+        for (int i = tid; i < npx * Cp; i += 256) xt[i] = 0.0f;
+    } else if (!a.up0 && !a.up1 && cn == Cin && a.C0 < 64 && a.C1 < 64) {
+        // Thin layers (every source under 64 channels: all of fcn / fcn_skip and their data gradients): a tile row is ONE
+        // contiguous run of TWH * C floats per source tensor -- lanes over that run (all 64 busy instead of C of them),
+        // sixteen pieces requested before the first is used; a Concatenate is two such runs side by side in the LDS pixel.
+        // (The lanes-over-channels path below spent 0.85 of deconv5's 1.19 ms on its two-source tile: 0.26 TB/s.)
+        for (int srcsel = 0; srcsel < (a.src1 ? 2 : 1); ++srcsel) {
+        const int C = srcsel ? a.C1 : a.C0, cbase = srcsel ? a.C0 : 0;
+        const float* const sbase = srcsel ? a.src1 : a.src0;
+        const float* const mbase = srcsel ? nullptr : a.mask;
+        const int rowf = TWH * C, nj = (rowf + 63) >> 6;
+        const unsigned invc = (1u << 20) / (unsigned)C + 1u;     // e < 67 * 64: e * invc < 2^32
         int dj0[FJ];                                     // the first sixteen pieces' (pixel, LDS offset), the same for every row
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
             const int e = j * 64 + lane;
-            const int px = (int)(((unsigned)e * invc) >> 20), c = e - px * Cin;
-            dj0[j] = e < rowf ? (px << 16 | (px * Cp + c)) : -1;
+            const int px = (int)(((unsigned)e * invc) >> 20), c = e - px * C;
+            dj0[j] = e < rowf ? (px << 16 | (px * Cp + cbase + c)) : -1;
         }
         for (int r = wave; r < THH; r += 4) {
             const int iy = iy0 + r;
             const bool rowok = iy >= 0 && iy < a.Hin;
-            const size_t ro = ((size_t)(rowok ? iy : 0) * a.Win) * a.C0;
-            const float* srow = a.src0 + ro + (ptrdiff_t)ix0 * a.C0;       // (lanes left of the image are masked below)
-            const float* mrow = a.mask ? a.mask + ro + (ptrdiff_t)ix0 * a.C0 : nullptr;
+            const size_t ro = ((size_t)(rowok ? iy : 0) * a.Win) * C;
+            const float* srow = sbase + ro + (ptrdiff_t)ix0 * C;           // (lanes left of the image are masked below)
+            const float* mrow = mbase ? mbase + ro + (ptrdiff_t)ix0 * C : nullptr;
             float* drow = xt + (size_t)r * TWH * Cp;
             for (int j0 = 0; j0 < nj; j0 += FJ) {
                 float v[FJ], mv[FJ];
@@ -97,8 +104,8 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
                     const int e = (j0 + j) * 64 + lane;
                     int pk = dj0[j];
                     if (j0) {
-                        const int px_ = (int)(((unsigned)e * invc) >> 20), c = e - px_ * Cin;
-                        pk = e < rowf ? (px_ << 16 | (px_ * Cp + c)) : -1;
+                        const int px_ = (int)(((unsigned)e * invc) >> 20), c = e - px_ * C;
+                        pk = e < rowf ? (px_ << 16 | (px_ * Cp + cbase + c)) : -1;
                     }
                     const int px = pk >> 16;
                     dj[j] = pk < 0 ? -1 : (pk & 0xFFFF);
@@ -117,6 +124,7 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
                     if (dj[j] >= 0) drow[dj[j]] = x;
                 }
             }
+        }
         }
         // the channel pad of every pixel (k-steps run over 4 * ceil(Cin / 4) channels)
         for (int i = tid; i < npx * (Cp - Cin); i += 256) {
@@ -188,7 +196,8 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                               \
         _Pragma("unroll") for (int m = 0; m < MT; ++m)                                           \
             acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(WF[t], XF[m], acc[m][t], 0, 0, 0);
-    if constexpr (!FLAT) {
+    if (a.dbg & 4) {
+    } else if constexpr (!FLAT) {
         const int nks = (cn + 3) >> 2;         // k-steps per tap
         for (int ky = 0; ky < a.KH; ++ky)
             for (int kx = 0; kx < a.KW; ++kx) {
@@ -254,29 +263,61 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
     }   // channel blocks
 #undef PSEG_XMMA
 
-    // ---- epilogue: acc + bias (+ add), ReLU; lane owns n = 4g..4g+3 of pixel p16 in every tile
+    // ---- epilogue: acc + bias (+ add), ReLU; lane owns n = 4g..4g+3 of pixel p16 in every tile.  The lane's four values are
+    // consecutive output channels of one pixel (of one sub-pixel, for the transposed GEMM: Cout % 4 == 0 keeps a quad inside
+    // its sub-pixel): one 16-byte (or two 8-byte, Cout even) store instead of four 4-byte ones -- Conv2DTranspose k2 s2 at full
+    // resolution (deconv5: 252 MB of output) spent 1.28 ms in scalar scatter stores.
     const int osy = a.out_sy ? a.out_sy : 1, osx = a.out_sx ? a.out_sx : 1;
     const int pitch = a.dst_pitch ? a.dst_pitch : a.Wout;
+    const int vecw = (a.Cout & 3) == 0 ? 4 : ((a.Cout & 1) == 0 ? 2 : 1);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int y = oy0 + wave * RW + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
-        if (y >= a.Hout || x >= a.Wout) continue;
+        if (y >= a.Hout || x >= a.Wout || ((a.dbg & 2) && acc[m][0][0] != 123.456f)) continue;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            const int n0 = co_base + t * 16 + 4 * g;
+            if (n0 >= Ntot) continue;
+            float v[4];
+            size_t off[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = co_base + t * 16 + 4 * g + r;
-                if (n < Ntot) {
-                    const int ab = a.deconv4 ? n / a.Cout : 0;
-                    const int co = n - ab * a.Cout;
-                    const size_t opix = a.deconv4 ? (size_t)(2 * y + (ab >> 1)) * pitch + (size_t)(2 * x + (ab & 1))
-                                                  : (size_t)(y * osy + a.out_oy) * pitch + (size_t)(x * osx + a.out_ox);
-                    float v = a.bias ? acc[m][t][r] + a.bias[co] : acc[m][t][r];
-                    if (a.add) v = v + a.add[opix * a.Cout + co];
-                    if (a.relu) v = v > 0.0f ? v : 0.0f;
-                    a.dst[opix * a.Cout + co] = v;
+                const int n = n0 + r;
+                const int nn = n < Ntot ? n : n0;                 // (values past the layer are never stored)
+                const int ab = a.deconv4 ? nn / a.Cout : 0;
+                const int co = nn - ab * a.Cout;
+                const size_t opix = a.deconv4 ? (size_t)(2 * y + (ab >> 1)) * pitch + (size_t)(2 * x + (ab & 1))
+                                              : (size_t)(y * osy + a.out_oy) * pitch + (size_t)(x * osx + a.out_ox);
+                off[r] = opix * a.Cout + co;
+                v[r] = a.bias ? acc[m][t][r] + a.bias[co] : acc[m][t][r];
+            }
+            if (a.add) {
+                if (vecw == 4 && n0 + 3 < Ntot) {
+                    const float4 ad = *(const float4*)(a.add + off[0]);
+                    v[0] = v[0] + ad.x; v[1] = v[1] + ad.y; v[2] = v[2] + ad.z; v[3] = v[3] + ad.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < Ntot) v[r] = v[r] + a.add[off[r]];
                 }
             }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+            }
+            if (vecw == 4 && n0 + 3 < Ntot) {
+                *(float4*)(a.dst + off[0]) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (vecw >= 2) {
+                if (n0 + 1 < Ntot) *(float2*)(a.dst + off[0]) = make_float2(v[0], v[1]);
+                else a.dst[off[0]] = v[0];
+                if (n0 + 3 < Ntot) *(float2*)(a.dst + off[2]) = make_float2(v[2], v[3]);
+                else if (n0 + 2 < Ntot) a.dst[off[2]] = v[2];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < Ntot) a.dst[off[r]] = v[r];
+            }
+        }
     }
 }
 
@@ -296,8 +337,10 @@ static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, int CB, dim3 g
 
 // Returns 1 when the layer was launched on the MFMA kernel, 0 when it does not fit (caller falls
 // back to the scalar kernel), < 0 on error.
-int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st) {
+int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     if (PSEG_KNOB("PSEG_EXACT_SCALAR")) return 0;
+    ConvArgs a = a_in;
+    if (const char* dv = PSEG_KNOB("PSEG_XM_DBG")) a.dbg = atoi(dv);
     const int Cin = a.C0 + a.C1;
     if (Cin < 1 || a.Cout < 1 || a.KH != a.KW) return 0;
     const int Ntot = a.deconv4 ? 4 * a.Cout : a.Cout;

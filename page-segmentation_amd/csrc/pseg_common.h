@@ -109,6 +109,7 @@ struct Op {
     bool fused_away = false;  // bf16 mode: op folded into a neighbour (pool -> conv epilogue, logits -> deconv tail)
     int fuse1 = -1;           // bf16 mode: OP_CONV that recomputes this first-layer op on its halo tile
     int tail_logits = -1;     // bf16 mode: OP_DECONV2 that also runs this OP_LOGITS (fused tail)
+    int dq_fuse = -1;         // bf16 mode: OP_CONV (k5, 80 couts) whose epilogue also runs this later OP_DECONV2 (k2 s2) on its accumulators; the deconv is fused_away
     int into_tail = -1;       // bf16 mode: OP_DECONV2 (ReLU) computed inside the composed-tail kernel of this later OP_DECONV2 (fused_away)
     bool pool_only = false;   // bf16 mode: the full-resolution output is read by nothing but the fused pool: it is not stored
     int skiplog = -1;         // bf16 mode: conv whose output only feeds (a fused pool and) this OP_LOGITS as the skip: it stores

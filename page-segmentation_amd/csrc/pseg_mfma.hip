@@ -82,6 +82,8 @@ struct MConv {
     int PS2, row_pitch, THH, TWH, GK, NB, G, lds_w_off, lds_tab_off;
     // output
     uint16_t* dst;
+    // FL_DQ: Conv2DTranspose k2 s2 fused behind this conv (its accumulators are the deconv's B operands)
+    const uint16_t* dq_w; const float* dq_bias; uint16_t* dq_dst; unsigned dq_bytes; int dq_nch, dq_relu;
     uint16_t* dst2;       // second copy of the output stored as max(x, 0) (res_unet: read by the next block's pre-activation conv), or null
     int nch_out;
     uint16_t* pool_dst;
@@ -215,7 +217,7 @@ constexpr int STAGE_SLOTS = 12;  // 16-byte loads a lane keeps in flight while s
 // "read it from the argument block" (generic fallback).  With ~50 runtime geometry fields the
 // compiler hoists and spills scalars by the hundred; with constants the prologue collapses.
 enum { MODE_CONV = 0, MODE_DECONV = 1, MODE_TAIL = 2 };
-enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16, FL_FUSE1 = 32, FL_PERSIST = 64, FL_LOGITS = 128, FL_SKIPLOG = 256 };
+enum { FL_POOL = 1, FL_ADD = 2, FL_INRELU = 4, FL_UP0 = 8, FL_UP1 = 16, FL_FUSE1 = 32, FL_PERSIST = 64, FL_LOGITS = 128, FL_SKIPLOG = 256, FL_DQ = 512 };
 #ifndef PSEG_DIAG
 #define PSEG_DIAG 0   // 1: compile the in-kernel trace stamps / ablation switches (diagnostic builds)
 #endif
@@ -899,6 +901,82 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
         break;
     }
 
+    if constexpr (FIXED && (FL_ & FL_DQ) != 0) {
+        // Conv2DTranspose k2 s2 (ReLU) behind this conv, on its accumulators: a 16x16 accumulator tile has the pixel on the
+        // lane and four channels in registers, so two tiles are one B operand (k x pixel) of the next MFMA -- the conv's 80
+        // output channels (bias was the start value; ReLU, bf16 rounding here) are three k-steps, the third half empty.  Per
+        // sub-pixel ab: D2[cout][pixel] = bias2 + W2[ab] . d1(pixel), ReLU, bf16, stored at (2y + ab / 2, 2x + ab % 2).
+        // The 1/8-resolution tensor never exists in memory and the transposed conv's own launch is gone.
+        static_assert(!(FL_ & FL_DQ) || (NT == 5 && MT == 4), "the fused transposed conv is written for 80 channels on 8 x 32 tiles");
+        uint4 bq[MT][3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            uint32_t pk[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                pk[t][0] = pk_bf16(acc[m][t][0], acc[m][t][1]);
+                pk[t][1] = pk_bf16(acc[m][t][2], acc[m][t][3]);
+                if (a.relu) { pk[t][0] = relu_pk_bf16(pk[t][0], 0u); pk[t][1] = relu_pk_bf16(pk[t][1], 0u); }
+            }
+            bq[m][0] = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+            bq[m][1] = make_uint4(pk[2][0], pk[2][1], pk[3][0], pk[3][1]);
+            bq[m][2] = make_uint4(pk[4 % NT][0], pk[4 % NT][1], 0u, 0u);
+        }
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)a.dq_dst, 0, a.dq_bytes, 0x00020000);
+        const int Cs2 = a.dq_nch * 8, W2 = 2 * a.Wout;
+        constexpr unsigned OOBQ = 0xfffffff0u;
+        unsigned pxo[MT];     // byte offset of the (2y, 2x) output pixel of this lane's conv pixel, or OOB
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int y = oy0 + wave * (MT / 2) + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+            pxo[m] = (y < a.Hout && x < a.Wout) ? (unsigned)((2 * y) * W2 + 2 * x) * (unsigned)(Cs2 * 2) : OOBQ;
+        }
+        // eight groups (sub-pixel ab, pair of cout tiles th): the six A fragments of group q + 1 are requested before group q is
+        // multiplied (they come from L2: 48 KB shared by every workgroup)
+        bf16x8 wf[2][2][3];
+        auto fetch_w = [&](int q, bf16x8 (&w)[2][3]) {
+            const int ab = q >> 1, th = q & 1;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3)
+                    w[tt][s3] = *(const bf16x8*)(a.dq_w + ((size_t)((ab * 4 + 2 * th + tt) * 3 + s3) * 64 + lane) * 8);
+        };
+        float4 b2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b2[t] = *(const float4*)(a.dq_bias + t * 16 + 4 * g);
+        fetch_w(0, wf[0]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ab = q >> 1, th = q & 1;
+            if (q + 1 < 8) fetch_w(q + 1, wf[(q + 1) & 1]);
+            const unsigned abo = (unsigned)((ab >> 1) * W2 + (ab & 1)) * (unsigned)(Cs2 * 2);
+            f32x4 z[MT][2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) z[m][tt] = f32x4{b2[2 * th + tt].x, b2[2 * th + tt].y, b2[2 * th + tt].z, b2[2 * th + tt].w};
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        z[m][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q & 1][tt][s3], __builtin_bit_cast(bf16x8, bq[m][s3]), z[m][tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int n = (2 * th + tt) * 16 + 4 * g;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    uint2 pk = make_uint2(pk_bf16(z[m][tt][0], z[m][tt][1]), pk_bf16(z[m][tt][2], z[m][tt][3]));
+                    if (a.dq_relu) pk = make_uint2(relu_pk_bf16(pk.x, 0u), relu_pk_bf16(pk.y, 0u));
+                    const unsigned o = (pxo[m] == OOBQ || n >= Cs2) ? OOBQ : pxo[m] + abo + (unsigned)n * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rq, o, 0, 0);
+                }
+            }
+        }
+        break;
+    }
     // Direct stores: lane (p16, g) owns couts 4g..4g+3 of pixel p16 in every 16x16 tile, i.e.
     // 8 contiguous bytes of the NHWC row; the cout tiles / four g of a pixel complete its line
     // across consecutive store instructions.  Bounds are enforced by the buffer descriptors (an
@@ -2599,6 +2677,8 @@ struct MfmaPlan {
     bool nw8_ok = false;        // an 8-wave kernel instance exists for this layer shape
     bool nw8_resident = false;  // ... and its whole weight set stays resident beside the 16-row tile
     int cmax = 4;
+    uint16_t* d_dq_w = nullptr;    // deconv fused behind a conv (Op::dq_fuse): A fragments [ab][cout tile 4][k-step 3][64][8], bias[64]
+    float* d_dq_bias = nullptr;
     uint16_t* d_q_w = nullptr;     // into_tail deconv: A fragments [ab][2][4][64][8] and bias[32] for tail_fused2_kernel
     float* d_q_bias = nullptr;
     uint16_t* d_t2_wD = nullptr;   // composed tail with the inner deconv: composed kernel fragments
@@ -2620,6 +2700,7 @@ void mfma_free_op(Op& op) {
     (void)hipFree(p->d_tc_wA1); (void)hipFree(p->d_tc_wA2); (void)hipFree(p->d_tc_beta);
     upsplit_free(p->upsplit);
     (void)hipFree(p->d_skiplog);
+    (void)hipFree(p->d_dq_w); (void)hipFree(p->d_dq_bias);
     (void)hipFree(p->d_q_w); (void)hipFree(p->d_q_bias); (void)hipFree(p->d_t2_wD); (void)hipFree(p->d_t2_wC);
     delete p;
     op.plan = nullptr;
@@ -2758,6 +2839,25 @@ int mfma_plan_graph(Engine& e) {
             c2.fuse1 = (int)ci;
             c1.fused_away = true;
             e.tensors[c1.dst].fused = true;
+        }
+    // Conv2DTranspose k2 s2 behind a k5 conv whose 80-channel output nothing else reads (fcn / fcn_skip: deconv1 -> deconv2, 1/8
+    // -> 1/4 resolution): the transposed conv is pointwise in the conv's output pixels, so it runs on the conv's accumulators in
+    // its epilogue (FL_DQ) -- one launch less, the 1/8-resolution tensor is neither written nor read
+    if (!PSEG_KNOB("PSEG_NO_DQ") && !PSEG_KNOB("PSEG_GENERIC"))
+        for (size_t di = 0; di < e.ops.size(); ++di) {
+            Op& dq = e.ops[di];
+            if (dq.type != OP_DECONV2 || dq.src1 >= 0 || dq.tail_logits >= 0 || dq.into_tail >= 0 || dq.fused_away || dq.Cout > 64) continue;
+            const int pi = producer_of(e, dq.src0);
+            if (pi < 0) continue;
+            Op& pc = e.ops[pi];
+            if (pc.type != OP_CONV || pc.k != 5 || pc.stride != 1 || pc.Cout != 80 || !pc.relu || pc.add >= 0 || pc.in_relu || pc.up0 || pc.up1 ||
+                pc.pool_dst >= 0 || pc.fuse1 >= 0 || pc.tail_logits >= 0 || pc.skiplog >= 0 || pc.relu_dst >= 0) continue;
+            int users = 0;
+            for (auto& o : e.ops) users += (o.src0 == pc.dst) + (o.src1 == pc.dst) + (o.add == pc.dst);
+            if (users != 1) continue;
+            pc.dq_fuse = (int)di;
+            dq.fused_away = true;
+            e.tensors[pc.dst].fused = true;
         }
     for (auto& op : e.ops) {
         if (op.type != OP_POOL) continue;
@@ -3242,6 +3342,32 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         PSEG_TRY(upload(&P->d_q_w, wq));
         PSEG_TRY(upload(&P->d_q_bias, bq));
     }
+    if (deconv) {
+        bool fused_behind_conv = false;
+        for (auto& o : e.ops) fused_behind_conv |= o.dq_fuse == (int)(&op - e.ops.data());
+        if (fused_behind_conv) {
+            // this transposed conv runs in the epilogue of the conv that produces its input: the B operand of k-step s is built
+            // from that conv's accumulator tiles 2s and 2s + 1 -- lane (pixel, g) holds channels 16 (2s) + 4g .. + 3 in elements
+            // 0-3 and 16 (2s + 1) + 4g .. + 3 in elements 4-7 -- so A fragment (ab, cout tile t, s): lane (cout 16t + l % 16,
+            // g = l / 16), element j <-> input channel 16 (2s + j / 4) + 4g + j % 4
+            std::vector<uint16_t> wq((size_t)4 * 4 * 3 * 64 * 8, 0);
+            for (int ab = 0; ab < 4; ++ab)
+                for (int t = 0; t < 4; ++t)
+                    for (int sidx = 0; sidx < 3; ++sidx)
+                        for (int l = 0; l < 64; ++l) {
+                            const int co = t * 16 + (l & 15), gg = l >> 4;
+                            if (co >= Cout) continue;
+                            for (int j = 0; j < 8; ++j) {
+                                const int ci = 16 * (2 * sidx + (j >> 2)) + 4 * gg + (j & 3);
+                                if (ci < Cin) wq[((((size_t)ab * 4 + t) * 3 + sidx) * 64 + l) * 8 + j] = f2bf(w[((size_t)ab * Cin + ci) * Cout + co]);
+                            }
+                        }
+            std::vector<float> bq(64, 0.0f);
+            for (int c = 0; c < Cout; ++c) bq[c] = bias[c];
+            PSEG_TRY(upload(&P->d_dq_w, wq));
+            PSEG_TRY(upload(&P->d_dq_bias, bq));
+        }
+    }
     if (!deconv && op.skiplog >= 0) {
         // skip-logits fusion: the logits kernel rows of this layer's channels (they follow the deconv channels in the
         // concat, Keras (1,1,Cdec+Cout,C): w[(Cdec + co)*C + c]) as ONE A fragment: lane l = (class = l & 15, g = l >> 4),
@@ -3413,7 +3539,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     const int mode = a.tail ? MODE_TAIL : (a.deconv ? MODE_DECONV : MODE_CONV);
     const int fl = (a.pool_dst ? FL_POOL : 0) | (a.add ? FL_ADD : 0) | (a.in_relu ? FL_INRELU : 0) |
                    (a.up0 ? FL_UP0 : 0) | (a.up1 ? FL_UP1 : 0) | (a.f1_img ? FL_FUSE1 : 0) | (a.ntiles > 0 ? FL_PERSIST : 0) |
-                   ((!a.deconv && a.tail_wa && !a.skip_logits) ? FL_LOGITS : 0) | (a.skip_logits ? FL_SKIPLOG : 0);
+                   ((!a.deconv && a.tail_wa && !a.skip_logits) ? FL_LOGITS : 0) | (a.skip_logits ? FL_SKIPLOG : 0) | (a.dq_w ? FL_DQ : 0);
     const int sg = a.sigma, st_ = a.stride, ks = P.KS;
     if (a.f1_img && !(P.MT == 8 && P.NT == 2 && ks == 5 && sg == 3 && mode == MODE_CONV && (fl & ~(FL_PERSIST | FL_SKIPLOG)) == (FL_POOL | FL_FUSE1)))
         return fail(PSEG_EUNSUPPORTED, "first-layer fusion has no kernel instance for this shape");
@@ -3452,6 +3578,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, 0)            // conv5
     PSEG_TRY_INST(4, 4, 5, 1, 6, MODE_CONV, FL_POOL)      // conv6
     PSEG_TRY_INST(4, 5, 5, 1, 6, MODE_CONV, 0)            // conv7, deconv1
+    PSEG_TRY_INST(4, 5, 5, 1, 6, MODE_CONV, FL_DQ)        // deconv1 + deconv2 (k2 s2) on its accumulators
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, 0)            // unet: k3 convs (64..1024 channels, 32-channel blocks)
     PSEG_TRY_INST(4, 4, 3, 1, 6, MODE_CONV, FL_POOL)      // unet: k3 conv + fused pool
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, 0)            // unet: dense tile, three workgroups per CU
@@ -3470,6 +3597,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     PSEG_TRY_INST(4, 4, 3, 1, 4, MODE_CONV, FL_INRELU | FL_ADD | FL_LOGITS)   // res_unet: last block + logits + argmax
     if (fl & FL_LOGITS) return fail(PSEG_EUNSUPPORTED, "conv + logits fusion has no kernel instance for this shape");
     if (fl & FL_SKIPLOG) return fail(PSEG_EUNSUPPORTED, "skip-logits fusion has no kernel instance for this shape");
+    if (fl & FL_DQ) return fail(PSEG_EUNSUPPORTED, "the fused transposed conv has no kernel instance for this shape (MT %d NT %d k %d sigma %d flags %d)", P.MT, P.NT, ks, sg, fl);
     PSEG_TRY_INST(4, 4, 2, 1, 6, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv
     PSEG_TRY_INST(2, 4, 3, 2, 4, MODE_CONV, 0)            // res_unet encoder: stride-2 shortcut conv (four-row tiles, dense de-interleaved tile)
     PSEG_TRY_INST(2, 4, 3, 2, 4, MODE_CONV, FL_INRELU)    // res_unet encoder: stride-2 first conv of the block
@@ -3669,6 +3797,15 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         a.f1_bias = P1->d_bias;
         a.f1_relu = c1.relu;
         a.lds_f1_off = P->lds_f1_off;
+    }
+    if (op.dq_fuse >= 0) {
+        const Op& dq = e.ops[op.dq_fuse];
+        auto* PQ = (MfmaPlan*)dq.plan;
+        if (!PQ || !PQ->d_dq_w) return fail(PSEG_EINVAL, "fused transposed conv: plan data missing");
+        const Tensor& qd = e.tensors[dq.dst];
+        a.dq_w = PQ->d_dq_w; a.dq_bias = PQ->d_dq_bias; a.dq_dst = (uint16_t*)qd.d; a.dq_nch = qd.Cs / 8; a.dq_relu = dq.relu;
+        a.dq_bytes = (unsigned)((size_t)e.tH(qd) * e.tW(qd) * qd.Cs * 2);
+        a.dst_bytes = 0;          // (the conv's own tensor is not stored)
     }
     dim3 grid(cdiv(a.Wout, TW) * cdiv(a.Hout, P->NW * (P->MT / 2)), P->nblocks_n);
     a.xq = PSEG_KNOB("PSEG_NO_XCD") ? -1 : (int)grid.x / 8;

@@ -44,6 +44,7 @@ def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, monkeypatch, arch, C, shape):
     monkeypatch.setenv("PSEG_NO_SKIPLOG", "1")
     monkeypatch.setenv("PSEG_NO_TAIL2", "1")
     monkeypatch.setenv("PSEG_NO_RELU_FWD", "1")      # res_unet: tensors otherwise stored after their readers' pre-activation ReLU
+    monkeypatch.setenv("PSEG_NO_DQ", "1")            # fcn graphs: deconv1's output otherwise lives only inside the kernel that also runs deconv2
     eng = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
     eng.set_weights(Wt)
     logit_k, _, pred_k = eng.predict(img)
@@ -354,3 +355,37 @@ def test_bf16_ping_pong_mid_layer_kernel_is_bit_identical(gpu, monkeypatch, arch
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
     assert np.abs(res[0][2]).max() > 0
+
+
+@pytest.mark.parametrize("arch,shape", [("fcn_skip", (256, 320)), ("fcn", (96, 64)), ("fcn_skip", (1024, 768)), ("fcn_skip", (70, 50))])
+def test_bf16_transposed_conv_behind_its_producer(gpu, oracle_mod, monkeypatch, arch, shape):
+    """deconv2 (Conv2DTranspose k2 s2) runs on deconv1's accumulators in deconv1's epilogue (FL_DQ): against the engine with the
+    two launches (PSEG_NO_DQ) the same products, another float32 summation grouping (k-steps pair the accumulator tiles):
+    logits within 2e-3, labels equal except at near-ties, deconv2's tensor within one bf16 ulp step of the unfused one."""
+    from pseg_amd import synth
+    C = 3
+    img = synth.synth_page(11, max(shape[0], 96), max(shape[1], 96), C)[0][:shape[0], :shape[1]].copy()
+    Wt = oracle_mod.init_weights(arch, C, seed=21, gain=1.5, bias_scale=0.05)
+    res = []
+    for knob in (None, "PSEG_NO_DQ"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        e = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
+        e.set_weights(Wt)
+        z, _, l = e.predict(img, want_probs=False)
+        d2 = e.activation("conv2d_transpose_1")
+        if knob is None:
+            with pytest.raises(gpu.PsegError, match="fused"):
+                e.activation("conv2d_transpose")
+        else:
+            assert e.activation("conv2d_transpose").shape[2] == 80
+        res.append((z, l, d2))
+        e.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    (z1, l1, d1), (z0, l0, d0) = res
+    assert d1.shape == d0.shape and np.abs(d1 - d0).max() <= 2 ** -6 * max(1.0, np.abs(d0).max())
+    assert np.abs(z1 - z0).max() <= 2e-3 * max(1.0, np.abs(z0).max())
+    assert _check_labels(l1, z1, z0)[0] == 0
+    z_o = oracle_mod.forward(arch, Wt, img, "f32")
+    assert np.abs(z1 - z_o).max() <= TOL * max(1.0, np.abs(z_o).max())

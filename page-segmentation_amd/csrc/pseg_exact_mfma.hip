@@ -321,6 +321,114 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
     }
 }
 
+// Layers whose all-channel halo tile does not fit LDS (unet's 1024 / 1536-channel concats, res_unet's 768 ...): the same
+// MFMA formulation with BOTH operands fetched straight from global memory in fragment layout -- no tile, so no limit on the
+// channel count, and the chain still runs (ky, kx, ci ascending) in one accumulator per output: the same bits as the scalar
+// kernel these layers used to fall back to (2.3 TFLOP/s: unet's float32 predict spent 0.9 s per 2048x1536 page there).
+//   B (pixels): lane (pixel p16, g) holds x[pixel + tap][channel 4s + g]  -- a buffer load, out-of-image taps and channels past
+//               the layer read zeros through an out-of-range offset (fmaf(0, w, acc) == acc exactly);
+//   A (weights): as conv_exact_mfma_kernel (zero slack for the lanes without a weight).
+// A pixel's value is fetched once per tap and cout block; the re-reads hit L1 / L2 (the halo of a 4-row x 32-pixel tile).
+// The fragments of k-step s + 1 are requested before the MFMAs of step s; the pre-activation ReLU is applied at the rotation.
+// Sources must hold a multiple of four channels (a k-step never straddles the Concatenate).
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_exact_direct_kernel(ConvArgs a) {
+    constexpr int RW = MT / 2, TH = 4 * RW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p16 = lane & 15, g = lane >> 4;
+    const int tiles_x = (a.Wout + XTW - 1) / XTW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * XTW;
+    const int Cin = a.C0 + a.C1;
+    const int co_base = blockIdx.y * (NT * 16);
+    constexpr unsigned OOB = 0xfffffff0u;
+    const int H0 = a.Hin >> a.up0, W0 = a.Win >> a.up0, H1 = a.Hin >> a.up1, W1 = a.Win >> a.up1;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)((size_t)H0 * W0 * a.C0 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
+                                                                        a.src1 ? (unsigned)((size_t)H1 * W1 * a.C1 * 4) : 0u, 0x00020000);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int py[MT], px[MT];                    // this lane's input pixel at tap (0, 0)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        py[m] = (oy0 + wave * RW + (m >> 1)) * a.stride - a.pt;
+        px[m] = (ox0 + (m & 1) * 16 + p16) * a.stride - a.pl;
+    }
+    int wcol[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = co_base + t * 16 + p16;
+        wcol[t] = n < a.Cout ? n : -1;
+    }
+    const int zoff = a.KH * a.KW * Cin * a.Cout;
+    const int nks0 = a.C0 >> 2, nks = Cin >> 2;       // k-steps per tap (both sources hold multiples of four channels)
+    const int total = a.KH * a.KW * nks;
+    float xa[MT], wa[NT], xn[MT], wn[NT];
+    // fragments of flat step index q = tap * nks + s
+    auto load = [&](int q, float* xf, float* wf) {
+        const int tap = q / nks, sidx = q - tap * nks;
+        const int ky = tap / a.KW, kx = tap - ky * a.KW;
+        const bool second = sidx >= nks0;                                   // wave-uniform: the step lies in src1
+        const int up = second ? a.up1 : a.up0, Ws = second ? W1 : W0, C = second ? a.C1 : a.C0;
+        const int c = (second ? sidx - nks0 : sidx) * 4 + g;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int iy = py[m] + ky, ix = px[m] + kx;
+            const bool in = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            const unsigned o = in ? (unsigned)(((iy >> up) * Ws + (ix >> up)) * C + c) * 4u : OOB;
+            xf[m] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r1, o, 0, 0)
+                                                     : __builtin_amdgcn_raw_buffer_load_b32(r0, o, 0, 0));
+        }
+        const int ci = sidx * 4 + g;
+        const int wbase = (tap * Cin + ci) * a.Cout;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wf[t] = a.w[wcol[t] >= 0 ? wbase + wcol[t] : zoff];
+    };
+    if (total > 0) load(0, xn, wn);
+    for (int q = 0; q < total; ++q) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xa[m] = (a.in_relu && !(xn[m] > 0.0f)) ? 0.0f : xn[m];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wa[t] = wn[t];
+        if (q + 1 < total) load(q + 1, xn, wn);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], xa[m], acc[m][t], 0, 0, 0);
+    }
+    // ---- epilogue (as conv_exact_mfma_kernel) ----
+    const int osy = a.out_sy ? a.out_sy : 1, osx = a.out_sx ? a.out_sx : 1;
+    const int pitch = a.dst_pitch ? a.dst_pitch : a.Wout;
+    const bool vec4 = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int y = oy0 + wave * RW + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+        if (y >= a.Hout || x >= a.Wout) continue;
+        const size_t opix = (size_t)(y * osy + a.out_oy) * pitch + (size_t)(x * osx + a.out_ox);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n0 = co_base + t * 16 + 4 * g;
+            if (n0 >= a.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = n0 + r < a.Cout ? n0 + r : n0;
+                v[r] = a.bias ? acc[m][t][r] + a.bias[co] : acc[m][t][r];
+                if (a.add && n0 + r < a.Cout) v[r] = v[r] + a.add[opix * a.Cout + co];
+                if (a.relu) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+            }
+            if (vec4 && n0 + 3 < a.Cout) *(float4*)(a.dst + opix * a.Cout + n0) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < a.Cout) a.dst[opix * a.Cout + n0 + r] = v[r];
+            }
+        }
+    }
+}
+
 template <int MT, int NT, bool FLAT>
 static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, int CB, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_set[64] = {false};
@@ -366,7 +474,22 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
         Cp = CB + 2;                               // CB is a multiple of 4: stride 2 (mod 4)
         MT = 2;
     }
-    if (!MT) return 0;
+    if (!MT) {
+        // the all-channel tile does not fit LDS: operands straight from global memory (same chain, same bits)
+        if (a.deconv4 || a.mask || (a.C0 & 3) || (a.C1 & 3) || PSEG_KNOB("PSEG_EXACT_NO_DIRECT")) return 0;
+        if ((size_t)a.Hin * a.Win * std::max(a.C0, a.C1) * 4 >= ((size_t)1 << 32) || (size_t)a.KH * a.KW * Cin * a.Cout >= ((size_t)1 << 31)) return 0;
+        const int ntall_d = cdiv(a.Cout, 16);
+        const int NTd = ntall_d >= 4 ? 4 : ntall_d;
+        dim3 gd(cdiv(a.Wout, XTW) * cdiv(a.Hout, 8), cdiv(ntall_d, NTd));
+        switch (NTd) {
+            case 1: conv_exact_direct_kernel<4, 1><<<gd, 256, 0, st>>>(a); break;
+            case 2: conv_exact_direct_kernel<4, 2><<<gd, 256, 0, st>>>(a); break;
+            case 3: conv_exact_direct_kernel<4, 3><<<gd, 256, 0, st>>>(a); break;
+            default: conv_exact_direct_kernel<4, 4><<<gd, 256, 0, st>>>(a); break;
+        }
+        PSEG_HIP(hipGetLastError());
+        return 1;
+    }
     THH = (4 * (MT / 2) - 1) * a.stride + a.KH;
     const size_t lds = (size_t)THH * TWH * Cp * 4;
     const int ntall = cdiv(Ntot, 16);

@@ -474,6 +474,9 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
         Cp = CB + 2;                               // CB is a multiple of 4: stride 2 (mod 4)
         MT = 2;
     }
+    // a 4-row tile that fills the CU's LDS alone (128+ channels) loses to the LDS-free kernel below: unet 97 -> 78 ms, res_unet
+    // 102 -> 86 ms per float32 page (fcn_skip's 120-channel deconv3 the other way round: 7.3 vs 8.2 ms)
+    if (MT == 2 && !a.relaxed && Cin >= 128 && !a.deconv4 && !a.mask && !(a.C0 & 3) && !(a.C1 & 3) && !PSEG_KNOB("PSEG_EXACT_NO_DIRECT")) MT = 0;
     if (!MT) {
         // the all-channel tile does not fit LDS: operands straight from global memory (same chain, same bits)
         if (a.deconv4 || a.mask || (a.C0 & 3) || (a.C1 & 3) || PSEG_KNOB("PSEG_EXACT_NO_DIRECT")) return 0;

@@ -365,9 +365,10 @@ __global__ __launch_bounds__(256) void conv_exact_direct_kernel(ConvArgs a) {
     const int zoff = a.KH * a.KW * Cin * a.Cout;
     const int nks0 = a.C0 >> 2, nks = Cin >> 2;       // k-steps per tap (both sources hold multiples of four channels)
     const int total = a.KH * a.KW * nks;
-    float xa[MT], wa[NT], xn[MT], wn[NT];
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.src0), 0, a.mask ? (unsigned)((size_t)H0 * W0 * a.C0 * 4) : 0u, 0x00020000);
+    float xa[MT], wa[NT], xn[MT], wn[NT], mn[MT];
     // fragments of flat step index q = tap * nks + s
-    auto load = [&](int q, float* xf, float* wf) {
+    auto load = [&](int q, float* xf, float* wf, float* mf) {
         const int tap = q / nks, sidx = q - tap * nks;
         const int ky = tap / a.KW, kx = tap - ky * a.KW;
         const bool second = sidx >= nks0;                                   // wave-uniform: the step lies in src1
@@ -380,19 +381,21 @@ __global__ __launch_bounds__(256) void conv_exact_direct_kernel(ConvArgs a) {
             const unsigned o = in ? (unsigned)(((iy >> up) * Ws + (ix >> up)) * C + c) * 4u : OOB;
             xf[m] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r1, o, 0, 0)
                                                      : __builtin_amdgcn_raw_buffer_load_b32(r0, o, 0, 0));
+            // training data gradients: the value counts only where the ReLU mask (laid out as src0) is positive
+            mf[m] = (a.mask && !second) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, o, 0, 0)) : 1.0f;
         }
         const int ci = sidx * 4 + g;
         const int wbase = (tap * Cin + ci) * a.Cout;
 #pragma unroll
         for (int t = 0; t < NT; ++t) wf[t] = a.w[wcol[t] >= 0 ? wbase + wcol[t] : zoff];
     };
-    if (total > 0) load(0, xn, wn);
+    if (total > 0) load(0, xn, wn, mn);
     for (int q = 0; q < total; ++q) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) xa[m] = (a.in_relu && !(xn[m] > 0.0f)) ? 0.0f : xn[m];
+        for (int m = 0; m < MT; ++m) xa[m] = ((a.in_relu && !(xn[m] > 0.0f)) || !(mn[m] > 0.0f)) ? 0.0f : xn[m];
 #pragma unroll
         for (int t = 0; t < NT; ++t) wa[t] = wn[t];
-        if (q + 1 < total) load(q + 1, xn, wn);
+        if (q + 1 < total) load(q + 1, xn, wn, mn);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -476,10 +479,10 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     }
     // a 4-row tile that fills the CU's LDS alone (128+ channels) loses to the LDS-free kernel below: unet 97 -> 78 ms, res_unet
     // 102 -> 86 ms per float32 page (fcn_skip's 120-channel deconv3 the other way round: 7.3 vs 8.2 ms)
-    if (MT == 2 && !a.relaxed && Cin >= 128 && !a.deconv4 && !a.mask && !(a.C0 & 3) && !(a.C1 & 3) && !PSEG_KNOB("PSEG_EXACT_NO_DIRECT")) MT = 0;
+    if (MT == 2 && (!a.relaxed || PSEG_KNOB("PSEG_TRAIN_DIRECT")) && Cin >= 128 && !a.deconv4 && !(a.C0 & 3) && !(a.C1 & 3) && !PSEG_KNOB("PSEG_EXACT_NO_DIRECT")) MT = 0;
     if (!MT) {
         // the all-channel tile does not fit LDS: operands straight from global memory (same chain, same bits)
-        if (a.deconv4 || a.mask || (a.C0 & 3) || (a.C1 & 3) || PSEG_KNOB("PSEG_EXACT_NO_DIRECT")) return 0;
+        if (a.deconv4 || (a.C0 & 3) || (a.C1 & 3) || PSEG_KNOB("PSEG_EXACT_NO_DIRECT")) return 0;
         if ((size_t)a.Hin * a.Win * std::max(a.C0, a.C1) * 4 >= ((size_t)1 << 32) || (size_t)a.KH * a.KW * Cin * a.Cout >= ((size_t)1 << 31)) return 0;
         const int ntall_d = cdiv(a.Cout, 16);
         const int NTd = ntall_d >= 4 ? 4 : ntall_d;

@@ -1957,6 +1957,14 @@ __global__ __launch_bounds__(256) void tail_fused2_kernel(Tail2 a) {
         for (int s = 0; s < 2; ++s) wc[t][s] = *(const bf16x8*)(a.wC + ((size_t)(t * 2 + s) * 64 + lane) * 8);
         bt[t] = *(const float4*)(a.beta + t * 16 + 4 * g);
     }
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+    constexpr unsigned OOBT = 0xfffffff0u;
+    const bool two_q = a.nq1 > 0;
+    const unsigned qpix = (unsigned)(a.Hh >> 1) * (unsigned)(a.Wh >> 1), hpix = (unsigned)a.Hh * (unsigned)a.Wh;
+    const __amdgpu_buffer_rsrc_t rq0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.q0, 0, qpix * (unsigned)a.nq0 * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.q1 ? a.q1 : a.q0), 0, a.q1 ? qpix * (unsigned)a.nq1 * 16u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc3 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c3 ? a.c3 : a.q0), 0, a.c3 ? hpix * (unsigned)a.nc3 * 16u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)(a.S ? (const void*)a.S : (const void*)a.q0), 0, a.S ? hpix * (unsigned)(4 * CP * 4) : 0u, 0x00020000);
     const int C = a.C;
 #pragma unroll 1
     for (int it = 0; it < T2_ITER; ++it) {
@@ -1965,29 +1973,39 @@ __global__ __launch_bounds__(256) void tail_fused2_kernel(Tail2 a) {
         const int hxr = x0 + 2 * p16 + b;
         const bool inx = hxr < a.Wh;
         const int hx = inx ? hxr : a.Wh - 1;                 // clamp: loads stay in bounds, stores are masked
-        const size_t qpx = (size_t)(hy >> 1) * (a.Wh >> 1) + (hx >> 1);
-        const size_t hpx = (size_t)hy * a.Wh + hx;
-        // ---- all loads first ----
+        const unsigned qpx = (unsigned)(hy >> 1) * (unsigned)(a.Wh >> 1) + (unsigned)(hx >> 1);
+        const unsigned hpx = (unsigned)hy * (unsigned)a.Wh + (unsigned)hx;
+        // ---- all loads first: buffer loads with 32-bit offsets; every load reads ONE tensor (two quarter-resolution sources: k-steps
+        // 0-1 <- source 0, 2-3 <- source 1, the host packs the weights that way); a lane with nothing to fetch gets an out-of-range
+        // offset and reads zeros -- no exec-mask branches, no 64-bit address arithmetic
         uint4 xq[4], xc[2];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int ch = 4 * s + g;
-            xq[s] = make_uint4(0, 0, 0, 0);
-            if (ch < a.nq0) xq[s] = *(const uint4*)(a.q0 + (qpx * a.nq0 + ch) * 8);
-            else if (ch < a.nq0 + a.nq1) xq[s] = *(const uint4*)(a.q1 + (qpx * a.nq1 + (ch - a.nq0)) * 8);
+            u32x4_t v;
+            if (two_q) {
+                const int ch = 4 * (s & 1) + g;
+                if (s < 2) v = __builtin_amdgcn_raw_buffer_load_b128(rq0, ch < a.nq0 ? (qpx * (unsigned)a.nq0 + (unsigned)ch) * 16u : OOBT, 0, 0);
+                else v = __builtin_amdgcn_raw_buffer_load_b128(rq1, ch < a.nq1 ? (qpx * (unsigned)a.nq1 + (unsigned)ch) * 16u : OOBT, 0, 0);
+            } else {
+                const int ch = 4 * s + g;
+                v = __builtin_amdgcn_raw_buffer_load_b128(rq0, ch < a.nq0 ? (qpx * (unsigned)a.nq0 + (unsigned)ch) * 16u : OOBT, 0, 0);
+            }
+            xq[s] = make_uint4(v[0], v[1], v[2], v[3]);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int ch = 4 * s + g;
-            xc[s] = ch < a.nc3 ? *(const uint4*)(a.c3 + (hpx * a.nc3 + ch) * 8) : make_uint4(0, 0, 0, 0);
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rc3, ch < a.nc3 ? (hpx * (unsigned)a.nc3 + (unsigned)ch) * 16u : OOBT, 0, 0);
+            xc[s] = make_uint4(v[0], v[1], v[2], v[3]);
         }
         f32x4 acc[NTL];
 #pragma unroll
         for (int t = 0; t < NTL; ++t) {
             const int row0 = 16 * t + 4 * g, abo = row0 / CP, c0 = row0 - abo * CP;
-            const size_t px = (size_t)(2 * hy + (abo >> 1)) * (2 * a.Wh) + 2 * hx + (abo & 1);
-            const float4 sv = a.S ? *(const float4*)(a.S + px * CP + c0) : make_float4(0.f, 0.f, 0.f, 0.f);   // fcn: no skip
-            acc[t] = f32x4{bt[t].x + sv.x, bt[t].y + sv.y, bt[t].z + sv.z, bt[t].w + sv.w};
+            const unsigned px = (unsigned)(2 * hy + (abo >> 1)) * (unsigned)(2 * a.Wh) + (unsigned)(2 * hx + (abo & 1));
+            const u32x4_t sv = __builtin_amdgcn_raw_buffer_load_b128(rS, (px * CP + c0) * 4u, 0, 0);   // fcn: no skip buffer (zero-length descriptor)
+            const f32x4 svf = __builtin_bit_cast(f32x4, sv);   // (as ONE vector: element-wise bit casts of the loaded dwords made the compiler narrow the load to one dword)
+            acc[t] = f32x4{bt[t].x + svf[0], bt[t].y + svf[1], bt[t].z + svf[2], bt[t].w + svf[3]};
         }
         // ---- inner deconv: d4[co][pixel] for this wave's sub-pixel ----
         // (bias = start value, as every MFMA conv of the engine: the stand-alone deconv kernel rounds the same way)
@@ -2904,6 +2922,7 @@ int mfma_plan_graph(Engine& e) {
             Op& dq = e.ops[di];
             if (dq.type != OP_DECONV2 || !dq.relu || dq.Cout > 32 || dq.tail_logits >= 0 || dq.into_tail >= 0) continue;
             if ((e.tensors[dq.src0].Cs + (dq.src1 >= 0 ? e.tensors[dq.src1].Cs : 0)) / 8 > 16) continue;
+            if (dq.src1 >= 0 && (e.tensors[dq.src0].Cs > 64 || e.tensors[dq.src1].Cs > 64)) continue;   // k-steps 0-1 <- source 0, 2-3 <- source 1
             int du = 0;
             for (auto& o : e.ops) du += (o.src0 == dq.dst) + (o.src1 == dq.dst) + (o.add == dq.dst);
             if (du != 1) continue;
@@ -2921,6 +2940,7 @@ int mfma_plan_graph(Engine& e) {
             Op& dq = e.ops[di];
             if (dq.type != OP_DECONV2 || !dq.relu || dq.Cout > 32 || dq.tail_logits >= 0 || dq.into_tail >= 0) continue;
             if ((e.tensors[dq.src0].Cs + (dq.src1 >= 0 ? e.tensors[dq.src1].Cs : 0)) / 8 > 16) continue;
+            if (dq.src1 >= 0 && (e.tensors[dq.src0].Cs > 64 || e.tensors[dq.src1].Cs > 64)) continue;   // k-steps 0-1 <- source 0, 2-3 <- source 1
             int du = 0;
             for (auto& o : e.ops) du += (o.src0 == dq.dst) + (o.src1 == dq.dst) + (o.add == dq.dst);
             if (du != 1) continue;
@@ -3328,8 +3348,16 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
             for (int t = 0; t < 2; ++t)
                 for (int sidx = 0; sidx < 4; ++sidx)
                     for (int l = 0; l < 64; ++l) {
-                        const int co = t * 16 + (l & 15), chunk = 4 * sidx + (l >> 4);
+                        // one source: chunk 4s + g; two sources (each <= 8 chunks): k-steps 0-1 take source 0, k-steps 2-3 source 1, so that
+                        // every fragment load of the tail kernel reads ONE tensor
+                        const int co = t * 16 + (l & 15), gg = l >> 4;
                         if (co >= Cout) continue;
+                        int chunk = 4 * sidx + gg;
+                        if (s1) {
+                            const int c2 = 4 * (sidx & 1) + gg;
+                            if (c2 >= (sidx < 2 ? Cs0 : Cs1) / 8) continue;
+                            chunk = sidx < 2 ? c2 : Cs0 / 8 + c2;
+                        }
                         for (int j = 0; j < 8; ++j) {
                             const int cs = chunk * 8 + j;
                             if (cs >= Cs0 + Cs1) continue;

@@ -7,11 +7,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/pseg.h"
 
+struct pseg_engine;
 namespace pseg {
 
 // ---- error plumbing (thread-local message, int status: SURVEY.md 8b "Errors") -------------
@@ -32,31 +34,46 @@ int fail(int code, const char* fmt, ...);
         if (_rc != PSEG_OK) return _rc;                                                        \
     } while (0)
 
-// Developer knobs (PSEG_* environment variables: ablation switches, alternative kernel choices).  A release build
-// snapshots the PSEG_* part of the environment when an engine is created (pseg_create) and answers every knob query
-// from that snapshot -- a kernel launch costs no getenv(), and a stray change of the environment cannot alter a
-// running engine; each call site caches its answer per snapshot generation.  The diagnostic build (libpseg_diag.so:
-// tools/trace_layers.py flips knobs between launches) reads the environment every time.
+// Developer knobs (PSEG_* environment variables: alternative kernel choices that must not change results beyond the
+// documented bars; every one is exercised by a bit-identity or tolerance test).  pseg_create snapshots the PSEG_* part of
+// the environment ONCE for the new engine; the engine keeps that snapshot for its whole life (std::shared_ptr, freed
+// with the last engine that holds it) and every entry point that takes an engine answers knob queries from the
+// engine's OWN snapshot (KnobScope, thread-local) -- plan-time and launch-time reads of one engine always agree, and
+// neither a later change of the environment nor the creation of another engine (e.g. the float32 companion of the
+// label-exact mode, which inherits its parent's snapshot) can alter a running engine.  Engine-less entries (post-
+// process, resize) read the newest snapshot.  Each call site caches its answer per snapshot id.
+// Knobs that produce WRONG results (timing ablations: PSEG_DBG, PSEG_XM_DBG, PSEG_PP_NODMA, PSEG_PP_NOEPI, the
+// in-kernel trace stamps) exist only in the diagnostic build (libpseg_diag.so, -DPSEG_DIAG=1): PSEG_DIAG_KNOB is a
+// constant nullptr in the release library (tests/test_abi.py checks that the release .so does not even hold the names).
 #ifndef PSEG_DIAG
 #define PSEG_DIAG 0
 #endif
-unsigned knob_generation();                 // current snapshot number (>= 1)
-const char* knob_lookup(const char* name);  // value in the current snapshot, or nullptr
-void knobs_refresh();                       // take a new snapshot (pseg_create)
+struct KnobSnap;                                  // id + the PSEG_* variables at the time of the snapshot
+std::shared_ptr<const KnobSnap> knobs_snapshot(); // snapshot the environment now; it also becomes the "newest" one
+unsigned knob_generation();                       // id of the snapshot in scope (the engine's, else the newest), >= 1
+const char* knob_lookup(const char* name);        // value in that snapshot, or nullptr
+struct Engine;
+struct KnobScope {                                // RAII: knob queries on this thread read `e`'s snapshot
+    explicit KnobScope(const Engine& e);
+    ~KnobScope();
+    const KnobSnap* prev;
+};
 #if PSEG_DIAG
 #define PSEG_KNOB(name) getenv(name)
+#define PSEG_DIAG_KNOB(name) getenv(name)
 #else
 #define PSEG_KNOB(name)                                                                                   \
     ([]() -> const char* {                                                                                \
-        static unsigned gen_ = 0;                                                                         \
-        static const char* v_ = nullptr;                                                                  \
+        static thread_local unsigned gen_ = 0;       /* per thread: no torn (id, value) pairs */         \
+        static thread_local const char* v_ = nullptr;                                                     \
         const unsigned g_ = ::pseg::knob_generation();                                                    \
-        if (__atomic_load_n(&gen_, __ATOMIC_ACQUIRE) != g_) {                                             \
-            __atomic_store_n(&v_, ::pseg::knob_lookup(name), __ATOMIC_RELAXED);                           \
-            __atomic_store_n(&gen_, g_, __ATOMIC_RELEASE);                                                \
+        if (gen_ != g_) {                                                                                 \
+            v_ = ::pseg::knob_lookup(name);                                                               \
+            gen_ = g_;                                                                                    \
         }                                                                                                 \
-        return __atomic_load_n(&v_, __ATOMIC_RELAXED);                                                    \
+        return v_;                                                                                        \
     }())
+#define PSEG_DIAG_KNOB(name) ((const char*)nullptr)
 #endif
 
 constexpr int PSEG_MAXC = 64;   // classes the train-step metric slots and the wide bf16 logits kernel are sized for
@@ -142,6 +159,7 @@ struct TimingSlot {
 };
 
 struct Engine {
+    std::shared_ptr<const KnobSnap> knobs;   // the PSEG_* snapshot this engine was created under (see PSEG_KNOB)
     int arch = 0, n_classes = 0, in_ch = 1, device = 0, mode = 0;
     unsigned flags = 0;            // PSEG_FLAG_* of pseg_create_ex
     bool bn_training = false;      // float32 engine, while a TRAINING forward runs: BatchNormalization layers use batch statistics and update their moving ones
@@ -229,6 +247,8 @@ int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* d_logit
                    uint8_t* d_labels_u8, hipStream_t st, float* d_margin);
 void launch_margin_from_logits(const float* d_logits, size_t n, int C, float* d_margin, hipStream_t st);
 bool mfma_tail_emits_margin(const Engine& e);   // the bf16 graph's tail kernel writes the margin map itself
+int create_engine(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
+                  std::shared_ptr<const KnobSnap> inherit, struct ::pseg_engine** out);   // pseg_create_ex; `inherit` = a parent engine's knob snapshot
 void exact_free(Engine& e);                     // label-exact mode state (pseg_exactlabels.hip)
 int set_canvas(Engine& e, int H, int W, hipStream_t st);
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs, int64_t* d_labels,

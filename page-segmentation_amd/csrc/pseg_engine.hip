@@ -22,42 +22,54 @@ std::string& last_error() {
 }
 
 // ---- knob snapshots (see pseg_common.h) -------------------------------------------------------------------------
+struct KnobSnap {
+    unsigned id = 0;
+    std::map<std::string, std::string> kv;
+};
 namespace {
 std::mutex g_knob_mu;
-std::vector<std::map<std::string, std::string>*> g_knob_snaps;   // every snapshot stays alive: call sites may hold pointers into it
-unsigned g_knob_gen = 0;
+std::shared_ptr<const KnobSnap> g_knob_latest;     // what engine-less entries read
+std::vector<std::shared_ptr<const KnobSnap>> g_knob_retired;
+unsigned g_knob_next_id = 0;
+thread_local const KnobSnap* tls_knobs = nullptr;  // the snapshot of the engine whose entry point is running on this thread
 extern "C" char** environ;
-void knobs_snapshot_locked() {
-    auto* m = new std::map<std::string, std::string>();
+}  // namespace
+std::shared_ptr<const KnobSnap> knobs_snapshot() {
+    auto m = std::make_shared<KnobSnap>();
     for (char** ep = environ; ep && *ep; ++ep) {
         if (strncmp(*ep, "PSEG_", 5) != 0) continue;
         const char* eq = strchr(*ep, '=');
-        if (eq) (*m)[std::string(*ep, eq - *ep)] = std::string(eq + 1);
+        if (eq) m->kv[std::string(*ep, eq - *ep)] = std::string(eq + 1);
     }
-    g_knob_snaps.push_back(m);
-    __atomic_store_n(&g_knob_gen, g_knob_gen + 1, __ATOMIC_RELEASE);
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    // an unchanged environment (the normal case: one snapshot per process) shares the newest snapshot; a changed one
+    // retires it -- retired "newest" snapshots stay alive (an engine-less call site on another thread may still hold a
+    // pointer into it), one per CHANGE of the PSEG_* environment, not one per engine
+    if (g_knob_latest && g_knob_latest->kv == m->kv) return g_knob_latest;
+    if (g_knob_latest) g_knob_retired.push_back(g_knob_latest);
+    m->id = ++g_knob_next_id;
+    g_knob_latest = m;
+    return m;
 }
-}  // namespace
-unsigned knob_generation() {
-    unsigned g = __atomic_load_n(&g_knob_gen, __ATOMIC_ACQUIRE);
-    if (g == 0) {
+static std::shared_ptr<const KnobSnap> knobs_latest() {
+    {
         std::lock_guard<std::mutex> lk(g_knob_mu);
-        if (g_knob_gen == 0) knobs_snapshot_locked();
-        g = g_knob_gen;
+        if (g_knob_latest) return g_knob_latest;
     }
-    return g;
+    return knobs_snapshot();
 }
+unsigned knob_generation() { return tls_knobs ? tls_knobs->id : knobs_latest()->id; }
 const char* knob_lookup(const char* name) {
-    (void)knob_generation();
-    std::lock_guard<std::mutex> lk(g_knob_mu);
-    const auto& m = *g_knob_snaps.back();
-    auto it = m.find(name);
-    return it == m.end() ? nullptr : it->second.c_str();
+    // The returned pointer lives as long as the snapshot: an engine's snapshot for the engine's life; the newest one until
+    // the next pseg_create -- a call site never hands out a cached pointer under another snapshot id (ids are never reused).
+    const KnobSnap* k = tls_knobs;
+    std::shared_ptr<const KnobSnap> hold;
+    if (!k) { hold = knobs_latest(); k = hold.get(); }
+    auto it = k->kv.find(name);
+    return it == k->kv.end() ? nullptr : it->second.c_str();
 }
-void knobs_refresh() {
-    std::lock_guard<std::mutex> lk(g_knob_mu);
-    knobs_snapshot_locked();
-}
+KnobScope::KnobScope(const Engine& e) : prev(tls_knobs) { if (e.knobs) tls_knobs = e.knobs.get(); }
+KnobScope::~KnobScope() { tls_knobs = prev; }
 
 int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -148,7 +160,9 @@ __global__ __launch_bounds__(256) void conv1x1_exact_kernel(ConvArgs a) {
         const int C = srcsel ? a.C1 : a.C0, cbase = srcsel ? a.C0 : 0;
         const float* p = (srcsel ? a.src1 : a.src0) + ((size_t)y * a.Win + x0) * C;
         const int n = npx * C;
-        const unsigned inv = (1u << 20) / (unsigned)C + 1u;     // n <= 256 * C: e * inv < 2^32 for C >= 1
+        // e / C by a reciprocal multiply: floor(e * inv / 2^32) with inv = floor(2^32 / C) + 1 is exact while e * C < 2^32
+        // (here e < 256 * C <= 2^15).  (A 20-bit reciprocal, exact only while e * C < 2^20, was wrong for 73 <= C <= 127.)
+        const unsigned long long inv = (1ull << 32) / (unsigned)C + 1ull;
         for (int e0 = 0; e0 < n; e0 += 256 * 8) {
             float v[8];
 #pragma unroll
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(256) void conv1x1_exact_kernel(ConvArgs a) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = e0 + u * 256 + (int)threadIdx.x;
-                const int px = (int)(((unsigned long long)(unsigned)e * inv) >> 20), c = e - px * C;
+                const int px = (int)(((unsigned long long)(unsigned)e * inv) >> 32), c = e - px * C;
                 if (e < n) xs[px * P + cbase + c] = v[u];
             }
         }
@@ -502,10 +516,20 @@ int set_canvas(Engine& e, int H, int W, hipStream_t st) {
     // flight on the engine's (non-blocking) stream or on a caller's stream: drain the device first, and clear on
     // the stream the coming kernels run on -- a hipMemset on the null stream is NOT ordered with non-blocking
     // streams (that race corrupted the first predict after shrinking from a 4096x3072 canvas).
+    const size_t esz = e.mode == PSEG_MODE_BF16 ? 2 : 4;
+    if (e.mode == PSEG_MODE_BF16) {
+        // the throughput kernels address every tensor through 32-bit buffer descriptors / offsets (out-of-range reads give
+        // zeros, out-of-range stores are dropped -- silently wrong labels, not a fault): refuse canvases whose largest
+        // tensor, or the 16 B/px skip-logits / margin planes, reach 4 GiB (unet: 64 bf16 channels -> about 5790 x 5790)
+        size_t worst = (size_t)Hp * Wp * 16 * 4;
+        for (auto& t : e.tensors) worst = std::max(worst, (size_t)(Hp >> t.s) * (Wp >> t.s) * t.Cs * esz);
+        if (worst >= ((size_t)1 << 32))
+            return fail(PSEG_EUNSUPPORTED, "page %dx%d: a tensor of this graph would reach 4 GiB (32-bit buffer addressing in the bf16 kernels); "
+                                           "predict it in tiles or use the float32 mode", H, W);
+    }
     PSEG_HIP(hipDeviceSynchronize());
     e.Hp = Hp;
     e.Wp = Wp;
-    const size_t esz = e.mode == PSEG_MODE_BF16 ? 2 : 4;
     for (auto& t : e.tensors) {
         const size_t bytes = (size_t)e.tH(t) * e.tW(t) * t.Cs * esz;
         if (bytes > t.bytes) {
@@ -926,6 +950,15 @@ int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
 
 int pseg_create_ex(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
                    pseg_engine** out) {
+    return pseg::create_engine(arch, n_classes, in_channels, device, mode, flags, nullptr, out);
+}
+
+}  // extern "C"
+
+// `inherit`: the snapshot of a parent engine (the float32 companion of the label-exact mode is created in the middle of
+// its parent's predict call and must not see another environment than its parent); nullptr = snapshot the environment now
+int pseg::create_engine(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
+                        std::shared_ptr<const KnobSnap> inherit, pseg_engine** out) {
     if (!out) return fail(PSEG_EINVAL, "out is NULL");
     if (flags & ~(unsigned)PSEG_FLAG_BATCHNORM) return fail(PSEG_EINVAL, "unknown flag bits 0x%x", flags);
     *out = nullptr;
@@ -937,9 +970,10 @@ int pseg_create_ex(int arch, int n_classes, int in_channels, int device, int mod
         return fail(PSEG_EHIP, "no HIP device visible: libpseg has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(PSEG_EINVAL, "device %d of %d", device, ndev);
     PSEG_HIP(hipSetDevice(device));
-    knobs_refresh();   // the PSEG_* developer knobs are read here, once per engine creation, never per launch
     auto* h = new pseg_engine();
     Engine& e = h->e;
+    e.knobs = inherit ? inherit : knobs_snapshot();   // the PSEG_* developer knobs are read here, once per engine, never per launch
+    KnobScope ks(e);
     e.arch = arch;
     e.n_classes = n_classes;
     e.in_ch = in_channels;
@@ -964,6 +998,8 @@ int pseg_create_ex(int arch, int n_classes, int in_channels, int device, int mod
     *out = h;
     return PSEG_OK;
 }
+
+extern "C" {
 
 int pseg_destroy(pseg_engine* h) {
     if (!h) return PSEG_OK;
@@ -1017,6 +1053,7 @@ static Param* find_param(Engine& e, const char* name) {
 int pseg_set_weights(pseg_engine* h, const char* name, const float* data, const int64_t* shape,
                      int ndim) {
     if (!h || !name || !data || !shape) return fail(PSEG_EINVAL, "NULL argument");
+    KnobScope knob_scope(h->e);
     Param* p = find_param(h->e, name);
     if (!p) return fail(PSEG_ENOTFOUND, "no weight named '%s'", name);
     if (ndim != p->ndim) return fail(PSEG_EINVAL, "weight '%s': rank %d, expected %d", name, ndim, p->ndim);
@@ -1044,6 +1081,7 @@ int pseg_get_weights(const pseg_engine* h, const char* name, float* out, int64_t
 int pseg_predict_device(pseg_engine* h, const uint8_t* d_img, int H, int W, float* d_logits,
                         float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8, void* stream) {
     if (!h || !d_img) return fail(PSEG_EINVAL, "NULL argument");
+    KnobScope knob_scope(h->e);
     hipStream_t st = stream ? (hipStream_t)stream : h->e.stream;
     return predict_device(h->e, d_img, H, W, d_logits, d_probs, d_labels, d_labels_u8, st, nullptr);
 }
@@ -1051,6 +1089,7 @@ int pseg_predict_device(pseg_engine* h, const uint8_t* d_img, int H, int W, floa
 int pseg_predict(pseg_engine* h, const uint8_t* img, int H, int W, float* logits, float* probs,
                  int64_t* labels) {
     if (!h || !img) return fail(PSEG_EINVAL, "NULL argument");
+    KnobScope knob_scope(h->e);
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     Engine& e = h->e;
     PSEG_HIP(hipSetDevice(e.device));
@@ -1073,6 +1112,7 @@ int pseg_predict(pseg_engine* h, const uint8_t* img, int H, int W, float* logits
 int pseg_predict_batch(pseg_engine* h, int n_pages, const uint8_t* const* imgs, const int* H, const int* W,
                        int64_t* const* labels, uint8_t* const* labels_u8) {
     if (!h || n_pages < 0 || (n_pages > 0 && (!imgs || !H || !W))) return fail(PSEG_EINVAL, "bad argument");
+    KnobScope knob_scope(h->e);
     if (!labels && !labels_u8) return fail(PSEG_EINVAL, "no output requested");
     return predict_batch(h->e, n_pages, imgs, H, W, labels, labels_u8);
 }
@@ -1113,6 +1153,7 @@ static inline float bf16_to_f32(uint16_t v) {
 
 int pseg_get_activation(pseg_engine* h, const char* layer, float* out, int64_t cap, int dims[3]) {
     if (!h || !layer) return fail(PSEG_EINVAL, "NULL argument");
+    KnobScope knob_scope(h->e);
     Engine& e = h->e;
     PSEG_HIP(hipSetDevice(e.device));
     for (auto& t : e.tensors) {

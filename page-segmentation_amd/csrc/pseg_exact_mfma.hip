@@ -451,7 +451,7 @@ static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, int CB, dim3 g
 int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     if (PSEG_KNOB("PSEG_EXACT_SCALAR")) return 0;
     ConvArgs a = a_in;
-    if (const char* dv = PSEG_KNOB("PSEG_XM_DBG")) a.dbg = atoi(dv);
+    if (const char* dv = PSEG_DIAG_KNOB("PSEG_XM_DBG")) a.dbg = atoi(dv);   // wrong-result timing switches: diagnostic build only
     const int Cin = a.C0 + a.C1;
     if (Cin < 1 || a.Cout < 1 || a.KH != a.KW) return 0;
     const int Ntot = a.deconv4 ? 4 * a.Cout : a.Cout;

@@ -123,7 +123,7 @@ __global__ void widen_u8_kernel(const uint8_t* in, int64_t* out, size_t n) {
 
 static int sync_weights(Engine& e, ExactState& x) {
     if (!x.f32) {
-        PSEG_TRY(pseg_create_ex(e.arch, e.n_classes, e.in_ch, e.device, PSEG_MODE_F32_EXACT, e.flags, &x.f32));
+        PSEG_TRY(create_engine(e.arch, e.n_classes, e.in_ch, e.device, PSEG_MODE_F32_EXACT, e.flags, e.knobs, &x.f32));   // the companion reads its parent's knob snapshot
         e.exact_dirty = true;
     }
     if (!e.exact_dirty) return PSEG_OK;
@@ -303,6 +303,7 @@ extern "C" {
 int pseg_predict_margin_device(pseg_engine* h, const uint8_t* d_img, int H, int W, uint8_t* d_labels_u8, float* d_margin,
                                void* stream) {
     if (!h || !d_img || !d_margin) return fail(PSEG_EINVAL, "NULL argument");
+    KnobScope knob_scope(h->e);
     hipStream_t st = stream ? (hipStream_t)stream : h->e.stream;
     return predict_device(h->e, d_img, H, W, nullptr, nullptr, nullptr, d_labels_u8, st, d_margin);
 }
@@ -310,6 +311,7 @@ int pseg_predict_margin_device(pseg_engine* h, const uint8_t* d_img, int H, int 
 int pseg_predict_exact_labels_device(pseg_engine* h, const uint8_t* d_img, int H, int W, uint8_t* d_labels_u8,
                                      int64_t* d_labels, float* d_margin, void* stream) {
     if (!h || !d_img || !d_labels_u8) return fail(PSEG_EINVAL, "NULL argument (the uint8 label map is required)");
+    KnobScope knob_scope(h->e);
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     hipStream_t st = stream ? (hipStream_t)stream : h->e.stream;
     return exact_labels(h->e, d_img, H, W, d_labels_u8, d_labels, d_margin, st);
@@ -317,6 +319,7 @@ int pseg_predict_exact_labels_device(pseg_engine* h, const uint8_t* d_img, int H
 
 int pseg_predict_exact_labels(pseg_engine* h, const uint8_t* img, int H, int W, int64_t* labels, uint8_t* labels_u8) {
     if (!h || !img || (!labels && !labels_u8)) return fail(PSEG_EINVAL, "NULL argument");
+    KnobScope knob_scope(h->e);
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     Engine& e = h->e;
     PSEG_HIP(hipSetDevice(e.device));

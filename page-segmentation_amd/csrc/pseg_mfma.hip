@@ -3658,7 +3658,7 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
 
 static int launch_generic_any(const MConv& a0, const MfmaPlan& P, dim3 grid, hipStream_t st, const char* layer) {
 #if PSEG_DIAG
-    const char* tr = PSEG_KNOB("PSEG_TRACE");
+    const char* tr = PSEG_DIAG_KNOB("PSEG_TRACE");
     if (tr && strcmp(tr, layer) == 0) {
         MConv a = a0;
         const size_t n = (size_t)grid.x * grid.y * 12;
@@ -3708,7 +3708,7 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.CoP = P.CoP;
     a.nb_loop = 1;
     a.nb_total = P.nblocks_n;
-    a.dbg = (PSEG_DIAG && PSEG_KNOB("PSEG_DBG")) ? atoi(PSEG_KNOB("PSEG_DBG")) : 0;
+    a.dbg = PSEG_DIAG_KNOB("PSEG_DBG") ? atoi(PSEG_DIAG_KNOB("PSEG_DBG")) : 0;   // wrong-result ablations: diagnostic build only
     if (PSEG_KNOB("PSEG_INRELU_VGPR")) a.dbg |= 16;
 }
 
@@ -3859,8 +3859,8 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
             w.lds_w_off = TB;
             w.ntiles = (int)grid.x;
             if (PSEG_KNOB("PSEG_PP_PRIO")) w.dbg |= 0x400;
-            if (PSEG_KNOB("PSEG_PP_NODMA")) w.dbg |= 0x800;
-            if (PSEG_KNOB("PSEG_PP_NOEPI")) w.dbg |= 0x1000;
+            if (PSEG_DIAG_KNOB("PSEG_PP_NODMA")) w.dbg |= 0x800;     // wrong results, timing only: diagnostic build only
+            if (PSEG_DIAG_KNOB("PSEG_PP_NOEPI")) w.dbg |= 0x1000;
             const dim3 gp((unsigned)cus_pp);
 #define PSEG_PP(SG_, POOL_)                                                                                       \
             if (a.sigma == SG_ && (a.pool_dst != nullptr) == POOL_) {                                             \
@@ -3879,7 +3879,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     }
     if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && P->MT == 8 && P->NT == 2 && P->KS == 5 && a.sigma == 3 &&
         a.pool_dst && !a.add && !a.in_relu && !a.relu && !PSEG_KNOB("PSEG_NO_WS") && !PSEG_KNOB("PSEG_NO_PERSIST") && !PSEG_KNOB("PSEG_GENERIC") && !a.trace) {
-        const bool ws_trace = PSEG_KNOB("PSEG_WS_TRACE") != nullptr;   // developer aid: per-wave phase cycles -> gpurun_out/ws_trace.bin
+        const bool ws_trace = PSEG_DIAG_KNOB("PSEG_WS_TRACE") != nullptr;   // developer aid: per-wave phase cycles -> gpurun_out/ws_trace.bin
         static int cus_ws = 0;
         int dev = 0;
         PSEG_HIP(hipGetDevice(&dev));

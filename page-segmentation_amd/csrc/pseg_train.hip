@@ -1391,6 +1391,7 @@ extern "C" {
 
 int pseg_train_init(pseg_engine* h, float beta1, float beta2, float eps, float clipnorm, float clipvalue) {
     if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    KnobScope knob_scope(h->e);
     PSEG_HIP(hipSetDevice(h->e.device));
     return train_init(h->e, beta1, beta2, eps, clipnorm, clipvalue);
 }
@@ -1432,6 +1433,7 @@ int pseg_train_set_loss(pseg_engine* h, int loss) {
 
 int pseg_train_forward_backward(pseg_engine* h, const uint8_t* img, const uint8_t* mask, int H, int W, float metrics[4]) {
     if (!h || !img || !mask) return fail(PSEG_EINVAL, "NULL argument");
+    KnobScope knob_scope(h->e);
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     PSEG_TRY(train_fwd_bwd(h->e, img, mask, H, W, true));
     if (metrics) PSEG_TRY(train_metrics(h->e, metrics));
@@ -1440,6 +1442,7 @@ int pseg_train_forward_backward(pseg_engine* h, const uint8_t* img, const uint8_
 
 int pseg_train_forward_backward_f32(pseg_engine* h, const float* img, const uint8_t* mask, int H, int W, float metrics[4]) {
     if (!h || !img || !mask) return fail(PSEG_EINVAL, "NULL argument");
+    KnobScope knob_scope(h->e);
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     PSEG_TRY(train_fwd_bwd(h->e, nullptr, mask, H, W, true, img));
     if (metrics) PSEG_TRY(train_metrics(h->e, metrics));
@@ -1448,6 +1451,7 @@ int pseg_train_forward_backward_f32(pseg_engine* h, const float* img, const uint
 
 int pseg_eval_step(pseg_engine* h, const uint8_t* img, const uint8_t* mask, int H, int W, float metrics[4]) {
     if (!h || !img || !mask || !metrics) return fail(PSEG_EINVAL, "NULL argument");
+    KnobScope knob_scope(h->e);
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     if (!h->e.train) PSEG_TRY(train_init(h->e, 0.9f, 0.999f, 1e-7f, 0.0f, 0.0f));
     PSEG_TRY(train_fwd_bwd(h->e, img, mask, H, W, false));
@@ -1469,6 +1473,7 @@ int pseg_train_metrics(pseg_engine* h, float metrics[4]) {
 
 int pseg_train_apply(pseg_engine* h, float lr, float grad_scale) {
     if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    KnobScope knob_scope(h->e);
     return train_apply(h->e, lr, grad_scale);
 }
 

@@ -20,7 +20,7 @@ def predict_pages_sharded(predict_fn: Callable[[np.ndarray], np.ndarray], pages:
     """Every rank predicts its own pages with `predict_fn(page) -> label map`; with gather=True
     rank 0 returns all label maps in page order (other ranks return None).  Pages may differ
     in size (ragged) and a rank may own no page at all.  Label maps travel as plain tensors, one point-to-point
-    message per page (a label map has its page's shape, which rank 0 knows; nothing is pickled)."""
+    message per page (shapes and dtypes are exchanged first in one small integer table; nothing is pickled)."""
     mine = shard_pages(len(pages), rank, world)
     local = [(i, np.ascontiguousarray(predict_fn(pages[i]))) for i in mine]
     if world == 1:
@@ -31,12 +31,22 @@ def predict_pages_sharded(predict_fn: Callable[[np.ndarray], np.ndarray], pages:
     import torch.distributed as dist
     on_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    dtype = local[0][1].dtype if local else None
-    # every rank tells rank 0 the dtype code of its maps (a rank may own no page)
-    code = torch.tensor([{None: 0, np.dtype(np.uint8): 1, np.dtype(np.int64): 2}.get(np.dtype(dtype) if dtype is not None else None, 3)],
-                        dtype=torch.int64, device=dev)
-    codes = [torch.zeros_like(code) for _ in range(world)] if rank == 0 else None
-    dist.gather(code, codes, dst=0)
+    # Every rank publishes (height, width, dtype code) of each of its label maps BEFORE any map travels: rank 0 sizes
+    # its receive buffers from what the sender really holds (a predict_fn may rescale its output, e.g. high_res_output),
+    # and an unsupported dtype makes EVERY rank raise together instead of leaving the senders blocked in dist.send.
+    dcode = {np.dtype(np.uint8): 1, np.dtype(np.int64): 2, np.dtype(np.int32): 3}
+    meta = torch.zeros((len(pages), 3), dtype=torch.int64, device=dev)
+    for i, lab in local:
+        if lab.ndim != 2:
+            meta[i] = torch.tensor([0, 0, -1], dtype=torch.int64)
+        else:
+            meta[i] = torch.tensor([lab.shape[0], lab.shape[1], dcode.get(lab.dtype, -1)], dtype=torch.int64)
+    dist.all_reduce(meta, op=dist.ReduceOp.SUM)      # disjoint rows per rank: the sum is the table
+    meta_h = meta.cpu().numpy()
+    bad = [i for i in range(len(pages)) if meta_h[i, 2] not in (1, 2, 3)]
+    if bad:
+        raise ValueError("page(s) %r: label maps must be 2-D uint8 / int32 / int64 arrays (rank %d sends page %d)"
+                         % (bad, bad[0] % world, bad[0]))
     if rank != 0:
         for _, lab in local:
             dist.send(torch.from_numpy(lab).to(dev), dst=0)
@@ -44,15 +54,12 @@ def predict_pages_sharded(predict_fn: Callable[[np.ndarray], np.ndarray], pages:
     out: List[Optional[np.ndarray]] = [None] * len(pages)
     for i, lab in local:
         out[i] = lab
-    tdt = {1: torch.uint8, 2: torch.int64}
+    tdt = {1: torch.uint8, 2: torch.int64, 3: torch.int32}
     for i in range(len(pages)):                      # page order = interleaved rank order: every sender's queue is drained in its send order
         r = i % world
         if r == 0:
             continue
-        c = int(codes[r].item())
-        if c not in tdt:
-            raise ValueError("rank %d sends label maps of an unsupported dtype" % r)
-        buf = torch.empty(tuple(pages[i].shape[:2]), dtype=tdt[c], device=dev)
+        buf = torch.empty((int(meta_h[i, 0]), int(meta_h[i, 1])), dtype=tdt[int(meta_h[i, 2])], device=dev)
         dist.recv(buf, src=r)
         out[i] = buf.cpu().numpy()
     return out  # type: ignore[return-value]

@@ -65,3 +65,31 @@ def test_library_links_no_vendor_gemm():
     import pseg_amd
     out = subprocess.run(["ldd", pseg_amd.lib_path()], capture_output=True, text=True).stdout.lower()
     assert not any(k in out for k in ("hipblas", "rocblas", "miopen")), out
+
+
+def test_release_library_has_no_wrong_result_switches():
+    """Timing ablations that produce wrong results (PSEG_DBG, PSEG_XM_DBG, PSEG_PP_NODMA, PSEG_PP_NOEPI, the in-kernel
+    trace stamps) are compiled into the diagnostic build only (PSEG_DIAG_KNOB is a constant nullptr in the release
+    library): the release .so does not even contain their names, so no environment can switch them on."""
+    import pseg_amd
+    blob = open(pseg_amd.lib_path(), "rb").read()
+    for name in (b"PSEG_PP_NODMA", b"PSEG_PP_NOEPI", b"PSEG_XM_DBG", b"PSEG_DBG\0", b"PSEG_WS_TRACE", b"PSEG_TRACE\0"):
+        assert name not in blob, name
+    src = open(os.path.join(ROOT, "page-segmentation_amd", "csrc", "pseg_common.h")).read()
+    assert "#define PSEG_DIAG_KNOB(name) ((const char*)nullptr)" in src
+
+
+def test_reciprocal_pixel_index_is_exact_for_every_channel_count():
+    """conv1x1_exact_kernel splits a flat element index e < 256*C into (pixel, channel) with a reciprocal multiply,
+    floor(e * (2^32 // C + 1) / 2^32); exact for every per-source channel count the launch gate admits (<= 127).  (A
+    20-bit reciprocal was wrong for C in 73..127 -- ADVICE round 2.)  conv_exact_mfma_kernel's staging keeps the 20-bit
+    form under its own gate: C < 64 and e < 67 * 64."""
+    import numpy as np
+    for C in range(1, 128):
+        e = np.arange(256 * C, dtype=np.uint64)
+        inv = np.uint64((1 << 32) // C + 1)
+        assert np.array_equal((e * inv) >> np.uint64(32), e // np.uint64(C)), C
+    for C in range(1, 64):
+        e = np.arange(67 * 64, dtype=np.uint64)
+        inv = np.uint64((1 << 20) // C + 1)
+        assert np.array_equal((e * inv) >> np.uint64(20), e // np.uint64(C)), C

@@ -29,7 +29,17 @@ def _predict(page):
     return np.argmax(oracle.forward("fcn", Wt, page), -1)
 
 
-def _worker(rank, world, port, q):
+def _predict_rescaled(page):
+    """A predict_fn whose label map does not have its page's shape (Predictor with high_res_output rescales)."""
+    lab = _predict(page)
+    return np.repeat(np.repeat(lab, 2, 0), 3, 1).astype(np.uint8)
+
+
+def _predict_bad_dtype(page):
+    return _predict(page).astype(np.float32)
+
+
+def _worker(rank, world, port, q, fn_name="_predict"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "page-segmentation_amd")]
@@ -38,7 +48,19 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pages = _pages()
-    out = predict_pages_sharded(_predict, pages, rank, world)
+    fn = globals()[fn_name]
+    if fn_name == "_predict_bad_dtype":
+        # every rank must raise (nobody is left blocked in a send): the barrier below is reached by both
+        try:
+            predict_pages_sharded(fn, pages, rank, world)
+            raised = False
+        except ValueError:
+            raised = True
+        dist.barrier()
+        q.put((rank, raised))
+        dist.destroy_process_group()
+        return
+    out = predict_pages_sharded(fn, pages, rank, world)
     dist.barrier()
     if rank == 0:
         q.put([o.tolist() for o in out])
@@ -47,21 +69,40 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_page_sharding_matches_single_process(oracle_mod):
+def _run_two_ranks(fn_name, n_results=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, fn_name)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=240)
+    got = [q.get(timeout=240) for _ in range(n_results)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return got
+
+
+def test_two_rank_page_sharding_matches_single_process(oracle_mod):
+    got = _run_two_ranks("_predict")[0]
     want = [_predict(p) for p in _pages()]
     assert len(got) == len(want)
     for g, w_ in zip(got, want):
         assert np.array_equal(np.array(g), w_)
+
+
+def test_two_rank_gather_takes_the_senders_shape_and_dtype(oracle_mod):
+    """Label maps that do not have their page's shape (a rescaling predict_fn) arrive intact: rank 0 sizes its receive
+    buffers from the table the ranks exchange first, not from the page."""
+    got = _run_two_ranks("_predict_rescaled")[0]
+    want = [_predict_rescaled(p) for p in _pages()]
+    for g, w_ in zip(got, want):
+        assert np.array_equal(np.array(g, dtype=np.uint8), w_)
+
+
+def test_two_rank_gather_rejects_a_bad_dtype_on_every_rank(oracle_mod):
+    got = dict(_run_two_ranks("_predict_bad_dtype", n_results=2))
+    assert got == {0: True, 1: True}
 
 
 # ---- data-parallel train step (SURVEY.md 8e): sum of flat gradients over ranks, 1/world at apply -------

@@ -4,10 +4,11 @@
 One "step" = one pass of the predict hot path (x/255 -> pad -> fcn_skip -> crop -> logits ->
 argmax) over `--pages` synthetic pages per rank, inputs already resident in HBM, uint8 label
 maps left in HBM (the task's measurement contract; the host-buffer / PCIe-inclusive rate of the
-drop-in boundary is reported next to it under `extra.host_path`, never as `value`).  N=1 runs
-BASELINE.json configs[1] (single 2048x1536 page, 3 classes, bf16 activations).  N>1: one
-process per GPU, independent pages per rank, no data-path collective (weak scaling); value =
-pixels of all ranks / max-over-ranks time.
+drop-in boundary -- SURVEY.md 8d's "uint8 page in pinned host memory -> label map in host memory" -- is
+reported next to it at the top level as `value_host_path` and in detail under `extra.host_path`, never as
+`value`).  N=1 runs BASELINE.json configs[1] (single 2048x1536 page, 3 classes, bf16 activations).  N>1:
+one process per GPU, BASELINE.json configs[2]'s shape -- 32 independent pages per rank per step (`--pages`),
+no data-path collective (weak scaling); value = pixels of all ranks / max-over-ranks time.
 
 `python bench.py --gpus N` with WORLD_SIZE unset starts the N rank processes itself (a parent
 that never touches the GPU spawns fresh children with RANK / LOCAL_RANK / WORLD_SIZE set and
@@ -16,7 +17,8 @@ relays rank 0's line); under torchrun (WORLD_SIZE set) the process is one rank.
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, algorithmic FLOPs / HIP-event
 duration measured here), `cpu_baseline` (the float32 restatement on torch-CPU / oneDNN at n = all
 cores and n = 1; the reference's TensorFlow path cannot run offline) and
-`extra` (host path from pinned memory, label-exact mode, unet, configs[4] pipeline).
+`extra` (host path from pinned memory, float32 engine, configs[3] train step, label-exact mode, unet, res_unet,
+configs[4] pipeline, the drop-in Predictor chain).
 """
 import argparse
 import json
@@ -45,10 +47,13 @@ def parse_args(argv=None):
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--width", type=int, default=1536)
-    ap.add_argument("--pages", type=int, default=1, help="pages per rank per step")
+    ap.add_argument("--pages", type=int, default=None, help="pages per rank per step (default: 1 at --gpus 1 = configs[1]; 32 at --gpus N > 1 = configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.* legs (host path, unet, configs[4], label-exact)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.pages is None:
+        args.pages = 1 if args.gpus <= 1 else 32
+    return args
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -209,10 +214,101 @@ def leg_config5(torch, np, pseg_amd, synth, dev):
     return res
 
 
+def leg_f32(torch, pseg_amd, synth, weights, d_img, H, W, C, dev, arch):
+    """The float32 engine (PSEG_MODE_F32_EXACT: the bit-exact referee, the default of the drop-in Network, and the cost of a
+    whole-page referee in the label-exact mode) on the same page and weights: ms/page and fraction of the 157.3 TFLOP/s
+    float32 MFMA peak on the algorithmic FLOPs."""
+    e32 = pseg_amd.Engine(arch, C, device=dev.index, mode=pseg_amd.MODE_F32_EXACT)
+    e32.set_weights(weights)
+    lab = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    fn = lambda: e32.predict_device(d_img.data_ptr(), H, W, d_labels_u8=lab.data_ptr(), stream=st)
+    t = _sync_time(torch, fn, 5, warm=2)
+    e32.timing_enable(True)
+    e32.timing_reset()
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize(dev)
+    slots = [s for s in e32.timing() if s[2] > 0]
+    e32.timing_enable(False)
+    res = {"ms_per_page": round(t * 1e3, 4), "Mpixels_s": round(H * W / t / 1e6, 1),
+           "whole_net_frac_f32_peak": round(e32.flops_per_pixel() * H * W / t / 1e12 / PEAK_TFLOPS["f32"], 5),
+           "per_kernel_ms": {s[0]: round(s[1] / s[2], 5) for s in slots},
+           "what": "PSEG_MODE_F32_EXACT, %dx%d, %s, uint8 labels left in HBM; peak 157.3 TFLOP/s (dense f32 MFMA)" % (H, W, arch)}
+    e32.close()
+    return res
+
+
+def leg_train(torch, np, pseg_amd, synth, H, W, C, dev, arch, steps=10, warm=2):
+    """BASELINE.json configs[3] on one rank: float32 train step (forward, loss + metrics, backward, per-tensor clipnorm 1,
+    Adam lr 1e-4) on synthetic 2048x1536 pages with synthetic masks, batch of one page as the reference
+    (lib/network.py:235-241).  Fraction of the float32 MFMA peak on 3 x the forward FLOPs."""
+    e = pseg_amd.Engine(arch, C, device=dev.index, mode=pseg_amd.MODE_F32_EXACT)
+    e.set_weights(synth.glorot_weights(e.weight_specs(), seed=42))
+    e.train_init(clipnorm=1.0)
+    pages = [synth.synth_page(2000 + i, H, W, C) for i in range(2)]
+    losses = []
+
+    def step(i):
+        img, _, mask = pages[i % len(pages)]
+        m = e.train_forward_backward(img, mask)
+        e.train_apply(1e-4, 1.0)
+        losses.append(float(m[0]))
+
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    torch.cuda.synchronize(dev)
+    t = (time.perf_counter() - t0) / steps
+    res = {"ms_per_step": round(t * 1e3, 3), "steps_per_s": round(1.0 / t, 2), "Mpixels_s": round(H * W / t / 1e6, 1),
+           "frac_f32_peak": round(3.0 * e.flops_per_pixel() * H * W / t / 1e12 / PEAK_TFLOPS["f32"], 5),
+           "loss_first": round(losses[0], 5), "loss_last": round(losses[-1], 5), "steps": steps + warm,
+           "what": "configs[3] on one rank: %s %d-class train step on %dx%d synthetic pages / masks, batch of one page, "
+                   "Adam lr 1e-4 + clipnorm 1, host uint8 page + mask in, 4 metrics out (PCIe included); "
+                   "FLOPs = 3 x forward" % (arch, C, H, W)}
+    e.close()
+    return res
+
+
+def leg_api_path(np, pseg_amd, synth, dev):
+    """The drop-in chain a caller of the reference API gets (lib/predictor.py:32-54): Predictor.predict_masks on a
+    4096x3072 6-class page with the cc_majority post-processor -- predict, vote and generate_output_masks stay on the device,
+    label map and the four masks come down once."""
+    from ocr4all_pixel_classifier.lib.predictor import Predictor
+    from ocr4all_pixel_classifier.lib.predictor_data import PredictSettings
+    from ocr4all_pixel_classifier.lib.dataset import SingleData
+    from ocr4all_pixel_classifier.lib.network import Network
+    from ocr4all_pixel_classifier.lib.postprocess import vote_connected_component_class
+    H, W, C = 4096, 3072, 6
+    img, binary, _ = synth.synth_page(1000, H, W, C)
+    net = Network("Predict", n_classes=C, exact=False, device=dev.index)
+    net.model.set_weights(synth.glorot_weights(net.model.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    cm = ColorMap({(255, 255, 255): (0, "bg"), (255, 0, 0): (1, "a"), (0, 255, 0): (2, "b"), (0, 0, 255): (3, "c"),
+                   (255, 255, 0): (4, "d"), (0, 255, 255): (5, "e")})
+    settings = PredictSettings(n_classes=C, network=None, output=None, color_map=cm, post_process=[vote_connected_component_class])
+    pred = Predictor(settings, network=net)
+    data = SingleData(image=img, binary=binary, original_shape=img.shape, image_path="p.png")
+    pred.predict_masks(data)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        masks = pred.predict_masks(data)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    t = ts[len(ts) // 2]
+    return {"predict_masks_ms": round(t * 1e3, 3), "Mpixels_s": round(H * W / t / 1e6, 1),
+            "what": "Predictor.predict_masks (lib/predictor.py:44-54) at 4096x3072x6 with cc_majority, NumPy page in, the four "
+                    "(H,W,3) masks out as NumPy arrays (37.7 MB each over PCIe); median of 5"}
+
+
 def leg_cpu_baseline(np, weights, page, arch):
     """the float32 restatement of the predict path on torch-CPU (oneDNN convolutions), 3 warm-ups
-    + median of 10, at n = all cores on the full page and at n = 1 on a 512x512 crop (configs[0]'s size) so that the
-    whole leg stays within ~30 s of CPU work.  The C oracle (sequential-fmaf port) is timed once on 256 rows."""
+    + median of 10 for both, at n = all cores on the full page and at n = 1 on a 512x512 crop (configs[0]'s size) so that
+    the whole leg stays within ~30 s of CPU work.  The C oracle (sequential-fmaf port) is timed once on 256 rows."""
     import torch
     import oracle
     from oracle import torch_cpu
@@ -243,7 +339,7 @@ def leg_cpu_baseline(np, weights, page, arch):
     big = page if probe * (H * W) / (512 * 512) < 2.0 else page[:1024, :768].copy()
     t_all = torch_cpu.time_predict(arch, weights, np.ascontiguousarray(big), ncores, warmup=3, reps=10)
     small = np.ascontiguousarray(page[:512, :512])
-    t_one = torch_cpu.time_predict(arch, weights, small, 1, warmup=1, reps=5)
+    t_one = torch_cpu.time_predict(arch, weights, small, 1, warmup=3, reps=10)
     torch.set_num_threads(ncores)
     oracle.build()
     rows = np.ascontiguousarray(page[:256])
@@ -256,7 +352,7 @@ def leg_cpu_baseline(np, weights, page, arch):
             "sample": "%dx%d page, n=%d threads (fastest of the probed counts; %d cores visible), 3 warm-ups + median of 10 (%.3f s per page)"
                       % (big.shape[0], big.shape[1], ncores, ncores_seen, t_all),
             "n1": {"value": round(small.size / t_one / 1e6, 4), "cores": 1,
-                   "sample": "512x512 crop (configs[0] size), 1 warm-up + median of 5 (%.2f s per page)" % t_one},
+                   "sample": "512x512 crop (configs[0] size), 3 warm-ups + median of 10 (%.2f s per page)" % t_one},
             "oracle_port": {"value": round(rows.size / t_port / 1e6, 4), "cores": oracle.num_threads(),
                             "sample": "rows 0..256 of the page, oracle/pseg_oracle.c (sequential fmaf chains, OpenMP), one pass %.2f s" % t_port}}
 
@@ -379,7 +475,7 @@ def run_rank(args):
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
         # runs, gfx950 correction applied) recorded under profiles/ by tools/pmc_traffic.py -- replayed, not measured here
         traffic, traffic_src = None, None
-        for fn in ("r02_traffic.json", "r01e_traffic.json"):
+        for fn in ("r03_traffic.json", "r02_traffic.json", "r01e_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     tr = json.load(f).get(name)
@@ -393,7 +489,10 @@ def run_rank(args):
                 "traffic_unit": "HBM bytes per launch, replayed from profiles/%s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)" % traffic_src,
                 "avg_ms": round(avg_ms, 5), "launches": int(n),
                 "flop_per_launch": flops,
-                "whole_net_frac": round(eng.flops_per_pixel() * H * W / (total_ms * 1e-3) / 1e12 / peak, 5),
+                "whole_net_frac": round(eng.flops_per_pixel() * H * W / (dt / args.steps / args.pages) / 1e12 / peak, 5),
+                "whole_net_frac_what": "algorithmic FLOPs of the page / ms_per_step (the timed region); per_kernel_ms is a separate pass "
+                                       "with event timing on, whose sum prices whole_net_frac_kernel_sum",
+                "whole_net_frac_kernel_sum": round(eng.flops_per_pixel() * H * W / (total_ms * 1e-3) / 1e12 / peak, 5),
                 "per_kernel_ms": {s[0]: round(s[1] / s[2], 5) for s in slots}}
         ksize = {n.split("/")[0]: sh[0] for n, sh in eng.weight_specs() if n.endswith("kernel")}
         k3 = [s for s in slots if ksize.get(s[0]) == 3 and s[3] > 1e10]
@@ -406,10 +505,13 @@ def run_rank(args):
         default_cfg = (H, W, C, args.arch, args.mode) == (2048, 1536, 3, "fcn_skip", "bf16")
         if not args.no_extra and default_cfg:
             for key, fn in (("host_path", lambda: leg_host_path(np, pseg_amd, eng, synth, H, W, C)),
+                            ("f32", lambda: leg_f32(torch, pseg_amd, synth, weights, pages[0], H, W, C, dev, args.arch)),
+                            ("train", lambda: leg_train(torch, np, pseg_amd, synth, H, W, C, dev, args.arch)),
                             ("label_exact", lambda: leg_label_exact(torch, np, pseg_amd, eng, pages[0], H, W, dev, synth, C, args.arch)),
                             ("unet", lambda: leg_arch(torch, pseg_amd, synth, "unet", H, W, C, dev)),
                             ("res_unet", lambda: leg_arch(torch, pseg_amd, synth, "res_unet", H, W, C, dev)),
-                            ("config5", lambda: leg_config5(torch, np, pseg_amd, synth, dev))):
+                            ("config5", lambda: leg_config5(torch, np, pseg_amd, synth, dev)),
+                            ("api_path", lambda: leg_api_path(np, pseg_amd, synth, dev))):
                 try:
                     extra[key] = fn()
                 except Exception as ex:   # an extra leg must not take the headline line down with it
@@ -434,14 +536,23 @@ def run_rank(args):
             "vs_baseline": None,
             "dtype": args.mode,
             "data": "synthetic pages (numpy default_rng(1000+i)), glorot random-init weights (default_rng(42))",
-            "config": {"workload": "configs[1]: single %dx%d page, %d-class %s predict, inputs resident in HBM, uint8 label maps left in HBM "
-                                   "(value = HBM-resident rate per the measurement contract; host-buffer rate under extra.host_path)"
-                                   % (H, W, C, args.arch),
+            "config": {"workload": (("configs[1]: single %dx%d page, %d-class %s predict" % (H, W, C, args.arch)) if world == 1 and args.pages == 1 else
+                                    ("configs[2] shape: %d independent %dx%d pages per rank per step, %d-class %s predict, page-parallel, "
+                                     "no data-path collective" % (args.pages, H, W, C, args.arch)))
+                                   + ", inputs resident in HBM, uint8 label maps left in HBM (value = HBM-resident rate per the measurement "
+                                     "contract; SURVEY 8d's pinned-host-in / host-out rate is value_host_path)",
                        "pages_per_rank_per_step": args.pages, "parallelism": "page-parallel x%d" % world},
             "roofline": roof,
             "cpu_baseline": cpu,
             "extra": extra,
         }
+        hp = extra.get("host_path") if isinstance(extra.get("host_path"), dict) else None
+        if hp and "uint8" in hp:
+            # SURVEY.md 8d's boundary metric, named at the top level next to the HBM-resident `value`
+            out["value_host_path"] = {"value": hp["uint8"]["Mpixels_s"], "unit": "Mpixels/s", "ms_per_page": hp["uint8"]["ms_per_page"],
+                                      "what": "SURVEY 8d: uint8 pages in pinned host memory -> uint8 label maps in pinned host memory, "
+                                              "pseg_predict_batch (PCIe both ways, overlapped with compute); int64 labels: extra.host_path.int64"}
+            extra["hbm_resident"] = {"Mpixels_s": out["value"], "ms_per_page": round(dt / args.steps / args.pages * 1e3, 4)}
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

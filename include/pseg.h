@@ -104,14 +104,20 @@ int pseg_predict_batch(pseg_engine* e, int n_pages, const uint8_t* const* imgs, 
 /* Label-exact throughput mode (lib/network.py:259: argmax of the float32 logits).  A bf16 engine's label map differs
  * from the float32 engine's only at near-ties of the two largest logits.  pseg_predict_margin_device runs the graph
  * and also writes the margin map (float32 (H,W): top-1 minus top-2 logit; labels_u8 optional).
- * pseg_predict_exact_labels_device returns the float32 engine's label map: bf16 pass + margin, then the 64x64 blocks
- * that hold a pixel with margin < tau are re-evaluated, with their receptive-field halo, by a float32 companion
- * engine (bit-exact referee, same weights).  tau = 4 x the bf16 path's measured logit error on a calibration crop
- * and doubles whenever a refereed block shows a flipped pixel above it; pages whose flagged blocks cover most of the
- * area go through the float32 engine whole.  Synchronises `stream` internally (the flag map is read by the host).
+ * pseg_predict_exact_labels_device aims at the float32 engine's label map at a fraction of its cost: bf16 pass +
+ * margin, then the 32x32 blocks that hold a pixel with margin < tau are grouped into rectangles by a cost model and
+ * re-evaluated, with their receptive-field halo, by a float32 companion engine (the bit-exact referee, same weights);
+ * when the crops would cost more than one float32 pass over the page, the page goes through the float32 engine whole.
+ * CALIBRATED, NOT PROVEN: tau starts at 4 x the bf16 path's measured logit error on three calibration crops and is
+ * kept >= 2 x the largest change of a margin seen on ANY refereed pixel since the last weight change (every crop is
+ * also a measurement; sentinel blocks are refereed on every page; an unflagged pixel that flips doubles tau) -- an
+ * unflagged pixel outside every refereed rectangle is trusted on that evidence.  PSEG_MODE_F32_EXACT is the only mode
+ * that is bit-exact by construction.  Synchronises `stream` internally (the flag map is read by the host).
  * d_labels (int64) and d_margin are optional outputs.  pseg_label_exact_stats: {tau, calibration logit error,
  * flagged pixel fraction, refereed block fraction, refereed area (with halos) / page area, tau escalations,
- * whole-page fallback (0/1), labels changed by the referee} of the last call. */
+ * whole-page fallback (0/1), labels changed by the referee} of the last call; pseg_label_exact_stats_ex appends
+ * {running margin error, rectangles refereed, cost-model price of the crops / price of the whole page, block edge}
+ * (`cap` doubles are written). */
 int pseg_predict_margin_device(pseg_engine* e, const uint8_t* d_img, int H, int W, uint8_t* d_labels_u8,
                                float* d_margin, void* stream);
 int pseg_predict_exact_labels_device(pseg_engine* e, const uint8_t* d_img, int H, int W, uint8_t* d_labels_u8,
@@ -119,6 +125,7 @@ int pseg_predict_exact_labels_device(pseg_engine* e, const uint8_t* d_img, int H
 /* Host-buffer form (Network.predict_single_data's `pred`, lib/network.py:259): either output may be NULL, not both. */
 int pseg_predict_exact_labels(pseg_engine* e, const uint8_t* img, int H, int W, int64_t* labels, uint8_t* labels_u8);
 int pseg_label_exact_stats(const pseg_engine* e, double out[8]);
+int pseg_label_exact_stats_ex(const pseg_engine* e, double* out, int cap);
 
 /* Page-locked host memory for the host-buffer entries ("uint8 page in pinned host memory -> label
  * map in host memory").  Pages and label maps that live in buffers from pseg_host_alloc, or in caller memory

@@ -50,8 +50,10 @@ class Network:
         :param device: HIP device index (keyword-only extension)
         :param exact: arithmetic of predict (keyword-only extension).  True (default, as the reference computes in
                       float32): float32 sequential-fmaf engine, bit-identical to the CPU oracle; 'labels': bf16 MFMA
-                      throughput engine with the float32 referee on near-ties -- `pred` equals the float32 engine's,
-                      logits / probabilities carry bf16 accuracy; False: bf16 throughput engine alone (label maps may
+                      throughput engine with the float32 referee on near-ties -- `pred` is the float32 engine's wherever
+                      the referee looked and wherever the bf16 margin exceeds a threshold CALIBRATED (not proven) against
+                      the float32 engine on every refereed crop; logits / probabilities carry bf16 accuracy.  exact=True
+                      is the only mode that is bit-exact by construction.  False: bf16 throughput engine alone (label maps may
                       differ from float32 at near-ties of the two largest logits).  None reads PSEG_NETWORK_MODE
                       ('f32' default, 'bf16').
         """

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = (
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
     "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
     "pseg_host_alloc", "pseg_host_free", "pseg_host_register", "pseg_host_unregister",
-    "pseg_predict_margin_device", "pseg_predict_exact_labels_device", "pseg_predict_exact_labels", "pseg_label_exact_stats",
+    "pseg_predict_margin_device", "pseg_predict_exact_labels_device", "pseg_predict_exact_labels", "pseg_label_exact_stats", "pseg_label_exact_stats_ex",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
     "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_set_loss", "pseg_train_set_dropout_seed", "pseg_train_forward_backward", "pseg_train_forward_backward_f32", "pseg_train_grad_buffer", "pseg_train_metrics",
     "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
@@ -69,6 +69,7 @@ def lib():
     L.pseg_predict_exact_labels_device.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
     L.pseg_predict_exact_labels.argtypes = [vp, vp, i, i, vp, vp]
     L.pseg_label_exact_stats.argtypes = [vp, c.POINTER(c.c_double)]
+    L.pseg_label_exact_stats_ex.argtypes = [vp, c.POINTER(c.c_double), i]
     L.pseg_host_alloc.argtypes = [c.POINTER(vp), c.c_size_t]
     L.pseg_host_free.argtypes = [vp]
     L.pseg_host_register.argtypes = [vp, c.c_size_t]
@@ -256,8 +257,9 @@ class Engine:
                                                 ctypes.c_void_p(d_margin), ctypes.c_void_p(stream or None)))
 
     def predict_exact_labels_device(self, d_img, H, W, d_labels_u8, d_labels=0, d_margin=0, stream=0):
-        """Label-exact throughput mode: the uint8 label map equals the float32 engine's (bf16 pass + margin map,
-        float32 referee on the blocks that hold near-ties).  Synchronises the stream."""
+        """Label-exact throughput mode: bf16 pass + margin map, float32 referee on the blocks that hold near-ties; the
+        uint8 label map is the float32 engine's wherever the referee looked and wherever the bf16 margin exceeds the
+        calibrated threshold (calibrated, not proven: mode=MODE_F32_EXACT is the only bit-exact mode).  Synchronises the stream."""
         _check(lib().pseg_predict_exact_labels_device(self._h, ctypes.c_void_p(d_img), int(H), int(W), ctypes.c_void_p(d_labels_u8),
                                                       ctypes.c_void_p(d_labels or None), ctypes.c_void_p(d_margin or None),
                                                       ctypes.c_void_p(stream or None)))
@@ -276,12 +278,13 @@ class Engine:
         return out
 
     def label_exact_stats(self):
-        """Statistics of the last predict_exact_labels_device call."""
-        v = (ctypes.c_double * 8)()
-        _check(lib().pseg_label_exact_stats(self._h, v))
+        """Statistics of the last predict_exact_labels[_device] call."""
+        v = (ctypes.c_double * 12)()
+        _check(lib().pseg_label_exact_stats_ex(self._h, v, 12))
         return {"tau": float(v[0]), "calib_logit_err": float(v[1]), "flagged_px_frac": float(v[2]), "referee_tile_frac": float(v[3]),
                 "referee_area_frac": float(v[4]), "tau_escalations": int(v[5]), "whole_page_fallback": int(v[6]),
-                "labels_changed": int(v[7])}
+                "labels_changed": int(v[7]), "margin_err_running": float(v[8]), "referee_rects": int(v[9]),
+                "referee_cost_vs_full_page": float(v[10]), "flag_block": int(v[11])}
 
     def predict_batch(self, images, dtype=np.int64, out=None):
         """Label maps of a list of (H,W) uint8 pages (sizes may differ); copies overlap compute.

@@ -389,3 +389,29 @@ def test_bf16_transposed_conv_behind_its_producer(gpu, oracle_mod, monkeypatch, 
     assert _check_labels(l1, z1, z0)[0] == 0
     z_o = oracle_mod.forward(arch, Wt, img, "f32")
     assert np.abs(z1 - z_o).max() <= TOL * max(1.0, np.abs(z_o).max())
+
+
+def test_engines_keep_their_own_knob_snapshot(gpu, oracle_mod, monkeypatch):
+    """The PSEG_* developer knobs are snapshotted per engine at creation: an engine created earlier keeps working, bit for
+    bit, after the environment changed and ANOTHER engine was created under it (launch-time reads used to
+    follow the newest snapshot, so engine A's conv1+conv2 launch failed once engine B existed under PSEG_NO_WS), and the
+    later engine really runs under its own knobs."""
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=5, gain=1.5, bias_scale=0.05)
+    img = np.random.default_rng(5).integers(0, 256, size=(160, 96), dtype=np.uint8)
+    a = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
+    a.set_weights(Wt)
+    za, _, la = a.predict(img, want_probs=False)
+    for k in ("PSEG_NO_WS", "PSEG_NO_PERSIST", "PSEG_NO_TAIL2", "PSEG_NO_SKIPLOG"):
+        monkeypatch.setenv(k, "1")
+    b = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
+    b.set_weights(Wt)
+    zb, _, lb = b.predict(img, want_probs=False)
+    act_b = b.activation("conv2d_1")                 # materialised under PSEG_NO_SKIPLOG: engine b reads ITS snapshot
+    za2, _, la2 = a.predict(img, want_probs=False)    # engine a: planned with skip-logits fusion, must still launch that way
+    assert np.array_equal(za, za2) and np.array_equal(la, la2)
+    with pytest.raises(gpu.PsegError):
+        a.activation("conv2d_1")                      # ... its conv2 tensor is still fused away
+    assert act_b.shape[-1] == 30
+    assert np.abs(zb - za).max() <= 2e-2 * max(1.0, float(np.abs(za).max()))
+    a.close()
+    b.close()

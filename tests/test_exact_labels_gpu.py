@@ -65,12 +65,12 @@ def test_label_exact_small_pages_every_graph(gpu, oracle_mod, arch, C, shape):
 
 
 def test_label_exact_full_page_random_weights(gpu, oracle_mod):
-    """configs[1] page, glorot weights: random-init logits are near-tied nearly everywhere, the referee may
-    take the whole page -- the result must still be the float32 map."""
+    """configs[1] page, glorot weights: random-init logits are near-tied nearly everywhere: the cost model
+    must hand the whole page to the float32 engine (whole_page_fallback == 1) -- and the result is the float32 map."""
     from pseg_amd import synth
     img = synth.synth_page(0, 2048, 1536, 3)[0]
     Wt = synth.glorot_weights(gpu.Engine("fcn_skip", 3).weight_specs(), seed=42, gain=1.5, bias_scale=0.05)
-    stats = _exact_vs_f32(gpu, "fcn_skip", 3, Wt, img)
+    stats = _exact_vs_f32(gpu, "fcn_skip", 3, Wt, img, expect_partial=False)
     assert stats["tau"] > 0 and stats["calib_logit_err"] > 0
 
 
@@ -93,15 +93,72 @@ def _trained_weights(gpu, steps=150):
     return Wt
 
 
+def _sparse_page(seed, H, W, C=3, frac=0.25):
+    """A page with large single-class areas: paper everywhere, the synthetic text / image content only in the top-left
+    `frac` x `frac` of the page (title pages, end-of-chapter pages, margins of every scan)."""
+    from pseg_amd import synth
+    img = synth.synth_page(seed, H, W, C)[0]
+    h, w = int(H * frac) // 32 * 32, int(W * frac) // 32 * 32
+    rng = np.random.default_rng(seed)
+    out = (255 - np.clip(rng.normal(225.0, 8.0, size=(H, W)), 0, 255).astype(np.uint8)).astype(np.uint8)   # synth_page's paper, inverted
+    out[:h, :w] = img[:h, :w]
+    return out
+
+
 def test_label_exact_full_page_trained_weights(gpu):
-    """150-step-trained weights: confident regions keep their bf16 labels, only the blocks along class boundaries go
-    through the referee; the map equals the float32 engine's and the statistics are consistent."""
+    """150-step-trained weights, a full text page: class boundaries run through nearly every block at the line pitch;
+    whichever way the cost model decides, the map equals the float32 engine's and the statistics are consistent."""
     from pseg_amd import synth
     Wt = _trained_weights(gpu)
     img = synth.synth_page(99, 2048, 1536, 3)[0]
     stats = _exact_vs_f32(gpu, "fcn_skip", 3, Wt, img)
     assert 0.0 <= stats["flagged_px_frac"] <= 1.0 and 0.0 <= stats["referee_tile_frac"] <= 1.0
-    print("label-exact, trained weights, 2048x1536:", stats)
+    assert stats["margin_err_running"] >= 0.0 and stats["tau"] >= 2.0 * stats["margin_err_running"] - 1e-6
+    print("label-exact, trained weights, text page 2048x1536:", stats)
+
+
+def test_label_exact_partial_referee_on_a_page_with_large_single_class_areas(gpu):
+    """The PARTIAL path at BASELINE.json's page size: trained weights, content in a quarter of the page's width and
+    height -- the referee must NOT take the whole page (whole_page_fallback == 0), must re-evaluate well under half of
+    it, and the merged map must equal the float32 engine's everywhere (np.array_equal)."""
+    Wt = _trained_weights(gpu, steps=300)
+    img = _sparse_page(7, 2048, 1536)
+    stats = _exact_vs_f32(gpu, "fcn_skip", 3, Wt, img, expect_partial=True)
+    assert stats["whole_page_fallback"] == 0, stats
+    assert 0.0 < stats["referee_area_frac"] < 0.5, stats
+    assert stats["referee_rects"] >= 1 and stats["referee_cost_vs_full_page"] < 1.0, stats
+    assert stats["tau"] >= 2.0 * stats["margin_err_running"] - 1e-6
+    print("label-exact, partial referee, 2048x1536:", stats)
+
+
+def test_label_exact_threshold_follows_the_running_margin_error(gpu):
+    """Every refereed crop is a measurement: after a page has been refereed in parts the threshold is at least twice the
+    largest margin change the referee saw, and it stays that high on the next page (until the weights change)."""
+    torch = _torch()
+    Wt = _trained_weights(gpu, steps=300)
+    dev = torch.device("cuda:0")
+    eb = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
+    eb.set_weights(Wt)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    taus = []
+    for seed in (11, 12):
+        img = _sparse_page(seed, 1024, 768, frac=0.4)
+        d_img = torch.from_numpy(img).to(dev)
+        lab = torch.empty(img.shape, dtype=torch.uint8, device=dev)
+        eb.predict_exact_labels_device(d_img.data_ptr(), img.shape[0], img.shape[1], lab.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        s = eb.label_exact_stats()
+        assert s["tau"] >= 2.0 * s["margin_err_running"] - 1e-6 and s["margin_err_running"] > 0, s
+        taus.append((s["tau"], s["margin_err_running"]))
+    assert taus[1][1] >= taus[0][1] and taus[1][0] >= taus[0][0], taus      # the running maximum never shrinks between pages
+    eb.set_weights(Wt)                                                       # a weight change resets the evidence
+    img = _sparse_page(13, 1024, 768, frac=0.4)
+    d_img = torch.from_numpy(img).to(dev)
+    lab = torch.empty(img.shape, dtype=torch.uint8, device=dev)
+    eb.predict_exact_labels_device(d_img.data_ptr(), img.shape[0], img.shape[1], lab.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert eb.label_exact_stats()["margin_err_running"] > 0
+    eb.close()
 
 
 def test_label_exact_threshold_escalates_when_too_small(gpu, monkeypatch):

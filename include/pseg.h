@@ -101,6 +101,25 @@ int pseg_predict_device(pseg_engine* e, const uint8_t* d_img, int H, int W, floa
 int pseg_predict_batch(pseg_engine* e, int n_pages, const uint8_t* const* imgs, const int* H,
                        const int* W, int64_t* const* labels, uint8_t* const* labels_u8);
 
+/* ---- Predictor chain: lib/predictor.py:32-54 ---------------------------------------------------------------- */
+
+/* Predictor.predict_single / predict_masks as ONE device-resident call: Network.predict_single_data's argmax labels ->
+ * [scale_to_original_shape (lib/output.py:63-79): order-0 resize of the label map to (Ho, Wo); Ho = 0: none] -> the
+ * post-processors of PredictSettings.post_process in order (PSEG_POST_CC_VOTE = vote_connected_component_class,
+ * PSEG_POST_BBOX = add_bounding_boxes; lib/postprocess.py:9-42) -> [generate_output_masks (lib/output.py:44-60)].
+ * The uint8 label map stays in HBM between the stages; page and binarisation go up once, only the requested outputs
+ * come down (DMA straight into page-locked caller memory).  img: uint8 (H,W[,in_channels]); binary: the ink map the vote
+ * and the masks read, shape = the label map's final shape ((Ho,Wo) if resized, else (H,W)), may be NULL when neither is
+ * asked for; flags: PSEG_CHAIN_EXACT_LABELS runs a bf16 engine's network stage in the label-exact mode.  Outputs (host,
+ * each optional): labels int64 / labels_u8 (final shape), color / overlay / inverted / fg_color (final shape x 3).
+ * Synchronous; <= 256 classes. */
+enum { PSEG_POST_CC_VOTE = 1, PSEG_POST_BBOX = 2 };
+enum { PSEG_CHAIN_EXACT_LABELS = 1 };
+int pseg_predict_chain(pseg_engine* e, const uint8_t* img, int H, int W, int Ho, int Wo, const uint8_t* binary,
+                       const int* post_ops, int n_post, unsigned flags, int64_t* labels, uint8_t* labels_u8,
+                       const uint8_t* lut, int n_lut, uint8_t* color, uint8_t* overlay, uint8_t* inverted,
+                       uint8_t* fg_color);
+
 /* Label-exact throughput mode (lib/network.py:259: argmax of the float32 logits).  A bf16 engine's label map differs
  * from the float32 engine's only at near-ties of the two largest logits.  pseg_predict_margin_device runs the graph
  * and also writes the margin map (float32 (H,W): top-1 minus top-2 logit; labels_u8 optional).
@@ -236,6 +255,9 @@ int pseg_release_workspace(int device);
  * paints its bounding box; higher classes overwrite lower. out may alias nothing. */
 int pseg_bbox_fill(int device, const int64_t* pred, int64_t* out, int H, int W, int n_classes);
 
+/* add_bounding_boxes on the compact uint8 label map, device buffers (d_out must not alias d_pred); synchronises `stream`. */
+int pseg_bbox_fill_device_u8(int device, const uint8_t* d_pred, uint8_t* d_out, int H, int W, int n_classes, void* stream);
+
 /* generate_output_masks (lib/output.py:44-60).  lut: n_lut x 3 uint8 label->RGB
  * (ColorMap.to_rgb_array).  Outputs (H,W,3) uint8; any may be NULL. */
 int pseg_masks(int device, const int64_t* pred, const uint8_t* binary, const uint8_t* lut,
@@ -274,6 +296,10 @@ int pseg_gaussian_kernel(double sigma, double* w, int cap, int* radius);
  * warp of an (H,W) image of elem_bytes-sized pixels (1, 2, 3, 4 or 8) to (Ho,Wo).  Host pointers. */
 int pseg_resize_nearest(int device, const void* src, int H, int W, int elem_bytes, void* dst,
                         int Ho, int Wo);
+
+/* The same gather on device buffers, asynchronous on `stream` (scale_to_original_shape inside the Predictor chain). */
+int pseg_resize_nearest_device(int device, const void* d_src, int H, int W, int elem_bytes, void* d_dst, int Ho, int Wo,
+                               void* stream);
 
 /* scale_image (lib/dataset.py:122-128): bicubic resize of a uint8 or float64 (H,W) plane to a
  * float64 (Ho,Wo) plane, clipped to the input range; Gaussian anti-aliasing (sigma = max(0,

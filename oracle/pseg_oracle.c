@@ -26,9 +26,16 @@
  *   orc_round_bf16      build-defined: bf16 activation mode (round-to-nearest-even)
  *
  * Accumulation order (this is what the f32 "exact" HIP path reproduces bit for bit):
- *   acc = +0;  for ky, for kx, for ci (ascending): acc = fmaf(x, w, acc);  out = acc + bias;
- *   ReLU = max(out, 0).  Out-of-image taps are skipped (== adding an exact zero product to an
- *   accumulator that can never be -0).
+ *   acc = +0;
+ *   for cb in 0, 16, 32, ... (blocks of ORC_CHAIN_BLOCK = 16 input channels of the -- concatenated -- input):
+ *     for ky, for kx, for ci in the block (ascending): acc = fmaf(x, w, acc);
+ *   out = acc + bias;  ReLU = max(out, 0).
+ *   Out-of-image taps are skipped (== adding an exact zero product to an accumulator that can never be -0).
+ * TensorFlow's own float32 summation order is unspecified (Eigen / oneDNN block and vectorise the contraction, and differ
+ * between builds), so ANY fixed order is as faithful to "TF-CPU float32" as any other; this one is chosen because it is
+ * what an LDS-tiled matrix-core kernel can follow at speed (a 16-channel slab of the halo tile per pass: round 3; rounds
+ * 1-2 ran the chain over all channels inside each tap, which forced all-channel tiles).  A layer with <= 16 input
+ * channels, every 1x1 convolution and the k2 s2 transposed convolution (one tap per output) are unchanged by the blocking.
  */
 #include <math.h>
 #include <stdint.h>
@@ -40,6 +47,9 @@
 #endif
 
 #define ORC_MAX_COUT 1024
+#define ORC_CHAIN_BLOCK 16   /* input channels per pass of the accumulation chain (see the header) */
+
+int orc_chain_block(void) { return ORC_CHAIN_BLOCK; }
 
 int orc_abi_version(void) { return 1; }
 
@@ -94,19 +104,22 @@ int orc_conv2d(const float* in, int H, int W, int Cin, const float* w, const flo
         float acc[ORC_MAX_COUT];
         for (int x = 0; x < Wout; ++x) {
             for (int co = 0; co < Cout; ++co) acc[co] = 0.0f;
-            for (int ky = 0; ky < KH; ++ky) {
-                const int iy = y * stride + ky - pt;
-                if (iy < 0 || iy >= H) continue;
-                for (int kx = 0; kx < KW; ++kx) {
-                    const int ix = x * stride + kx - pl;
-                    if (ix < 0 || ix >= W) continue;
-                    const float* px = in + ((int64_t)iy * W + ix) * Cin;
-                    const float* wt = w + (int64_t)(ky * KW + kx) * Cin * Cout;
-                    for (int ci = 0; ci < Cin; ++ci) {
-                        const float xv = px[ci];
-                        const float* wr = wt + (int64_t)ci * Cout;
-                        for (int co = 0; co < Cout; ++co)
-                            acc[co] = __builtin_fmaf(xv, wr[co], acc[co]);
+            for (int cb = 0; cb < Cin; cb += ORC_CHAIN_BLOCK) {
+                const int ce = cb + ORC_CHAIN_BLOCK < Cin ? cb + ORC_CHAIN_BLOCK : Cin;
+                for (int ky = 0; ky < KH; ++ky) {
+                    const int iy = y * stride + ky - pt;
+                    if (iy < 0 || iy >= H) continue;
+                    for (int kx = 0; kx < KW; ++kx) {
+                        const int ix = x * stride + kx - pl;
+                        if (ix < 0 || ix >= W) continue;
+                        const float* px = in + ((int64_t)iy * W + ix) * Cin;
+                        const float* wt = w + (int64_t)(ky * KW + kx) * Cin * Cout;
+                        for (int ci = cb; ci < ce; ++ci) {
+                            const float xv = px[ci];
+                            const float* wr = wt + (int64_t)ci * Cout;
+                            for (int co = 0; co < Cout; ++co)
+                                acc[co] = __builtin_fmaf(xv, wr[co], acc[co]);
+                        }
                     }
                 }
             }

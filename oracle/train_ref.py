@@ -100,7 +100,7 @@ def dropout_key(seed, step, op_index):
     return (base + 0x85EBCA77 * op_index) & 0xFFFFFFFF
 
 
-def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None, float64=False, bn_stats=None):
+def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None, float64=False, bn_stats=None, route_acts=None):
     """unet (lib/model.py:151-203) and res_unet (:237-307) in torch with the reference's cross-entropy (lib/metrics.py:8-9);
     `drop` = (seed, step) enables unet's two Dropout(0.5) layers with the engine's masks (op indices 10 and 13 of the
     engine's op list; masks are laid out over the (H/8, W/8, 512) and (H/16, W/16, 1024) canvases).
@@ -108,6 +108,13 @@ def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None, float64=False, 
     (lib/model.py:265-271) in TRAINING form: batch statistics (biased variance, eps 1e-3); `bn_stats` (a dict), when
     given, receives name -> (batch mean, biased batch variance, samples seen) for the moving-statistics update
     moving -= (moving - batch) * (1 - 0.99), the variance with Bessel's correction.
+    `route_acts` (unet): the float32 oracle's activations (oracle.forward(..., return_acts=True)), which the engine
+    reproduces bit for bit.  A 2x2 max-pool routes its gradient to ONE element of the window; where the two largest values
+    of a window differ by less than float32 rounding, which one wins depends on the summation order of the convolution
+    that produced them, and a referee that picks the other one moves that gradient to a neighbouring pixel (observed:
+    one such window in 5 215 puts 1e-2 relative error on conv2d_5/kernel, every float32 order has its own).  With
+    route_acts the referee takes each window's winner from the float32 activations (first maximum in (0,0), (0,1),
+    (1,0), (1,1) order, as pool_bwd_kernel does), so that only rounding separates it from the engine.
     -> (loss, grads dict in Keras layouts, logits (H,W,C))."""
     import torch
     import torch.nn.functional as F
@@ -129,13 +136,29 @@ def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None, float64=False, 
         y = F.conv2d(x, T[n + "/kernel"].permute(3, 2, 0, 1), T[n + "/bias"], stride=stride)
         return F.relu(y) if relu else y
 
+    last_keep = [None]
+
     def dropped(x, op_index):
+        last_keep[0] = None
         if drop is None:
             return x
         _, c, h, w = x.shape
         keep = dropout_keep(h * w * c, dropout_key(drop[0], drop[1], op_index), 0.5).reshape(h, w, c)
+        last_keep[0] = keep
         m = torch.from_numpy(np.ascontiguousarray(keep.transpose(2, 0, 1)[None]).astype(np.float32))
         return x * m * 2.0
+
+    def pool(x, layer, keep=None):
+        if route_acts is None:
+            return F.max_pool2d(x, 2)
+        a = np.asarray(route_acts[layer], np.float32)
+        if keep is not None:
+            a = a * keep.astype(np.float32) * np.float32(2.0)
+        h, w, c = a.shape
+        win = a.reshape(h // 2, 2, w // 2, 2, c).transpose(0, 2, 4, 1, 3).reshape(h // 2, w // 2, c, 4)
+        idx = torch.from_numpy(win.argmax(-1))[..., None]                     # first maximum, (0,0) (0,1) (1,0) (1,1)
+        xv = x[0].permute(1, 2, 0).reshape(h // 2, 2, w // 2, 2, c).permute(0, 2, 4, 1, 3).reshape(h // 2, w // 2, c, 4)
+        return torch.gather(xv, -1, idx).squeeze(-1).permute(2, 0, 1)[None]
 
     def bn(x, n, relu):
         if bn_stats is not None:
@@ -152,12 +175,14 @@ def graph_loss_and_grads(arch, Wt, image_u8, mask_u8, drop=None, float64=False, 
         t, skips = x, []
         for l in range(5):
             t = conv(t, next(names), 3, True)
-            t = conv(t, next(names), 3, True)
+            second = next(names)
+            t = conv(t, second, 3, True)
+            last_keep[0] = None
             if l == 3: t = dropped(t, 10)
             if l == 4: t = dropped(t, 13)
             if l < 4:
                 skips.append(t)
-                t = F.max_pool2d(t, 2)
+                t = pool(t, second, last_keep[0])
         for l in (3, 2, 1, 0):
             u = conv(up(t), next(names), 2, True)
             t = conv(torch.cat([skips[l], u], 1), next(names), 3, True)

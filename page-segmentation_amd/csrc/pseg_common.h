@@ -76,6 +76,7 @@ struct KnobScope {                                // RAII: knob queries on this 
 #define PSEG_DIAG_KNOB(name) ((const char*)nullptr)
 #endif
 
+constexpr int PSEG_CHAIN_BLOCK = 16;   // float32 mode: input channels per pass of the accumulation chain (oracle/pseg_oracle.c ORC_CHAIN_BLOCK)
 constexpr int PSEG_MAXC = 64;   // classes the train-step metric slots and the wide bf16 logits kernel are sized for
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
@@ -191,6 +192,7 @@ struct Engine {
     void* train = nullptr;   // TrainState (pseg_train.hip), f32 mode only
     void* exact = nullptr;   // ExactState (pseg_exactlabels.hip): float32 companion engine, margin / flag buffers of the label-exact mode
     void* batch = nullptr;   // BatchState (pseg_predict_batch): copy streams, events, two staging slots
+    void* chain = nullptr;   // ChainState (pseg_predict_chain): device buffers of the Predictor chain
     int relaxed_f32 = 0;     // != 0 during a train / eval step: wide float32 layers may run channel-blocked on the matrix cores
     uint32_t drop_key = 0;   // != 0 while a TRAINING forward runs: Dropout layers are live (key = seed / step mix)
     const float* cur_img_f32 = nullptr;   // float32 exact mode: float page (0..255 scale) instead of the uint8 one (augmented training samples)
@@ -249,7 +251,8 @@ void launch_margin_from_logits(const float* d_logits, size_t n, int C, float* d_
 bool mfma_tail_emits_margin(const Engine& e);   // the bf16 graph's tail kernel writes the margin map itself
 int create_engine(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
                   std::shared_ptr<const KnobSnap> inherit, struct ::pseg_engine** out);   // pseg_create_ex; `inherit` = a parent engine's knob snapshot
-void exact_free(Engine& e);                     // label-exact mode state (pseg_exactlabels.hip)
+void exact_free(Engine& e);
+void chain_free(Engine& e);                     // Predictor chain buffers (pseg_chain.hip)                     // label-exact mode state (pseg_exactlabels.hip)
 int set_canvas(Engine& e, int H, int W, hipStream_t st);
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs, int64_t* d_labels,
               uint8_t* d_labels_u8, hipStream_t st);

@@ -1,7 +1,7 @@
 // pseg_engine.hip -- engine object, f32-exact kernels, and the C ABI of include/pseg.h.
 //
 // F32_EXACT mode: every tensor is dense NHWC float32 with its true channel count.  Each output
-// element is one sequential fmaf chain in (ky, kx, ci) order starting from +0, then "+ bias",
+// element is one sequential fmaf chain -- slabs of 16 input channels, (ky, kx, ci) inside a slab -- starting from +0, then "+ bias",
 // then the optional residual add and ReLU -- the same operation sequence as
 // oracle/pseg_oracle.c, so logits (and therefore label maps) are bit-identical to the oracle.
 // This mode is the parity referee; the throughput mode lives in pseg_mfma.hip.
@@ -89,6 +89,7 @@ constexpr int COT = 16;  // output channels per thread in the exact conv kernels
 
 // One thread = one output pixel x COT consecutive output channels.  Weights are indexed only by
 // loop counters and blockIdx, i.e. wave-uniform: hipcc serves them through the scalar cache.
+// Chain order = the oracle's: slabs of PSEG_CHAIN_BLOCK input channels of the concatenated input, inside a slab (ky, kx, ci).
 __global__ __launch_bounds__(256) void conv_exact_kernel(ConvArgs a) {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= a.Hout * a.Wout) return;
@@ -99,31 +100,27 @@ __global__ __launch_bounds__(256) void conv_exact_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < COT; ++j) acc[j] = 0.0f;
 
-    for (int ky = 0; ky < a.KH; ++ky) {
-        const int iy = y * a.stride + ky - a.pt;
-        if (iy < 0 || iy >= a.Hin) continue;
-        for (int kx = 0; kx < a.KW; ++kx) {
-            const int ix = x * a.stride + kx - a.pl;
-            if (ix < 0 || ix >= a.Win) continue;
-            const float* wt = a.w + (size_t)((ky * a.KW + kx) * Cin) * a.Cout + co0;
-            {
-                const float* p = a.src0 + ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0;
-                for (int ci = 0; ci < a.C0; ++ci) {
-                    float xv = p[ci];
+    for (int cb = 0; cb < Cin; cb += PSEG_CHAIN_BLOCK) {
+        const int ce = min(cb + PSEG_CHAIN_BLOCK, Cin);
+        for (int ky = 0; ky < a.KH; ++ky) {
+            const int iy = y * a.stride + ky - a.pt;
+            if (iy < 0 || iy >= a.Hin) continue;
+            for (int kx = 0; kx < a.KW; ++kx) {
+                const int ix = x * a.stride + kx - a.pl;
+                if (ix < 0 || ix >= a.Win) continue;
+                const float* wt = a.w + (size_t)((ky * a.KW + kx) * Cin) * a.Cout + co0;
+                const float* p0 = a.src0 + ((size_t)(iy >> a.up0) * (a.Win >> a.up0) + (ix >> a.up0)) * a.C0;
+                const float* p1 = a.C1 > 0 ? a.src1 + ((size_t)(iy >> a.up1) * (a.Win >> a.up1) + (ix >> a.up1)) * a.C1 : nullptr;
+                for (int ci = cb; ci < ce; ++ci) {
+                    float xv;
+                    if (ci < a.C0) {
+                        xv = p0[ci];
+                        if (a.mask) xv = a.mask[(p0 - a.src0) + ci] > 0.0f ? xv : 0.0f;
+                    } else {
+                        xv = p1[ci - a.C0];
+                    }
                     if (a.in_relu) xv = xv > 0.0f ? xv : 0.0f;
-                    if (a.mask) xv = a.mask[(p - a.src0) + ci] > 0.0f ? xv : 0.0f;
                     const float* wr = wt + (size_t)ci * a.Cout;
-#pragma unroll
-                    for (int j = 0; j < COT; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
-                }
-            }
-            if (a.C1 > 0) {
-                const float* p = a.src1 + ((size_t)(iy >> a.up1) * (a.Win >> a.up1) + (ix >> a.up1)) * a.C1;
-                const float* wt1 = wt + (size_t)a.C0 * a.Cout;
-                for (int ci = 0; ci < a.C1; ++ci) {
-                    float xv = p[ci];
-                    if (a.in_relu) xv = xv > 0.0f ? xv : 0.0f;
-                    const float* wr = wt1 + (size_t)ci * a.Cout;
 #pragma unroll
                     for (int j = 0; j < COT; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);
                 }
@@ -1008,6 +1005,7 @@ int pseg_destroy(pseg_engine* h) {
     if (e.stream) (void)hipStreamSynchronize(e.stream);
     train_free(e);
     exact_free(e);
+    chain_free(e);
     batch_free(e);
     for (auto& t : e.tensors) free_dev(t.d);
     for (auto& op : e.ops) {

@@ -3,22 +3,22 @@
 // v_mfma_f32_16x16x4_f32 accumulates its four k-values as the sequential chain
 // acc = fmaf(a[k], b[k], acc), k = 0..3, and continues the chain across instructions (checked on
 // MI355X by tools/microtests/mfma_f32_chain.hip: 256/256 outputs bitwise equal at K = 100).  With
-// k ordered (ky, kx, ci) -- the oracle's loop order -- this kernel therefore produces the SAME
-// bits as conv_exact_kernel / oracle/pseg_oracle.c, at MFMA rate (157 TFLOP/s f32 peak) instead
-// of one scalar FMA chain per thread:
-//   * out-of-image taps and the channel padding to a multiple of four feed x = 0 (and w = 0):
+// k ordered as the oracle's loop nest -- (block of 16 input channels, ky, kx, ci inside the block), oracle/pseg_oracle.c
+// -- the kernels below therefore produce the SAME bits as the scalar chain, at MFMA rate (157 TFLOP/s f32 peak):
+//   * out-of-image taps and the channel padding of a block to a multiple of four feed x = 0 (and w = 0):
 //     fmaf(0, w, acc) == acc exactly (acc is never -0: it starts at +0);
 //   * then acc + bias (+ residual), ReLU -- the same operation sequence as the scalar kernel.
-// Because the chain runs over ALL input channels inside each tap, the halo tile is staged in LDS
-// with every input channel (float32); layers whose tile does not fit 150 KB even at two output
-// rows per workgroup (unet's 1536-channel concats) stay on the scalar kernel.
+// Round 3: the chain is BLOCKED over the input channels (rounds 1-2 ran it over all channels inside each tap, which
+// forced all-channel LDS tiles: 140 KB for fcn_skip's 120-channel layer, no LDS form at all for unet's 1024).  A
+// workgroup now stages a 16-channel slab of its halo tile (31 KB for a k5 layer: four to five workgroups per CU, so one
+// workgroup's staging hides under the others' MFMAs), runs every tap over it, and moves to the next slab with the
+// accumulators in registers; any channel count fits, predict and train share one order and one kernel.
 //
 // Layout: D[cout][pixel] per 16x16 tile; lane l = (p16 = l & 15, g = l >> 4).
 //   A (weights):  lane holds w[k = 4s + g][cout = 16t + p16]   (global load, L1/L2 resident)
 //   B (pixels):   lane holds x[pixel p16][channel 4s + g]        (ds_read_b32 from the LDS tile)
 //   D:            lane holds couts 16t + 4g .. +3 of pixel p16  (16-byte store)
-// LDS pixel stride Cp = Cin rounded up to 2 (mod 4) floats: 16 pixels x 2 lane groups hit 32
-// distinct banks (conflict-free ds_read_b32 while the four lane groups stay inside one tap).
+// LDS pixel stride 18 floats (2 mod 4): 16 pixels x 2 lane groups hit 32 distinct banks (conflict-free ds_read_b32).
 // out_sy/out_sx/out_oy/out_ox scatter the output pixel grid (Conv2DTranspose k2 s2 = four 1x1
 // convolutions, one per sub-pixel, written to (2y + a, 2x + b)).
 #include <algorithm>
@@ -321,115 +321,246 @@ __global__ __launch_bounds__(256) void conv_exact_mfma_kernel(ConvArgs a, int Cp
     }
 }
 
-// Layers whose all-channel halo tile does not fit LDS (unet's 1024 / 1536-channel concats, res_unet's 768 ...): the same
-// MFMA formulation with BOTH operands fetched straight from global memory in fragment layout -- no tile, so no limit on the
-// channel count, and the chain still runs (ky, kx, ci ascending) in one accumulator per output: the same bits as the scalar
-// kernel these layers used to fall back to (2.3 TFLOP/s: unet's float32 predict spent 0.9 s per 2048x1536 page there).
-//   B (pixels): lane (pixel p16, g) holds x[pixel + tap][channel 4s + g]  -- a buffer load, out-of-image taps and channels past
-//               the layer read zeros through an out-of-range offset (fmaf(0, w, acc) == acc exactly);
-//   A (weights): as conv_exact_mfma_kernel (zero slack for the lanes without a weight).
-// A pixel's value is fetched once per tap and cout block; the re-reads hit L1 / L2 (the halo of a 4-row x 32-pixel tile).
-// The fragments of k-step s + 1 are requested before the MFMAs of step s; the pre-activation ReLU is applied at the rotation.
-// Sources must hold a multiple of four channels (a k-step never straddles the Concatenate).
+// ---- blocked-chain kernel (every layer with Cin >= 8) -----------------------------------------------------------------
+constexpr int XCB = PSEG_CHAIN_BLOCK;   // input channels per pass of the chain (oracle/pseg_oracle.c: ORC_CHAIN_BLOCK)
+constexpr int XCP = XCB + 2;     // LDS pixel pitch in floats
+
+// MT = pixel tiles per wave (4: two rows x two column tiles, 2: one row), NT = cout tiles per workgroup (<= 4: 64 accumulator
+// registers, four waves per SIMD).  One (tap, four channels) k-step = MT ds_read_b32 + NT global loads for MT x NT MFMAs of
+// 32 cycles each; the k-steps of a slab form ONE software-pipelined stream across taps (the fragments of step q + 1 are
+// requested before the MFMAs of step q; a per-tap pipeline would expose a load latency every four k-steps).
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void conv_exact_direct_kernel(ConvArgs a) {
-    constexpr int RW = MT / 2, TH = 4 * RW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p16 = lane & 15, g = lane >> 4;
+__global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int TWH, unsigned inv_twh) {
+    extern __shared__ __attribute__((aligned(16))) float xt[];   // [THH][TWH][XCP]
+    constexpr int RW = MT / 2;            // output rows per wave
+    constexpr int TH = 4 * RW;            // output rows per workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p16 = lane & 15, g = lane >> 4;
     const int tiles_x = (a.Wout + XTW - 1) / XTW;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int oy0 = ty * TH, ox0 = tx * XTW;
+    const int iy0 = oy0 * a.stride - a.pt, ix0 = ox0 * a.stride - a.pl;
     const int Cin = a.C0 + a.C1;
     const int co_base = blockIdx.y * (NT * 16);
-    constexpr unsigned OOB = 0xfffffff0u;
-    const int H0 = a.Hin >> a.up0, W0 = a.Win >> a.up0, H1 = a.Hin >> a.up1, W1 = a.Win >> a.up1;
-    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (unsigned)((size_t)H0 * W0 * a.C0 * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0,
-                                                                        a.src1 ? (unsigned)((size_t)H1 * W1 * a.C1 * 4) : 0u, 0x00020000);
+    const int Ntot = a.deconv4 ? 4 * a.Cout : a.Cout;
+    const int npx = THH * TWH;
+
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int py[MT], px[MT];                    // this lane's input pixel at tap (0, 0)
+
+    int pixoff[MT];   // float offset of this lane's pixel at tap (0,0), channel 0 of the slab
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        py[m] = (oy0 + wave * RW + (m >> 1)) * a.stride - a.pt;
-        px[m] = (ox0 + (m & 1) * 16 + p16) * a.stride - a.pl;
+        const int row = wave * RW + (m >> 1), col = (m & 1) * 16 + p16;
+        pixoff[m] = (row * a.stride * TWH + col * a.stride) * XCP;
     }
+    // this lane's weight column per cout tile: w[k*Cout + wcol] (transposed conv k2 s2 as one GEMM over
+    // n = ab*Cout + co: the sub-pixel's kernel starts ab*Cin*Cout further on), or -1 past the layer
     int wcol[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = co_base + t * 16 + p16;
-        wcol[t] = n < a.Cout ? n : -1;
+        const int ab = a.deconv4 ? n / a.Cout : 0;
+        wcol[t] = n < Ntot ? ab * Cin * a.Cout + (n - ab * a.Cout) : -1;
     }
-    const int zoff = a.KH * a.KW * Cin * a.Cout;
-    const int nks0 = a.C0 >> 2, nks = Cin >> 2;       // k-steps per tap (both sources hold multiples of four channels)
-    const int total = a.KH * a.KW * nks;
-    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.src0), 0, a.mask ? (unsigned)((size_t)H0 * W0 * a.C0 * 4) : 0u, 0x00020000);
-    float xa[MT], wa[NT], xn[MT], wn[NT], mn[MT];
-    // fragments of flat step index q = tap * nks + s
-    auto load = [&](int q, float* xf, float* wf, float* mf) {
-        const int tap = q / nks, sidx = q - tap * nks;
-        const int ky = tap / a.KW, kx = tap - ky * a.KW;
-        const bool second = sidx >= nks0;                                   // wave-uniform: the step lies in src1
-        const int up = second ? a.up1 : a.up0, Ws = second ? W1 : W0, C = second ? a.C1 : a.C0;
-        const int c = (second ? sidx - nks0 : sidx) * 4 + g;
+    // Lanes without a weight to load (cout padding, channel padding of the last slab) read the first float of the zero slack
+    // every weight buffer carries behind its last element: an unconditional load whose result needs no select.
+    const int zoff = (a.deconv4 ? 4 : a.KH * a.KW) * Cin * a.Cout;
+    const bool pairs = ((a.C0 | a.C1) & 1) == 0;     // even channel counts: a lane stages two channels with 8-byte accesses
+
+    for (int cb = 0; cb < Cin; cb += XCB) {
+        const int cn = min(XCB, Cin - cb);
+        if (cb) __syncthreads();                     // every wave is done reading the previous slab
+        // ---- stage the slab: channels cb .. cb+15 of the halo tile (zeros outside the image and past the layer's channels).
+        // An item = (pixel, channel pair): eight pixels per wave trip, their 16 channels 64 contiguous bytes each; SU trips are
+        // requested before the first value is touched (a value looked at right behind its load costs a full memory latency).
+        constexpr int SU = 8;
+        if (pairs) {
+            const int sp = lane >> 3, c2 = (lane & 7) * 2;
+            const int ch = cb + c2;
+            const bool chok = ch < Cin;
+            const bool second = ch >= a.C0;
+            const float* const sb = second ? a.src1 : a.src0;
+            const int C = second ? a.C1 : a.C0, chl = second ? ch - a.C0 : ch, up = second ? a.up1 : a.up0;
+            const int Ws = a.Win >> up;
+            const float* const mb = second ? nullptr : a.mask;
+            const int ngrp = (npx + 7) >> 3;
+            for (int g0 = wave; g0 < ngrp; g0 += 4 * SU) {
+                float2 v[SU], mv[SU];
+                int dsto[SU];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int iy = py[m] + ky, ix = px[m] + kx;
-            const bool in = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            const unsigned o = in ? (unsigned)(((iy >> up) * Ws + (ix >> up)) * C + c) * 4u : OOB;
-            xf[m] = __builtin_bit_cast(float, second ? __builtin_amdgcn_raw_buffer_load_b32(r1, o, 0, 0)
-                                                     : __builtin_amdgcn_raw_buffer_load_b32(r0, o, 0, 0));
-            // training data gradients: the value counts only where the ReLU mask (laid out as src0) is positive
-            mf[m] = (a.mask && !second) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, o, 0, 0)) : 1.0f;
+                for (int u = 0; u < SU; ++u) {
+                    const int grp = g0 + 4 * u, p = grp * 8 + sp;
+                    const bool valid = grp < ngrp && p < npx;
+                    const int r = (int)(((unsigned)p * inv_twh) >> 20), c = p - r * TWH;
+                    const int iy = iy0 + r, ix = ix0 + c;
+                    dsto[u] = valid ? p * XCP + c2 : -1;
+                    v[u] = make_float2(0.0f, 0.0f);
+                    mv[u] = make_float2(1.0f, 1.0f);
+                    if (valid && chok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                        const size_t o = ((size_t)(iy >> up) * Ws + (ix >> up)) * C + chl;
+                        v[u] = *(const float2*)(sb + o);
+                        if (mb) mv[u] = *(const float2*)(mb + o);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    float2 x = v[u];
+                    if (a.in_relu) { x.x = x.x > 0.0f ? x.x : 0.0f; x.y = x.y > 0.0f ? x.y : 0.0f; }
+                    x.x = mv[u].x > 0.0f ? x.x : 0.0f;
+                    x.y = mv[u].y > 0.0f ? x.y : 0.0f;
+                    if (dsto[u] >= 0) *(float2*)(xt + dsto[u]) = x;
+                }
+            }
+        } else {
+            const int sp = lane >> 4, c1 = lane & 15;
+            const int ch = cb + c1;
+            const bool chok = ch < Cin;
+            const bool second = ch >= a.C0;
+            const float* const sb = second ? a.src1 : a.src0;
+            const int C = second ? a.C1 : a.C0, chl = second ? ch - a.C0 : ch, up = second ? a.up1 : a.up0;
+            const int Ws = a.Win >> up;
+            const float* const mb = second ? nullptr : a.mask;
+            const int ngrp = (npx + 3) >> 2;
+            for (int g0 = wave; g0 < ngrp; g0 += 4 * SU) {
+                float v[SU], mv[SU];
+                int dsto[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int grp = g0 + 4 * u, p = grp * 4 + sp;
+                    const bool valid = grp < ngrp && p < npx;
+                    const int r = (int)(((unsigned)p * inv_twh) >> 20), c = p - r * TWH;
+                    const int iy = iy0 + r, ix = ix0 + c;
+                    dsto[u] = valid ? p * XCP + c1 : -1;
+                    v[u] = 0.0f;
+                    mv[u] = 1.0f;
+                    if (valid && chok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                        const size_t o = ((size_t)(iy >> up) * Ws + (ix >> up)) * C + chl;
+                        v[u] = sb[o];
+                        if (mb) mv[u] = mb[o];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    float x = v[u];
+                    if (a.in_relu) x = x > 0.0f ? x : 0.0f;
+                    x = mv[u] > 0.0f ? x : 0.0f;
+                    if (dsto[u] >= 0) xt[dsto[u]] = x;
+                }
+            }
         }
-        const int ci = sidx * 4 + g;
-        const int wbase = (tap * Cin + ci) * a.Cout;
+        __syncthreads();
+
+        // ---- the slab's k-steps: (ky, kx, four channels), one pipelined stream
+        const int nks = (cn + 3) >> 2;
+        const int KHW = a.deconv4 ? 1 : a.KH * a.KW;
+        const int nq = KHW * nks;
+        const int KWe = a.deconv4 ? 1 : a.KW;
+        int s_ = 0, kx_ = 0, toff = 0, wb = cb * a.Cout;     // wave-uniform walk state
+        const int wstep = Cin * a.Cout;
+        float xa[MT], wa[NT], xb[MT], wbf[NT];
+        auto load = [&](float* xf, float* wf) {
+            const int ks = 4 * s_ + g;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wf[t] = a.w[wcol[t] >= 0 ? wbase + wcol[t] : zoff];
-    };
-    if (total > 0) load(0, xn, wn, mn);
-    for (int q = 0; q < total; ++q) {
+            for (int m = 0; m < MT; ++m) xf[m] = xt[pixoff[m] + toff + ks];
+            const bool okc = ks < cn;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) xa[m] = ((a.in_relu && !(xn[m] > 0.0f)) || !(mn[m] > 0.0f)) ? 0.0f : xn[m];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) wa[t] = wn[t];
-        if (q + 1 < total) load(q + 1, xn, wn, mn);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], xa[m], acc[m][t], 0, 0, 0);
-    }
-    // ---- epilogue (as conv_exact_mfma_kernel) ----
+            for (int t = 0; t < NT; ++t) wf[t] = a.w[(okc && wcol[t] >= 0) ? wb + ks * a.Cout + wcol[t] : zoff];
+            if (++s_ == nks) {
+                s_ = 0;
+                toff += XCP;
+                wb += wstep;
+                if (++kx_ == KWe) { kx_ = 0; toff += (TWH - KWe) * XCP; }
+            }
+        };
+#define PSEG_XBMMA(XF, WF)                                                                       \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                               \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                           \
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(WF[t], XF[m], acc[m][t], 0, 0, 0);
+        load(xa, wa);
+        int q = 0;
+        for (; q + 2 <= nq; q += 2) {
+            load(xb, wbf);
+            PSEG_XBMMA(xa, wa)
+            if (q + 2 < nq) load(xa, wa);
+            PSEG_XBMMA(xb, wbf)
+        }
+        if (q < nq) { PSEG_XBMMA(xa, wa) }
+#undef PSEG_XBMMA
+    }   // slabs
+
+    // ---- epilogue: acc + bias (+ add), ReLU; lane owns n = 4g..4g+3 of pixel p16 in every tile.  The lane's four values are
+    // consecutive output channels of one pixel (of one sub-pixel, for the transposed GEMM: Cout % 4 == 0 keeps a quad inside
+    // its sub-pixel): one 16-byte (or two 8-byte, Cout even) store instead of four 4-byte ones.
     const int osy = a.out_sy ? a.out_sy : 1, osx = a.out_sx ? a.out_sx : 1;
     const int pitch = a.dst_pitch ? a.dst_pitch : a.Wout;
-    const bool vec4 = (a.Cout & 3) == 0;
+    const int vecw = (a.Cout & 3) == 0 ? 4 : ((a.Cout & 1) == 0 ? 2 : 1);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int y = oy0 + wave * RW + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
         if (y >= a.Hout || x >= a.Wout) continue;
-        const size_t opix = (size_t)(y * osy + a.out_oy) * pitch + (size_t)(x * osx + a.out_ox);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n0 = co_base + t * 16 + 4 * g;
-            if (n0 >= a.Cout) continue;
+            if (n0 >= Ntot) continue;
             float v[4];
+            size_t off[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = n0 + r < a.Cout ? n0 + r : n0;
+                const int n = n0 + r;
+                const int nn = n < Ntot ? n : n0;                 // (values past the layer are never stored)
+                const int ab = a.deconv4 ? nn / a.Cout : 0;
+                const int co = nn - ab * a.Cout;
+                const size_t opix = a.deconv4 ? (size_t)(2 * y + (ab >> 1)) * pitch + (size_t)(2 * x + (ab & 1))
+                                              : (size_t)(y * osy + a.out_oy) * pitch + (size_t)(x * osx + a.out_ox);
+                off[r] = opix * a.Cout + co;
                 v[r] = a.bias ? acc[m][t][r] + a.bias[co] : acc[m][t][r];
-                if (a.add && n0 + r < a.Cout) v[r] = v[r] + a.add[opix * a.Cout + co];
-                if (a.relu) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
             }
-            if (vec4 && n0 + 3 < a.Cout) *(float4*)(a.dst + opix * a.Cout + n0) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
+            if (a.add) {
+                if (vecw == 4 && n0 + 3 < Ntot) {
+                    const float4 ad = *(const float4*)(a.add + off[0]);
+                    v[0] = v[0] + ad.x; v[1] = v[1] + ad.y; v[2] = v[2] + ad.z; v[3] = v[3] + ad.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < Ntot) v[r] = v[r] + a.add[off[r]];
+                }
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+            }
+            if (vecw == 4 && n0 + 3 < Ntot) {
+                *(float4*)(a.dst + off[0]) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (vecw >= 2) {
+                if (n0 + 1 < Ntot) *(float2*)(a.dst + off[0]) = make_float2(v[0], v[1]);
+                else a.dst[off[0]] = v[0];
+                if (n0 + 3 < Ntot) *(float2*)(a.dst + off[2]) = make_float2(v[2], v[3]);
+                else if (n0 + 2 < Ntot) a.dst[off[2]] = v[2];
+            } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (n0 + r < a.Cout) a.dst[opix * a.Cout + n0 + r] = v[r];
+                    if (n0 + r < Ntot) a.dst[off[r]] = v[r];
             }
         }
     }
+}
+
+template <int MT, int NT>
+static int launch_xb(const ConvArgs& a, int THH, int TWH, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    PSEG_HIP(hipGetDevice(&dev));
+    if (!attr_set[dev & 63]) {
+        PSEG_HIP(hipFuncSetAttribute((const void*)conv_xb_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[dev & 63] = true;
+    }
+    conv_xb_kernel<MT, NT><<<grid, 256, lds, st>>>(a, THH, TWH, (1u << 20) / (unsigned)TWH + 1u);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
 }
 
 template <int MT, int NT, bool FLAT>
@@ -446,8 +577,8 @@ static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, int CB, dim3 g
     return PSEG_OK;
 }
 
-// Returns 1 when the layer was launched on the MFMA kernel, 0 when it does not fit (caller falls
-// back to the scalar kernel), < 0 on error.
+// Returns 1 when the layer was launched on a matrix-core kernel, 0 when it is not one for them (caller falls back to the
+// 1x1 / scalar kernels: a handful of output channels), < 0 on error.
 int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     if (PSEG_KNOB("PSEG_EXACT_SCALAR")) return 0;
     ConvArgs a = a_in;
@@ -455,62 +586,52 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     const int Cin = a.C0 + a.C1;
     if (Cin < 1 || a.Cout < 1 || a.KH != a.KW) return 0;
     const int Ntot = a.deconv4 ? 4 * a.Cout : a.Cout;
-    if (Ntot < 8) return 0;                    // a handful of couts (logits): the scalar kernel wastes less
-    const bool flat = Cin < 8;
-    // tap-aligned k-steps read up to 4*ceil(Cin/4) channels of a pixel: the pad must be the pixel's own zeros
-    int Cp = flat ? std::max(Cin, 2) : 4 * ((Cin + 3) / 4);
-    while (Cp % 4 != 2) ++Cp;                  // LDS pixel stride: 2 (mod 4) floats
-    const size_t budget = 150 * 1024;
-    int MT = 0, THH = 0, TWH = (XTW - 1) * a.stride + a.KW;
-    // 8-row tiles unless that leaves a single workgroup per CU and 4-row tiles fit twice (the MFMA pipe idles while
-    // the only resident workgroup stages its tile or stores its results)
-    auto lds_of = [&](int mt) { return (size_t)((4 * (mt / 2) - 1) * a.stride + a.KH) * TWH * Cp * 4; };
-    const size_t l4 = lds_of(4), l2 = lds_of(2);
-    int CB = Cin;
-    if (l4 <= budget && (160 * 1024 / l4 >= 2 || l2 > budget || 160 * 1024 / l2 < 2 || PSEG_KNOB("PSEG_EXACT_MT4"))) MT = 4;
-    else if (l2 <= budget) MT = 2;
-    if (!MT && a.relaxed && !flat) {
-        // the caller tolerates another summation order (train step): blocks of channels whose 4-row tile fits twice per CU
-        const size_t px2 = (size_t)((4 - 1) * a.stride + a.KH) * TWH;
-        CB = (int)(72 * 1024 / (px2 * 4)) / 4 * 4 - 4;
-        if (CB < 16) return 0;
-        Cp = CB + 2;                               // CB is a multiple of 4: stride 2 (mod 4)
-        MT = 2;
-    }
-    // a 4-row tile that fills the CU's LDS alone (128+ channels) loses to the LDS-free kernel below: unet 97 -> 78 ms, res_unet
-    // 102 -> 86 ms per float32 page (fcn_skip's 120-channel deconv3 the other way round: 7.3 vs 8.2 ms)
-    if (MT == 2 && (!a.relaxed || PSEG_KNOB("PSEG_TRAIN_DIRECT")) && Cin >= 128 && !a.deconv4 && !(a.C0 & 3) && !(a.C1 & 3) && !PSEG_KNOB("PSEG_EXACT_NO_DIRECT")) MT = 0;
-    if (!MT) {
-        // the all-channel tile does not fit LDS: operands straight from global memory (same chain, same bits)
-        if (a.deconv4 || (a.C0 & 3) || (a.C1 & 3) || PSEG_KNOB("PSEG_EXACT_NO_DIRECT")) return 0;
-        if ((size_t)a.Hin * a.Win * std::max(a.C0, a.C1) * 4 >= ((size_t)1 << 32) || (size_t)a.KH * a.KW * Cin * a.Cout >= ((size_t)1 << 31)) return 0;
-        const int ntall_d = cdiv(a.Cout, 16);
-        const int NTd = ntall_d >= 4 ? 4 : ntall_d;
-        dim3 gd(cdiv(a.Wout, XTW) * cdiv(a.Hout, 8), cdiv(ntall_d, NTd));
-        switch (NTd) {
-            case 1: conv_exact_direct_kernel<4, 1><<<gd, 256, 0, st>>>(a); break;
-            case 2: conv_exact_direct_kernel<4, 2><<<gd, 256, 0, st>>>(a); break;
-            case 3: conv_exact_direct_kernel<4, 3><<<gd, 256, 0, st>>>(a); break;
-            default: conv_exact_direct_kernel<4, 4><<<gd, 256, 0, st>>>(a); break;
+    if (Ntot < 8) return 0;                    // a handful of couts (logits): the 1x1 / scalar kernels waste less
+    const int ntall = cdiv(Ntot, 16);
+    const int TWH = (XTW - 1) * a.stride + a.KW;
+    if (Cin < 8) {
+        // first layers: K flattened across taps (one slab: the oracle's order), all-channel tile
+        if (a.deconv4) return 0;
+        int Cp = std::max(Cin, 2);
+        while (Cp % 4 != 2) ++Cp;
+        const int THH = (8 - 1) * a.stride + a.KH;
+        const size_t lds = (size_t)THH * TWH * Cp * 4;
+        if (lds > 150 * 1024) return 0;
+        const int NT = ntall <= 4 ? ntall : (ntall == 5 ? 5 : 4);
+        dim3 grid(cdiv(a.Wout, XTW) * cdiv(a.Hout, 8), cdiv(ntall, NT));
+        switch (NT) {
+            case 1: PSEG_TRY((launch_xm<4, 1, true>(a, Cp, THH, TWH, Cin, grid, lds, st))); break;
+            case 2: PSEG_TRY((launch_xm<4, 2, true>(a, Cp, THH, TWH, Cin, grid, lds, st))); break;
+            case 3: PSEG_TRY((launch_xm<4, 3, true>(a, Cp, THH, TWH, Cin, grid, lds, st))); break;
+            case 4: PSEG_TRY((launch_xm<4, 4, true>(a, Cp, THH, TWH, Cin, grid, lds, st))); break;
+            default: PSEG_TRY((launch_xm<4, 5, true>(a, Cp, THH, TWH, Cin, grid, lds, st))); break;
         }
-        PSEG_HIP(hipGetLastError());
         return 1;
     }
-    THH = (4 * (MT / 2) - 1) * a.stride + a.KH;
-    const size_t lds = (size_t)THH * TWH * Cp * 4;
-    const int ntall = cdiv(Ntot, 16);
-    const int NT = ntall <= 4 ? ntall : (ntall == 5 ? 5 : 4);
+    // blocked chain: 8-row tiles unless the 16-channel slab of a strided layer's halo tile would leave fewer than three
+    // workgroups per CU (then 4-row tiles)
+    auto lds_of = [&](int mt) { return (size_t)((4 * (mt / 2) - 1) * a.stride + a.KH) * TWH * XCP * 4; };
+    int MT = (lds_of(4) <= 52 * 1024 && !PSEG_KNOB("PSEG_EXACT_MT2")) ? 4 : 2;
+    if (lds_of(MT) > 150 * 1024) return 0;
     const int TH = 4 * (MT / 2);
-    dim3 grid(cdiv(a.Wout, XTW) * cdiv(a.Hout, TH), cdiv(ntall, NT));
-#define PSEG_XM(MT_, NT_)                                                                        \
+    const int THH = (TH - 1) * a.stride + a.KH;
+    const int tiles = cdiv(a.Wout, XTW) * cdiv(a.Hout, TH);
+    // cout tiles per workgroup: at most four (64 accumulator registers), split evenly over the cout blocks; small layers
+    // (1/8-resolution: 192 tiles for 256 CUs) split further until the chip is full -- restaging a 31 KB slab per cout
+    // block costs little next to 25 taps of float32 MFMAs
+    int nblk = cdiv(ntall, 4), NT = cdiv(ntall, nblk);
+    while (NT > 1 && tiles * nblk < 1024) { --NT; nblk = cdiv(ntall, NT); }
+    if (const char* fv = PSEG_KNOB("PSEG_EXACT_NT")) { NT = std::max(1, std::min(4, atoi(fv))); nblk = cdiv(ntall, NT); }
+    const size_t lds = lds_of(MT);
+    dim3 grid(tiles, nblk);
+#define PSEG_XB(MT_, NT_)                                                                        \
     if (MT == MT_ && NT == NT_) {                                                                \
-        if (flat) PSEG_TRY((launch_xm<MT_, NT_, true>(a, Cp, THH, TWH, CB, grid, lds, st)));         \
-        else PSEG_TRY((launch_xm<MT_, NT_, false>(a, Cp, THH, TWH, CB, grid, lds, st)));             \
+        PSEG_TRY((launch_xb<MT_, NT_>(a, THH, TWH, grid, lds, st)));                             \
         return 1;                                                                                \
     }
-    PSEG_XM(4, 1) PSEG_XM(4, 2) PSEG_XM(4, 3) PSEG_XM(4, 4) PSEG_XM(4, 5)
-    PSEG_XM(2, 1) PSEG_XM(2, 2) PSEG_XM(2, 3) PSEG_XM(2, 4) PSEG_XM(2, 5)
-#undef PSEG_XM
+    PSEG_XB(4, 1) PSEG_XB(4, 2) PSEG_XB(4, 3) PSEG_XB(4, 4)
+    PSEG_XB(2, 1) PSEG_XB(2, 2) PSEG_XB(2, 3) PSEG_XB(2, 4)
+#undef PSEG_XB
     return 0;
 }
 

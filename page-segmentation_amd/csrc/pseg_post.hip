@@ -733,6 +733,37 @@ int pseg_bbox_fill(int device, const int64_t* pred, int64_t* out, int H, int W, 
     return rc;
 }
 
+__global__ void widen_u8_i64_kernel(const uint8_t* in, int64_t* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+__global__ void narrow_i64_u8_kernel(const int64_t* in, uint8_t* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (uint8_t)in[i];
+}
+
+// add_bounding_boxes on the compact uint8 label map, device-resident (the Predictor chain): widened to the int64 form the
+// labelling kernels read, painted, narrowed back.  Synchronises `stream` (the component count is read by the host).
+int pseg_bbox_fill_device_u8(int device, const uint8_t* d_pred, uint8_t* d_out, int H, int W, int n_classes, void* stream) {
+    (void)n_classes;
+    if (!d_pred || !d_out) return fail(PSEG_EINVAL, "NULL argument");
+    if (H <= 0 || W <= 0) return PSEG_OK;
+    if ((int64_t)H * W > 0x7fffffffLL) return fail(PSEG_EUNSUPPORTED, "page too large");
+    PSEG_TRY(set_dev(device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)H * W;
+    int64_t* d_tmp = nullptr;
+    PSEG_HIP(hipMalloc((void**)&d_tmp, n * 16));
+    const int g = (int)std::min<size_t>((n + 255) / 256, 8192);
+    widen_u8_i64_kernel<<<g, 256, 0, st>>>(d_pred, d_tmp, n);
+    int rc = bbox_fill_device(d_tmp, d_tmp + n, H, W, st);
+    if (rc == PSEG_OK) {
+        narrow_i64_u8_kernel<<<g, 256, 0, st>>>(d_tmp + n, d_out, n);
+        if (hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "bbox narrow launch failed");
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(d_tmp);
+    return rc;
+}
+
 int pseg_masks_device(int device, const int64_t* d_pred, const uint8_t* d_binary,
                       const uint8_t* d_lut, int n_lut, int H, int W, uint8_t* d_color,
                       uint8_t* d_overlay, uint8_t* d_inverted, uint8_t* d_fg_color, void* stream) {

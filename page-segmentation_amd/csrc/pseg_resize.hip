@@ -445,6 +445,13 @@ int pseg_resize_nearest(int device, const void* src, int H, int W, int elem_byte
     return PSEG_OK;
 }
 
+int pseg_resize_nearest_device(int device, const void* d_src, int H, int W, int elem_bytes, void* d_dst, int Ho, int Wo, void* stream) {
+    if (!d_src || !d_dst) return fail(PSEG_EINVAL, "NULL argument");
+    PSEG_TRY(check_shape(H, W, Ho, Wo));
+    PSEG_TRY(rz_set_dev(device));
+    return nearest_dev(d_src, H, W, elem_bytes, d_dst, Ho, Wo, (hipStream_t)stream);
+}
+
 int pseg_scale_image(int device, const void* src, int src_is_f64, int H, int W, double* dst, int Ho, int Wo,
                      const double* wy, int ry, const double* wx, int rx) {
     if (!src || !dst) return fail(PSEG_EINVAL, "NULL argument");

@@ -1,5 +1,5 @@
 """Train step of unet and res_unet (float32 engine) against torch autograd (oracle/train_ref.py:graph_loss_and_grads):
-loss within 1e-4 relative (north_star), every gradient tensor within 2e-3 of its scale; unet's Dropout layers with
+loss within 1e-4 relative (north_star), every gradient tensor within 2e-3 of its scale (unet, with the max-pool winners taken from the float32 activations: 2e-4); unet's Dropout layers with
 the engine's counter-based masks restated in NumPy."""
 import numpy as np
 import pytest
@@ -13,12 +13,12 @@ def _sample(seed, H, W, C):
     return np.ascontiguousarray(img[:H, :W]), np.ascontiguousarray(mask[:H, :W])
 
 
-def _compare(g, g_o):
+def _compare(g, g_o, bar=2e-3):
     assert list(g.keys()) == list(g_o.keys())
     for k in g_o:
         scale = np.abs(g_o[k]).max() + 1e-12
         err = np.abs(g[k] - g_o[k]).max()
-        assert err <= 2e-3 * scale + 1e-9, "%s: max err %g vs scale %g" % (k, err, scale)
+        assert err <= bar * scale + 1e-9, "%s: max err %g vs scale %g" % (k, err, scale)
 
 
 @pytest.mark.parametrize("arch,C,shape", [("res_unet", 3, (64, 96)), ("res_unet", 4, (40, 50)), ("unet", 3, (32, 64))])
@@ -31,11 +31,15 @@ def test_gradients_match_autograd(gpu, oracle_mod, arch, C, shape):
     eng.train_init(clipnorm=1.0)
     if arch == "unet":
         eng.train_set_dropout_seed(77)
+        # max-pool windows whose two largest values tie to float32 rounding route their gradient by summation order:
+        # the referee takes the winners from the float32 oracle's activations, which the engine reproduces bit for bit
+        # (oracle/train_ref.py; without this one window in 5 215 put 1e-2 on conv2d_5/kernel)
+        acts = oracle_mod.forward(arch, Wt, img, "f32", return_acts=True)[1]
         for step in range(2):                                    # the mask changes with the step
-            loss_o, g_o, _ = graph_loss_and_grads(arch, Wt, img, mask, drop=(77, step))
+            loss_o, g_o, _ = graph_loss_and_grads(arch, Wt, img, mask, drop=(77, step), route_acts=acts)
             loss = eng.train_forward_backward(img, mask)[0]
             assert abs(loss - loss_o) <= 1e-4 * abs(loss_o), (step, loss, loss_o)
-            _compare(eng.gradients(), g_o)
+            _compare(eng.gradients(), g_o, bar=2e-4)              # routed referee: only rounding is left (measured 2e-6)
         # evaluation: Dropout is the identity
         loss_e, _, _ = graph_loss_and_grads(arch, Wt, img, mask)
         assert abs(eng.eval_step(img, mask)[0] - loss_e) <= 1e-4 * abs(loss_e)

@@ -78,12 +78,13 @@ extern "C" int pseg_predict_chain(pseg_engine* h, const uint8_t* img, int H, int
     ChainState& c = *(ChainState*)e.chain;
     hipStream_t st = e.stream;
     const size_t npx = (size_t)H * W, nl = (size_t)Hl * Wl;
+    const size_t nla = (nl + 255) & ~(size_t)255;          // buffer stride: the mask / vote kernels want 4-byte aligned maps
     // a reallocation must not race with the previous call's work: every call ends synchronised, so the buffers are idle here
     PSEG_TRY(censure(c, CB_IMG, npx * e.in_ch));
     PSEG_TRY(censure(c, CB_LAB, npx));
-    PSEG_TRY(censure(c, CB_LAB2, 2 * nl));           // resize target + bounding-box ping-pong
+    PSEG_TRY(censure(c, CB_LAB2, 2 * nla));          // resize target + bounding-box ping-pong
     if (need_bin) PSEG_TRY(censure(c, CB_BIN, nl));
-    if (want_masks) { PSEG_TRY(censure(c, CB_MASKS, 4 * nl * 3)); PSEG_TRY(censure(c, CB_LUT, (size_t)n_lut * 3)); }
+    if (want_masks) { PSEG_TRY(censure(c, CB_MASKS, 4 * nla * 3)); PSEG_TRY(censure(c, CB_LUT, (size_t)n_lut * 3)); }
     if (labels) PSEG_TRY(censure(c, CB_I64, nl * 8));
     // uploads: the page on the engine's stream (the network waits for it anyway), binarisation and colour table beside it
     PSEG_HIP(hipMemcpyAsync(c.d_buf[CB_IMG], img, npx * e.in_ch, hipMemcpyHostToDevice, st));
@@ -97,7 +98,7 @@ extern "C" int pseg_predict_chain(pseg_engine* h, const uint8_t* img, int H, int
         PSEG_TRY(predict_device(e, c.d_buf[CB_IMG], H, W, nullptr, nullptr, nullptr, c.d_buf[CB_LAB], st, nullptr));
     uint8_t* cur = c.d_buf[CB_LAB];
     uint8_t* const bufA = c.d_buf[CB_LAB2];
-    uint8_t* const bufB = c.d_buf[CB_LAB2] + nl;
+    uint8_t* const bufB = c.d_buf[CB_LAB2] + nla;
     // 2. scale_to_original_shape: order-0 gather of the label map (preserving_resize(pred, original_shape))
     if (resize) {
         PSEG_TRY(pseg_resize_nearest_device(e.device, cur, H, W, 1, bufA, Hl, Wl, st));
@@ -122,7 +123,7 @@ extern "C" int pseg_predict_chain(pseg_engine* h, const uint8_t* img, int H, int
     }
     if (want_masks) {
         uint8_t* m = c.d_buf[CB_MASKS];
-        uint8_t* dm[4] = {color ? m : nullptr, overlay ? m + nl * 3 : nullptr, inverted ? m + 2 * nl * 3 : nullptr, fg_color ? m + 3 * nl * 3 : nullptr};
+        uint8_t* dm[4] = {color ? m : nullptr, overlay ? m + nla * 3 : nullptr, inverted ? m + 2 * nla * 3 : nullptr, fg_color ? m + 3 * nla * 3 : nullptr};
         PSEG_TRY(pseg_masks_device_u8(e.device, cur, c.d_buf[CB_BIN], c.d_buf[CB_LUT], n_lut, Hl, Wl, dm[0], dm[1], dm[2], dm[3], st));
         uint8_t* hm[4] = {color, overlay, inverted, fg_color};
         for (int k = 0; k < 4; ++k)

@@ -222,9 +222,23 @@ struct ConvArgs {
     int out_sy, out_sx, out_oy, out_ox;   // MFMA kernel only: output pixel (y*sy + oy, x*sx + ox); 0 strides = 1
     int deconv4;         // MFMA kernel only: Conv2DTranspose k2 s2 as one GEMM, n = ab*Cout + co -> (2y + a, 2x + b)
     int dbg;             // MFMA kernel only: timing experiments (PSEG_XM_DBG: 1 no staging loads, 2 no stores, 4 no k-loop) -- wrong results
+    float* pool_dst;     // blocked MFMA kernel, 8-row tiles only: also store the 2x2 max-pool of the output ((Hout/2) x (Wout/2) x Cout)
     int relaxed;         // MFMA kernel only: the caller accepts a channel-blocked summation order (train step) for layers whose all-channel tile does not fit LDS
 };
-int launch_conv_exact(const ConvArgs& a, hipStream_t st);
+int launch_conv_exact(const ConvArgs& a, hipStream_t st, bool* pooled = nullptr);   // *pooled: ConvArgs.pool_dst was written by the conv kernel
+// HBM-bound float32 layers on the vector ALU (pseg_exact_valu.hip): first layer; Conv2DTranspose k2 s2, optionally with the
+// logits layer + argmax behind it.  1 = launched, 0 = not a layer for these kernels, < 0 error.
+struct TailArgs {
+    const float* src0; const float* src1; int C0, C1, Hin, Win;
+    const float* w; const float* bias; int Cout, relu;
+    float* dst;
+    const float* skip; int Cs;
+    const float* wl; const float* bl; int ncls;
+    int H, W;
+    float* logits; int64_t* labels; uint8_t* labels_u8;
+};
+int launch_conv_first_valu(const ConvArgs& a, hipStream_t st);
+int launch_deconv2_valu(const TailArgs& a, bool tail, hipStream_t st);
 int launch_conv_exact_mfma(const ConvArgs& a, hipStream_t st);   // 1 launched, 0 does not fit, < 0 error
 // split form of UpSampling2D(2) -> Conv2D(k2) (pseg_upsplit.hip)
 struct UpSplit;

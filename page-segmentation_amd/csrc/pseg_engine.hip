@@ -407,10 +407,16 @@ static int ensure(void** p, size_t* cap, size_t bytes) {
 // Upload weights in correlation form.  Conv2D: as is.  Conv2DTranspose s1 (kh,kw,Cout,Cin):
 // Wc[ky][kx][ci][co] = K[KH-1-ky][KW-1-kx][co][ci].  Conv2DTranspose k2 s2: [a][b][ci][co] =
 // K[a][b][co][ci].
-int launch_conv_exact(const ConvArgs& a, hipStream_t st) {
-    // matrix-core path (same bits, see pseg_exact_mfma.hip) when the all-channel tile fits in LDS
+int launch_conv_exact(const ConvArgs& a, hipStream_t st, bool* pooled) {
+    // matrix-core path (same bits, see pseg_exact_mfma.hip)
+    if (pooled) *pooled = false;
+    const int rv = a.pool_dst ? 0 : launch_conv_first_valu(a, st);     // 1 or 3 input channels: HBM-bound, vector ALU
+    if (rv != 0) return rv < 0 ? rv : PSEG_OK;
     const int rc = launch_conv_exact_mfma(a, st);
-    if (rc != 0) return rc < 0 ? rc : PSEG_OK;
+    if (rc != 0) {
+        if (pooled) *pooled = rc == 2;
+        return rc < 0 ? rc : PSEG_OK;
+    }
     const int Cin = a.C0 + a.C1;
     if (a.KH == 1 && a.KW == 1 && a.stride == 1 && !a.pt && !a.pl && !a.up0 && !a.up1 && !a.in_relu && !a.mask && Cin <= 127 &&
         !PSEG_KNOB("PSEG_EXACT_NO_1X1")) {
@@ -577,12 +583,16 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
             preprocess_exact_kernel<<<grid, 256, 0, st>>>(d_img, e.H, e.W, in.C, e.d_lut, (float*)in.d,
                                                           e.Hp, e.Wp);
     }
+    const Op* skip_pool = nullptr;
+    const Op* fused_logits = nullptr;
     for (auto& op : e.ops) {
         hipEvent_t ev0;
         PSEG_TRY(time_begin(e, op, st, &ev0));
         const Tensor& s0 = e.tensors[op.src0];
         const Tensor* s1 = op.src1 >= 0 ? &e.tensors[op.src1] : nullptr;
-        if (op.type == OP_CONV || op.type == OP_LOGITS) {
+        if (&op == fused_logits) {
+            // logits + argmax ran inside the transposed conv in front of it
+        } else if (op.type == OP_CONV || op.type == OP_LOGITS) {
             ConvArgs a{};
             a.src0 = (const float*)s0.d;
             a.src1 = s1 ? (const float*)s1->d : nullptr;
@@ -636,7 +646,17 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
                 }
                 a.add = op.add >= 0 ? (const float*)e.tensors[op.add].d : nullptr;
                 a.dst = (float*)d.d;
-                PSEG_TRY(launch_conv_exact(a, st));
+                // MaxPooling2D right behind this layer (every encoder stage of fcn / unet): pooled in the conv's epilogue
+                const Op* nx = (&op + 1 < e.ops.data() + e.ops.size()) ? &op + 1 : nullptr;
+                // (measured, fcn_skip 2048x1536: the fused form saves the pool passes -- 91 + 27 + 13 us -- and costs the three
+                // producers 84 + 40 + 12 us in their epilogues: no gain, so the separate streaming pass stays the default;
+                // PSEG_EXACT_POOL_FUSE=1 selects the fused form, tests keep both bit-identical)
+                const bool want_pool = nx && nx->type == OP_POOL && nx->src0 == op.dst && op.add < 0 && !(e.drop_key && op.dropout > 0.0f) &&
+                                       PSEG_KNOB("PSEG_EXACT_POOL_FUSE");
+                if (want_pool) a.pool_dst = (float*)e.tensors[nx->dst].d;
+                bool pooled = false;
+                PSEG_TRY(launch_conv_exact(a, st, &pooled));
+                skip_pool = pooled ? nx : nullptr;
             }
         } else if (op.type == OP_BN) {
             const size_t npx = (size_t)e.tH(s0) * e.tW(s0);
@@ -644,10 +664,46 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
             if (e.bn_training) PSEG_TRY(bn_train_forward((const float*)s0.d, y, npx, op.Cin, op.d_w, op.d_b, op.relu, op.up0, st));
             else PSEG_TRY(bn_infer((const float*)s0.d, y, npx, op.Cin, op.d_w, op.d_b, op.relu, st));
         } else if (op.type == OP_DECONV2) {
-            // Conv2DTranspose k2 s2 on the matrix cores: one 1x1 GEMM over n = (sub-pixel, cout), same chain
-            // order over ci as deconv2_exact_kernel; the scalar kernel if the all-channel tile does not fit
+            // Conv2DTranspose k2 s2: HBM-bound -- one output pixel per thread on the vector ALU (pseg_exact_valu.hip); when
+            // its only reader is the logits layer (fcn_skip / fcn: deconv5), that layer and the argmax run in the same
+            // kernel on the values still in registers.  Fallbacks: the matrix-core GEMM form, then the scalar kernel.
             bool done = false;
             {
+                TailArgs ta{};
+                ta.src0 = (const float*)s0.d; ta.src1 = s1 ? (const float*)s1->d : nullptr;
+                ta.C0 = s0.C; ta.C1 = s1 ? s1->C : 0; ta.Hin = e.tH(s0); ta.Win = e.tW(s0);
+                ta.w = op.d_w; ta.bias = op.d_b; ta.Cout = op.Cout; ta.relu = op.relu;
+                ta.dst = (float*)e.tensors[op.dst].d;
+                const Op* nx = (&op + 1 < e.ops.data() + e.ops.size()) ? &op + 1 : nullptr;
+                bool tail = nx && nx->type == OP_LOGITS && nx->src0 == op.dst && nx->k == 1 && !op.relu && op.Cout == 20 && nx->Cout <= 8 &&
+                            !(e.drop_key && op.dropout > 0.0f) && !PSEG_KNOB("PSEG_EXACT_NO_TAIL_FUSE");
+                if (tail) {
+                    const Tensor* sk = nx->src1 >= 0 ? &e.tensors[nx->src1] : nullptr;
+                    if (sk && sk->s != e.tensors[op.dst].s) tail = false;
+                    if (tail) {
+                        ta.skip = sk ? (const float*)sk->d : nullptr; ta.Cs = sk ? sk->C : 0;
+                        ta.wl = nx->d_w; ta.bl = nx->d_b; ta.ncls = nx->Cout; ta.H = e.H; ta.W = e.W;
+                        float* zl = d_logits;
+                        if (!zl && d_probs) {
+                            PSEG_TRY(ensure((void**)&e.d_logits_tmp, &e.logits_tmp_bytes, (size_t)e.H * e.W * nx->Cout * sizeof(float)));
+                            zl = e.d_logits_tmp;
+                        }
+                        ta.logits = zl; ta.labels = d_labels; ta.labels_u8 = d_labels_u8;
+                    }
+                }
+                int rv = launch_deconv2_valu(ta, tail, st);
+                if (rv == 0 && tail) { tail = false; rv = launch_deconv2_valu(ta, false, st); }
+                if (rv < 0) return rv;
+                done = rv == 1;
+                if (done && tail) {
+                    fused_logits = nx;
+                    if (d_probs) {
+                        const size_t n = (size_t)e.H * e.W;
+                        softmax_argmax_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(ta.logits, n, nx->Cout, d_probs, nullptr, nullptr);
+                    }
+                }
+            }
+            if (!done) {
                 ConvArgs c{};
                 c.src0 = (const float*)s0.d;
                 c.src1 = s1 ? (const float*)s1->d : nullptr;
@@ -685,6 +741,8 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
             dim3 grid(cdiv(a.Hin * a.Win, 256), cdiv(op.Cout, COT), 4);
             deconv2_exact_kernel<<<grid, 256, 0, st>>>(a);
             }
+        } else if (op.type == OP_POOL && &op == skip_pool) {
+            // done in the producing conv's epilogue
         } else if (op.type == OP_POOL) {
             const size_t n = (size_t)(e.tH(s0) / 2) * (e.tW(s0) / 2) * s0.C;
             const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);

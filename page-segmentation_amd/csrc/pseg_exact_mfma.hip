@@ -22,6 +22,7 @@
 // out_sy/out_sx/out_oy/out_ox scatter the output pixel grid (Conv2DTranspose k2 s2 = four 1x1
 // convolutions, one per sub-pixel, written to (2y + a, 2x + b)).
 #include <algorithm>
+#include <type_traits>
 
 #include "pseg_common.h"
 
@@ -351,24 +352,23 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int pixoff[MT];   // float offset of this lane's pixel at tap (0,0), channel 0 of the slab
+    int xbase[MT];   // float offset of this lane's fragment element at tap (0,0), k-step 0 of a slab: its pixel, channel g
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = wave * RW + (m >> 1), col = (m & 1) * 16 + p16;
-        pixoff[m] = (row * a.stride * TWH + col * a.stride) * XCP;
+        xbase[m] = (row * a.stride * TWH + col * a.stride) * XCP + g;
     }
-    // this lane's weight column per cout tile: w[k*Cout + wcol] (transposed conv k2 s2 as one GEMM over
-    // n = ab*Cout + co: the sub-pixel's kernel starts ab*Cin*Cout further on), or -1 past the layer
-    int wcol[NT];
+    // this lane's weight byte offset per cout tile: w[(k = g)*Cout + column] (transposed conv k2 s2 as one GEMM over
+    // n = ab*Cout + co: the sub-pixel's kernel starts ab*Cin*Cout further on); out of range past the layer (reads 0)
+    const unsigned wbytes = (unsigned)((size_t)(a.deconv4 ? 4 : a.KH * a.KW) * Cin * a.Cout * 4);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, wbytes, 0x00020000);
+    unsigned voff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = co_base + t * 16 + p16;
         const int ab = a.deconv4 ? n / a.Cout : 0;
-        wcol[t] = n < Ntot ? ab * Cin * a.Cout + (n - ab * a.Cout) : -1;
+        voff[t] = n < Ntot ? (unsigned)(ab * Cin * a.Cout + (n - ab * a.Cout) + g * a.Cout) * 4u : 0x7ffffff0u;
     }
-    // Lanes without a weight to load (cout padding, channel padding of the last slab) read the first float of the zero slack
-    // every weight buffer carries behind its last element: an unconditional load whose result needs no select.
-    const int zoff = (a.deconv4 ? 4 : a.KH * a.KW) * Cin * a.Cout;
     const bool pairs = ((a.C0 | a.C1) & 1) == 0;     // even channel counts: a lane stages two channels with 8-byte accesses
 
     for (int cb = 0; cb < Cin; cb += XCB) {
@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
         // An item = (pixel, channel pair): eight pixels per wave trip, their 16 channels 64 contiguous bytes each; SU trips are
         // requested before the first value is touched (a value looked at right behind its load costs a full memory latency).
         constexpr int SU = 8;
-        if (pairs) {
+        if (PSEG_DIAG && (a.dbg & 1)) {                 // timing ablation (diagnostic build): no staging loads
+            for (int i = tid; i < npx * XCP; i += 256) xt[i] = 0.0f;
+        } else if (pairs) {
             const int sp = lane >> 3, c2 = (lane & 7) * 2;
             const int ch = cb + c2;
             const bool chok = ch < Cin;
@@ -454,42 +456,87 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
         }
         __syncthreads();
 
-        // ---- the slab's k-steps: (ky, kx, four channels), one pipelined stream
+        // ---- the slab's k-steps: (ky, kx, four channels).  The pipeline unit is a TAP: the (up to) four k-steps of a tap are
+        // requested while the MFMAs of the tap before it run (two register sets).  No vector ALU instruction per fragment:
+        //   * pixel fragments: ds_read_b32 with the k-step's channel offset as the instruction's immediate; the per-lane
+        //     base address moves once per tap (MT adds per 4 x MT x NT MFMAs);
+        //   * weight fragments: buffer loads -- per-lane byte offset fixed for the whole kernel (voff), the (tap, slab,
+        //     k-step) part in the scalar offset; lanes without a weight (cout padding) carry an out-of-range offset, for
+        //     which the hardware returns 0, and the channel padding of the last slab needs no select at all: its x is
+        //     the slab's zero fill, and 0 * (a finite neighbouring weight, or the 0 behind the buffer's end) adds nothing.
+        // (The first version computed a 64-bit address and an exec-masked select per weight load and a shift-add per LDS
+        // read: ~22 vector ALU instructions per 8 MFMAs.  Vector ALU and matrix instructions share a SIMD's issue port:
+        // with the fragment loads switched off that build ran 1131 instead of 1430 us on conv2 -- tools/ab_f32.sh.)
         const int nks = (cn + 3) >> 2;
         const int KHW = a.deconv4 ? 1 : a.KH * a.KW;
-        const int nq = KHW * nks;
         const int KWe = a.deconv4 ? 1 : a.KW;
-        int s_ = 0, kx_ = 0, toff = 0, wb = cb * a.Cout;     // wave-uniform walk state
-        const int wstep = Cin * a.Cout;
-        float xa[MT], wa[NT], xb[MT], wbf[NT];
-        auto load = [&](float* xf, float* wf) {
-            const int ks = 4 * s_ + g;
+        int kx_ = 0, toff = 0;                                 // wave-uniform walk state: LDS float offset of the tap ...
+        unsigned wso = (unsigned)(cb * a.Cout) * 4u;            // ... and byte offset of (tap, slab) in the weight buffer
+        const unsigned wstep = (unsigned)(Cin * a.Cout) * 4u, kstep = (unsigned)(4 * a.Cout) * 4u;
+        float xf[4][MT], wf[4][NT];                             // fragments of the tap's (up to) four k-steps
+        const int ntap = (PSEG_DIAG && (a.dbg & 4)) ? 0 : KHW;  // dbg & 4: no k-loop
+        // NKS = k-steps per tap, a compile-time constant inside the loop (straight-line tap bodies: with a run-time count
+        // the per-k-step branches cut the body into basic blocks and the compiler issued each tap's loads right in front
+        // of its own MFMAs).  ONE register set, one tap of lead: k-step s of tap T + 1 is requested into the registers of
+        // k-step s of tap T as soon as that step's MFMAs have been issued.
+        auto slab = [&](auto nks_c) {
+            constexpr int NKS = decltype(nks_c)::value;
+            const float* xp[MT];
+            auto point = [&]() {                                // fragment pointers / weight offset of the tap the walk is at
 #pragma unroll
-            for (int m = 0; m < MT; ++m) xf[m] = xt[pixoff[m] + toff + ks];
-            const bool okc = ks < cn;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) wf[t] = a.w[(okc && wcol[t] >= 0) ? wb + ks * a.Cout + wcol[t] : zoff];
-            if (++s_ == nks) {
-                s_ = 0;
+                for (int m = 0; m < MT; ++m) xp[m] = xt + xbase[m] + toff;
+            };
+            auto advance = [&]() {
                 toff += XCP;
-                wb += wstep;
+                wso += wstep;
                 if (++kx_ == KWe) { kx_ = 0; toff += (TWH - KWe) * XCP; }
+            };
+            auto request = [&](int s4, unsigned wo) {           // k-step s4 of the tap `xp` / `wo` point at
+                if (PSEG_DIAG && (a.dbg & 8)) {                 // timing ablation: no weight loads
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) wf[s4][t] = (float)(wo + t);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        wf[s4][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, voff[t], wo + (unsigned)s4 * kstep, 0));
+                }
+                if (PSEG_DIAG && (a.dbg & 16)) {                // timing ablation: no LDS fragment reads
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) xf[s4][m] = (float)(wo + m);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) xf[s4][m] = xp[m][4 * s4];
+                }
+            };
+            auto mma = [&](int s4) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s4][t], xf[s4][m], acc[m][t], 0, 0, 0);
+            };
+            if (ntap <= 0) return;
+            point();
+#pragma unroll
+            for (int s4 = 0; s4 < NKS; ++s4) request(s4, wso);
+            for (int tap = 0; tap + 1 < ntap; ++tap) {
+                advance();
+                point();                                         // the NEXT tap
+#pragma unroll
+                for (int s4 = 0; s4 < NKS; ++s4) {
+                    mma(s4);
+                    request(s4, wso);
+                }
             }
+#pragma unroll
+            for (int s4 = 0; s4 < NKS; ++s4) mma(s4);
         };
-#define PSEG_XBMMA(XF, WF)                                                                       \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                               \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                           \
-            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(WF[t], XF[m], acc[m][t], 0, 0, 0);
-        load(xa, wa);
-        int q = 0;
-        for (; q + 2 <= nq; q += 2) {
-            load(xb, wbf);
-            PSEG_XBMMA(xa, wa)
-            if (q + 2 < nq) load(xa, wa);
-            PSEG_XBMMA(xb, wbf)
+        switch (nks) {
+            case 4: slab(std::integral_constant<int, 4>{}); break;
+            case 3: slab(std::integral_constant<int, 3>{}); break;
+            case 2: slab(std::integral_constant<int, 2>{}); break;
+            default: slab(std::integral_constant<int, 1>{}); break;
         }
-        if (q < nq) { PSEG_XBMMA(xa, wa) }
-#undef PSEG_XBMMA
     }   // slabs
 
     // ---- epilogue: acc + bias (+ add), ReLU; lane owns n = 4g..4g+3 of pixel p16 in every tile.  The lane's four values are
@@ -501,7 +548,7 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int y = oy0 + wave * RW + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
-        if (y >= a.Hout || x >= a.Wout) continue;
+        if (y >= a.Hout || x >= a.Wout || (PSEG_DIAG && (a.dbg & 2) && acc[m][0][0] != 123.456f)) continue;   // dbg & 2: no stores
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n0 = co_base + t * 16 + 4 * g;
@@ -547,6 +594,50 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
             }
         }
     }
+    // ---- fused MaxPooling2D 2x2 (lib/model.py:54,59,64) of the tensor just stored: a wave holds both rows of its pixel
+    // pairs (accumulator tiles m and m + 2), the horizontal neighbour sits in lane p16 ^ 1.  The same comparisons in the same
+    // order as pool_exact_kernel -- (x, x+1) of the upper row, of the lower row, then the two winners -- so the same bits
+    // (signed zeros included); the separate pass re-read the whole tensor (377 MB after conv2).
+    if constexpr (MT == 4) {
+        if (a.pool_dst) {
+            const int Wp = a.Wout >> 1;
+            const int yp = (oy0 >> 1) + wave;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int x = ox0 + c * 16 + p16;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int n0 = co_base + t * 16 + 4 * g;
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = n0 + r < Ntot ? n0 + r : 0;
+                        float u0 = a.bias ? acc[c][t][r] + a.bias[co] : acc[c][t][r];
+                        float u1 = a.bias ? acc[2 + c][t][r] + a.bias[co] : acc[2 + c][t][r];
+                        if (a.relu) { u0 = u0 > 0.0f ? u0 : 0.0f; u1 = u1 > 0.0f ? u1 : 0.0f; }
+                        const float r0 = __shfl_xor(u0, 1), r1 = __shfl_xor(u1, 1);
+                        const float mt = u0 > r0 ? u0 : r0, mb = u1 > r1 ? u1 : r1;
+                        o[r] = mt > mb ? mt : mb;
+                    }
+                    if ((p16 & 1) || 2 * yp + 1 >= a.Hout || x + 1 >= a.Wout) continue;
+                    if (n0 >= Ntot) continue;
+                    float* od = a.pool_dst + ((size_t)yp * Wp + (x >> 1)) * a.Cout + n0;
+                    if (vecw == 4 && n0 + 3 < Ntot) {
+                        *(float4*)od = make_float4(o[0], o[1], o[2], o[3]);
+                    } else if (vecw >= 2) {
+                        if (n0 + 1 < Ntot) *(float2*)od = make_float2(o[0], o[1]);
+                        else od[0] = o[0];
+                        if (n0 + 3 < Ntot) *(float2*)(od + 2) = make_float2(o[2], o[3]);
+                        else if (n0 + 2 < Ntot) od[2] = o[2];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n0 + r < Ntot) od[r] = o[r];
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int MT, int NT>
@@ -577,8 +668,8 @@ static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, int CB, dim3 g
     return PSEG_OK;
 }
 
-// Returns 1 when the layer was launched on a matrix-core kernel, 0 when it is not one for them (caller falls back to the
-// 1x1 / scalar kernels: a handful of output channels), < 0 on error.
+// Returns 1 when the layer was launched on a matrix-core kernel (2: with ConvArgs.pool_dst written too), 0 when it is not
+// one for them (caller falls back to the 1x1 / scalar kernels: a handful of output channels), < 0 on error.
 int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     if (PSEG_KNOB("PSEG_EXACT_SCALAR")) return 0;
     ConvArgs a = a_in;
@@ -592,6 +683,7 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     if (Cin < 8) {
         // first layers: K flattened across taps (one slab: the oracle's order), all-channel tile
         if (a.deconv4) return 0;
+        a.pool_dst = nullptr;                  // (no fused pool on this path: the caller sees return code 1 and pools itself)
         int Cp = std::max(Cin, 2);
         while (Cp % 4 != 2) ++Cp;
         const int THH = (8 - 1) * a.stride + a.KH;
@@ -612,6 +704,8 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     // workgroups per CU (then 4-row tiles)
     auto lds_of = [&](int mt) { return (size_t)((4 * (mt / 2) - 1) * a.stride + a.KH) * TWH * XCP * 4; };
     int MT = (lds_of(4) <= 52 * 1024 && !PSEG_KNOB("PSEG_EXACT_MT2")) ? 4 : 2;
+    const bool pooled = a.pool_dst != nullptr && MT == 4 && a.stride == 1 && !a.deconv4 && !a.add && !(a.Hout & 1) && !(a.Wout & 1);
+    if (!pooled) a.pool_dst = nullptr;
     if (lds_of(MT) > 150 * 1024) return 0;
     const int TH = 4 * (MT / 2);
     const int THH = (TH - 1) * a.stride + a.KH;
@@ -621,13 +715,14 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     // block costs little next to 25 taps of float32 MFMAs
     int nblk = cdiv(ntall, 4), NT = cdiv(ntall, nblk);
     while (NT > 1 && tiles * nblk < 1024) { --NT; nblk = cdiv(ntall, NT); }
+    NT = cdiv(ntall, nblk);                    // even split: 4 tiles over 2 blocks are 2 + 2, not 3 + 1 (idle MFMAs on the empty tiles)
     if (const char* fv = PSEG_KNOB("PSEG_EXACT_NT")) { NT = std::max(1, std::min(4, atoi(fv))); nblk = cdiv(ntall, NT); }
     const size_t lds = lds_of(MT);
     dim3 grid(tiles, nblk);
 #define PSEG_XB(MT_, NT_)                                                                        \
     if (MT == MT_ && NT == NT_) {                                                                \
         PSEG_TRY((launch_xb<MT_, NT_>(a, THH, TWH, grid, lds, st)));                             \
-        return 1;                                                                                \
+        return pooled ? 2 : 1;                                                                   \
     }
     PSEG_XB(4, 1) PSEG_XB(4, 2) PSEG_XB(4, 3) PSEG_XB(4, 4)
     PSEG_XB(2, 1) PSEG_XB(2, 2) PSEG_XB(2, 3) PSEG_XB(2, 4)

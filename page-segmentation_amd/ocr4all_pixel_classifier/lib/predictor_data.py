@@ -27,9 +27,15 @@ class LazyArray:
 
 class Prediction(_PredictionFields):
     """One predicted page: label map (H,W) int64, probabilities (H,W,C) float32, the input record
-    (lib/predictor_data.py:12-15: a NamedTuple of these three).  `probabilities` may be handed in as a LazyArray; it
-    is resolved on attribute access, indexing and unpacking, so readers always see an ndarray."""
+    (lib/predictor_data.py:12-15: a NamedTuple of these three).  `labels` (the device chain hands down the compact uint8
+    map; the int64 form of the reference is made on first read) and `probabilities` may be handed in as LazyArrays; they
+    are resolved on attribute access, indexing and unpacking, so readers always see an ndarray."""
     __slots__ = ()
+
+    @property
+    def labels(self):
+        v = tuple.__getitem__(self, 0)
+        return v.get() if isinstance(v, LazyArray) else v
 
     @property
     def probabilities(self):

@@ -16,16 +16,16 @@ FLAG_BATCHNORM = 1
 EXPORTED_SYMBOLS = (
     "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_create_ex", "pseg_destroy",
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
-    "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
+    "pseg_predict", "pseg_predict_device", "pseg_predict_batch", "pseg_predict_chain", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
     "pseg_host_alloc", "pseg_host_free", "pseg_host_register", "pseg_host_unregister",
     "pseg_predict_margin_device", "pseg_predict_exact_labels_device", "pseg_predict_exact_labels", "pseg_label_exact_stats", "pseg_label_exact_stats_ex",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
     "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_set_loss", "pseg_train_set_dropout_seed", "pseg_train_forward_backward", "pseg_train_forward_backward_f32", "pseg_train_grad_buffer", "pseg_train_metrics",
     "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
     "pseg_cc_vote", "pseg_cc_vote_device", "pseg_cc_vote_device_u8", "pseg_release_workspace", "pseg_bbox_fill",
-    "pseg_masks", "pseg_masks_device", "pseg_masks_device_u8",
+    "pseg_masks", "pseg_masks_device", "pseg_masks_device_u8", "pseg_bbox_fill_device_u8",
     "pseg_otsu_char_height",
-    "pseg_rescale_shape", "pseg_gaussian_kernel", "pseg_resize_nearest", "pseg_scale_image",
+    "pseg_rescale_shape", "pseg_gaussian_kernel", "pseg_resize_nearest", "pseg_resize_nearest_device", "pseg_scale_image",
     "pseg_prepare_images", "pseg_affine_warp",
     "pseg_eval_confusion", "pseg_cc_label", "pseg_cc_tables",
 )
@@ -65,6 +65,9 @@ def lib():
     L.pseg_predict.argtypes = [vp, vp, i, i, vp, vp, vp]
     L.pseg_predict_device.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp]
     L.pseg_predict_batch.argtypes = [vp, i, vp, vp, vp, vp, vp]
+    L.pseg_predict_chain.argtypes = [vp, vp, i, i, i, i, vp, c.POINTER(i), i, c.c_uint, vp, vp, vp, i, vp, vp, vp, vp]
+    L.pseg_bbox_fill_device_u8.argtypes = [i, vp, vp, i, i, i, vp]
+    L.pseg_resize_nearest_device.argtypes = [i, vp, i, i, i, vp, i, i, vp]
     L.pseg_predict_margin_device.argtypes = [vp, vp, i, i, vp, vp, vp]
     L.pseg_predict_exact_labels_device.argtypes = [vp, vp, i, i, vp, vp, vp, vp]
     L.pseg_predict_exact_labels.argtypes = [vp, vp, i, i, vp, vp]
@@ -159,6 +162,58 @@ def pinned_empty(shape, dtype=np.uint8):
     buf._pseg_block = blk                       # keeps the block alive as long as any view of the buffer
     a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
     return a
+
+
+class _PinnedPool:
+    """Recycled page-locked blocks for arrays handed to callers (the Predictor chain's label maps and masks): pinning
+    150 MB per call costs more than the chain itself, and a fresh pageable array that size pays ~18 ms of first-touch
+    page faults before the copy starts.  A block returns to the pool when the last NumPy view of it is collected."""
+    MAX_BYTES = 2 << 30
+
+    def __init__(self):
+        self.free, self.held = {}, 0
+
+    def take(self, nbytes):
+        lst = self.free.get(nbytes)
+        if lst:
+            self.held -= nbytes
+            return lst.pop()
+        return _PinnedBlock(nbytes)
+
+    def give(self, blk):
+        if self.held + blk.nbytes > self.MAX_BYTES:
+            return                                   # dropped: _PinnedBlock.__del__ frees it
+        self.free.setdefault(blk.nbytes, []).append(blk)
+        self.held += blk.nbytes
+
+    def clear(self):
+        self.free, self.held = {}, 0
+
+
+_POOL = _PinnedPool()
+
+
+class _PooledLease:
+    def __init__(self, blk):
+        self.blk = blk
+
+    def __del__(self):
+        try:
+            _POOL.give(self.blk)
+        except Exception:
+            pass
+
+
+def pinned_empty_pooled(shape, dtype=np.uint8):
+    """As pinned_empty, from the recycling pool (sizes rounded up to 1 MiB so that pages of one format share blocks)."""
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape, dtype=np.int64))
+    n = max(count * dt.itemsize, 1)
+    n = (n + (1 << 20) - 1) >> 20 << 20
+    blk = _POOL.take(n)
+    buf = (ctypes.c_char * n).from_address(blk.ptr)
+    buf._pseg_lease = _PooledLease(blk)
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
 
 
 def pinned_copy(a):
@@ -285,6 +340,41 @@ class Engine:
                 "referee_area_frac": float(v[4]), "tau_escalations": int(v[5]), "whole_page_fallback": int(v[6]),
                 "labels_changed": int(v[7]), "margin_err_running": float(v[8]), "referee_rects": int(v[9]),
                 "referee_cost_vs_full_page": float(v[10]), "flag_block": int(v[11])}
+
+    POST_OPS = {"cc_vote": 1, "bbox": 2}
+
+    def predict_chain(self, image, binary=None, out_shape=None, post_ops=(), exact_labels=False, labels="u8", lut=None,
+                      masks=False):
+        """The Predictor chain on the device (pseg_predict_chain; lib/predictor.py:32-54): predict -> [nearest resize of
+        the label map to out_shape] -> post-processors ("cc_vote" / "bbox", in order) -> [the four masks].  `binary` must
+        have the label map's final shape.  Returns {"labels": uint8 or int64 map or None, "masks": (color, overlay,
+        inverted, fg_color) or None}; the arrays live in recycled page-locked memory."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        H, W = img.shape[:2]
+        Ho, Wo = (int(out_shape[0]), int(out_shape[1])) if out_shape is not None else (0, 0)
+        Hl, Wl = (Ho, Wo) if Ho > 0 else (H, W)
+        b = None
+        if binary is not None:
+            b = np.ascontiguousarray(binary, dtype=np.uint8)
+            if b.shape != (Hl, Wl):
+                raise PsegError("binary has shape %r, the label map %r" % (b.shape, (Hl, Wl)))
+        ops = (ctypes.c_int * max(len(post_ops), 1))(*[self.POST_OPS[o] if isinstance(o, str) else int(o) for o in post_ops])
+        lab = None
+        if labels == "u8":
+            lab = pinned_empty_pooled((Hl, Wl), np.uint8)
+        elif labels == "i64":
+            lab = pinned_empty_pooled((Hl, Wl), np.int64)
+        elif labels is not None:
+            raise PsegError("labels must be 'u8', 'i64' or None")
+        t = None
+        outs = [None] * 4
+        if masks:
+            t = np.ascontiguousarray(lut, dtype=np.uint8).reshape(-1, 3)
+            outs = [pinned_empty_pooled((Hl, Wl, 3), np.uint8) for _ in range(4)]
+        _check(lib().pseg_predict_chain(self._h, _ptr(img), H, W, Ho, Wo, _ptr(b), ops, len(post_ops), 1 if exact_labels else 0,
+                                        _ptr(lab) if labels == "i64" else None, _ptr(lab) if labels == "u8" else None,
+                                        _ptr(t), 0 if t is None else t.shape[0], *[_ptr(o) for o in outs]))
+        return {"labels": lab, "masks": tuple(outs) if masks else None}
 
     def predict_batch(self, images, dtype=np.int64, out=None):
         """Label maps of a list of (H,W) uint8 pages (sizes may differ); copies overlap compute.

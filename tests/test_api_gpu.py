@@ -165,3 +165,73 @@ def test_config5_size_pipeline_properties(gpu, oracle_mod):
     color, overlay, inverted, fg = gpu.masks(v1, binary, lut)
     assert np.array_equal(color, lut[v1]) and (overlay[binary == 1] == 0).all() and np.array_equal(inverted, fg)
     eb.close()
+
+
+# ---- the Predictor chain on the device (pseg_predict_chain) against the stage-by-stage host chain -----------------------------
+
+def _host_chain(pred, data, want_masks):
+    """The reference's chain stage by stage through host arrays (lib/predictor.py:32-54), as rounds 1-2 ran it."""
+    from ocr4all_pixel_classifier.lib.output import generate_output_masks
+    d, _, lab = pred._labels(data)
+    return (d, lab, generate_output_masks(d, lab, pred.settings.color_map) if want_masks else None)
+
+
+@pytest.mark.parametrize("exact", [True, "labels", False])
+@pytest.mark.parametrize("posts,high_res", [(["cc_majority"], False), (["bounding_boxes"], False), (["cc_majority", "bounding_boxes"], True),
+                                            ([], True), (["bounding_boxes", "cc_majority"], False)])
+def test_predictor_device_chain_equals_the_host_chain(gpu, oracle_mod, exact, posts, high_res):
+    """Predictor.predict_single / predict_masks keep the uint8 label map on the device from the network through
+    scale_to_original_shape, the registered post-processors and generate_output_masks; the results must be array_equal to
+    the stage-by-stage host chain (int64 NumPy maps between the stages, as the reference has them)."""
+    from ocr4all_pixel_classifier.lib.predictor import Predictor
+    from ocr4all_pixel_classifier.lib.predictor_data import PredictSettings
+    from ocr4all_pixel_classifier.lib.postprocess import find_postprocessor
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    import dataclasses
+    net, Wt, data = _setup(gpu, oracle_mod, exact=exact, shape=(160, 96), page=4)
+    if high_res:
+        rng = np.random.default_rng(1)
+        orig = (231, 137)                                   # the scan's own resolution: not a multiple of anything
+        data = dataclasses.replace(data, original_shape=orig, orig_binary=(rng.random(orig) < 0.2).astype(np.uint8))
+    cm = ColorMap({"(255, 255, 255)": [0, "bg"], "(255, 0, 0)": [1, "text"], "(0, 255, 0)": [2, "image"]})
+    settings = PredictSettings(n_classes=3, color_map=cm, post_process=[find_postprocessor(p) for p in posts], high_res_output=high_res)
+    pred = Predictor(settings, net)
+    assert pred._chain_ops() == [{"cc_majority": "cc_vote", "bounding_boxes": "bbox"}[p] for p in posts]
+    d_h, lab_h, masks_h = _host_chain(pred, data, True)
+    p = pred.predict_single(data)
+    assert p.labels.dtype == np.int64 and p.labels.shape == lab_h.shape and np.array_equal(p.labels, lab_h)
+    assert np.array_equal(np.asarray(p.data.binary), np.asarray(d_h.binary)) and np.array_equal(p.data.image, d_h.image)
+    lab2, prob2, d2 = p                                         # unpacking resolves the lazy fields
+    assert np.array_equal(lab2, lab_h) and prob2.shape == data.image.shape + (3,)
+    m = pred.predict_masks(data)
+    for got, want in zip((m.color, m.overlay, m.inverted_overlay, m.fg_color_mask),
+                         (masks_h.color, masks_h.overlay, masks_h.inverted_overlay, masks_h.fg_color_mask)):
+        assert got.dtype == np.uint8 and np.array_equal(got, want)
+    # results stay valid after later calls (the recycled pinned blocks are not handed out twice while alive)
+    keep = p.labels.copy()
+    for _ in range(3):
+        pred.predict_masks(data)
+        pred.predict_single(data)
+    assert np.array_equal(p.labels, keep) and np.array_equal(m.color, masks_h.color)
+
+
+def test_predictor_chain_falls_back_for_foreign_postprocessors(gpu, oracle_mod):
+    from ocr4all_pixel_classifier.lib.predictor import Predictor
+    from ocr4all_pixel_classifier.lib.predictor_data import PredictSettings
+    from ocr4all_pixel_classifier.lib.postprocess import find_postprocessor
+    from ocr4all_pixel_classifier.lib.colors import ColorMap
+    net, Wt, data = _setup(gpu, oracle_mod, exact=True)
+    seen = []
+
+    def mine(pred, d):
+        seen.append(pred.dtype)
+        return np.where(pred == 1, 2, pred)
+
+    cm = ColorMap({"(255, 255, 255)": [0, "bg"], "(255, 0, 0)": [1, "text"], "(0, 255, 0)": [2, "image"]})
+    pred = Predictor(PredictSettings(n_classes=3, color_map=cm, post_process=[find_postprocessor("cc_majority"), mine]), net)
+    assert pred._chain_ops() is None
+    p = pred.predict_single(data)
+    assert seen == [np.dtype(np.int64)] and not (p.labels == 1).any()
+    lab_o = oracle_mod.predict_single_data("fcn_skip", Wt, data.image, "f32")[2]
+    want = oracle_mod.vote_connected_component_class(lab_o, data.binary)
+    assert np.array_equal(p.labels, np.where(want == 1, 2, want))

@@ -320,6 +320,10 @@ __global__ void vote_apply_kernel(const int* L, const int* hist, LT* pred, int n
     pred[p] = (LT)best;
 }
 
+// (Round 3 measured a tile-local variant -- 32 x 64 tiles labelled AND counted in LDS, only components that cross a tile
+// border going through global memory, 4 launches, ~3 B/px of traffic: 0.262 ms against 0.182 ms for the path below on
+// configs[4]'s page, 0.161 against 0.145 ms with the speckled image rectangles blanked.  Its LDS union-find over 2 048
+// pixels per workgroup (112 us) costs more than the 32-bit label traffic it saves; removed again)
 // Label / histogram workspace of the vote: grow-only, one per device, shared by every caller.  A 4096x3072 6-class
 // page needs 50 + 302 MB; allocating and freeing it per call cost more than the kernels.  Calls are ordered by an
 // event: a call on another stream than the previous user's first waits for that user's kernels, so two streams (or

@@ -103,3 +103,61 @@ def test_cc_vote_random_shapes_densities_and_class_counts(gpu, oracle_mod):
             want = oracle_mod.vote_connected_component_class(pred, binary)
             got = gpu.cc_vote(pred.copy(), binary, C)
             assert np.array_equal(got, want), (H, W, dens, C)
+
+
+def _vote_u8_device(gpu, pred_u8, binary, C):
+    """pseg_cc_vote_device_u8 on device buffers (the entry the Predictor chain and bench.py's configs[4] leg use)."""
+    import ctypes
+    import torch
+    from pseg_amd import engine as E
+    dev = torch.device("cuda:0")
+    d_p = torch.from_numpy(pred_u8.copy()).to(dev)
+    d_b = torch.from_numpy(binary).to(dev)
+    H, W = pred_u8.shape
+    st = torch.cuda.current_stream(dev).cuda_stream
+    vp = ctypes.c_void_p
+    E._check(E.lib().pseg_cc_vote_device_u8(0, vp(d_p.data_ptr()), vp(d_b.data_ptr()), H, W, C, vp(st)))
+    torch.cuda.synchronize()
+    return d_p.cpu().numpy()
+
+
+def test_cc_vote_uint8_and_int64_maps_on_shapes_around_the_tile_edges(gpu, oracle_mod):
+    """The vote on uint8 (device entry) and int64 maps gives the oracle's map bit for bit: shapes around the labelling tile
+    edges (16 x 64) and the counting tiles (32 x 32), specks to one percolating component, long thin components across many
+    tiles, labels outside [0, C) (ignored by the count)."""
+    rng = np.random.default_rng(5)
+    cases = []
+    for (H, W) in [(1, 1), (32, 64), (33, 65), (31, 63), (64, 128), (65, 200), (200, 131), (300, 517)]:
+        for dens, C in [(0.05, 3), (0.4, 6), (0.55, 8), (0.97, 2)]:
+            binary = (rng.random((H, W)) < dens).astype(np.uint8)
+            pred = rng.integers(0, C, size=(H, W)).astype(np.int64)
+            cases.append((pred, binary, C))
+    # horizontal and vertical bars crossing every tile, a frame, a comb
+    H, W = 130, 260
+    binary = np.zeros((H, W), np.uint8)
+    binary[5, :] = 1; binary[:, 7] = 1; binary[40, 3:250] = 1; binary[64:66, :] = 1; binary[:, 128] = 1
+    binary[100:120, ::2] = 1; binary[120, :] = 1
+    pred = ((np.add.outer(np.arange(H), np.arange(W)) // 9) % 5).astype(np.int64)
+    cases.append((pred, binary, 5))
+    pred2 = pred.copy(); pred2[::7, ::5] = 7
+    cases.append((np.minimum(pred2, 7), binary, 8))
+    for pred, binary, C in cases:
+        want = oracle_mod.vote_connected_component_class(pred, binary)
+        assert np.array_equal(gpu.cc_vote(pred.copy(), binary, C), want), (pred.shape, C)
+        got8 = _vote_u8_device(gpu, pred.astype(np.uint8), binary, C)
+        assert np.array_equal(got8.astype(np.int64), want), ("u8", pred.shape, C)
+
+
+def test_cc_vote_full_size_page_properties(gpu):
+    """configs[4] size (4096 x 3072, 6 classes), where the oracle is too slow: the vote is idempotent, leaves paper pixels
+    alone, makes every ink run of a row uniform, and the uint8 and int64 entries agree."""
+    from pseg_amd import synth
+    _, binary, mask = synth.synth_page(1000, 4096, 3072, 6)
+    rng = np.random.default_rng(0)
+    pred = np.where(rng.random(mask.shape) < 0.2, rng.integers(0, 6, mask.shape), mask).astype(np.uint8)
+    voted = _vote_u8_device(gpu, pred, binary, 6)
+    assert np.array_equal(_vote_u8_device(gpu, voted, binary, 6), voted)
+    assert np.array_equal(voted[binary == 0], pred[binary == 0])
+    same_run = (binary[:, 1:] != 0) & (binary[:, :-1] != 0)
+    assert np.array_equal(voted[:, 1:][same_run], voted[:, :-1][same_run])
+    assert np.array_equal(gpu.cc_vote(pred.astype(np.int64), binary, 6), voted.astype(np.int64))

@@ -137,7 +137,8 @@ __device__ __forceinline__ void lds_union(int* lab, int a, int b) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* bin, const int64_t* cls, int* L, int H, int W) {
+__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* bin, const int64_t* cls, int* L, int H, int W, int* hist = nullptr,
+                                                       int ncls = 0) {
     __shared__ int lab[CT_H * CT_W];
     const int tiles_x = (W + CT_W - 1) / CT_W;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -191,6 +192,10 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* bin, const
         if (fgr[j]) {
             const int root = lds_find(lab, r * CT_W + lane);
             g = (ty * CT_H + root / CT_W) * W + tx * CT_W + (root % CT_W);
+            // the vote's counters live in the root's row of a page-sized array: every tile-local root clears its row here (a
+            // component's final root is one of them: border unions only ever redirect a root to another tile's root)
+            if (hist && root == r * CT_W + lane)
+                for (int c = 0; c < ncls; ++c) hist[(size_t)g * ncls + c] = 0;
         }
         L[y * W + x] = g;
     }
@@ -240,12 +245,13 @@ static int ccl_run(const uint8_t* d_bin, const int64_t* d_cls, int* d_L, int H, 
         ccl_rows_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
         ccl_cols_kernel<MODE><<<grid, 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
     } else {
-        ccl_tile_kernel<MODE><<<cdiv(W, CT_W) * cdiv(H, CT_H), 256, 0, st>>>(d_bin, d_cls, d_L, H, W);
+        ccl_tile_kernel<MODE><<<cdiv(W, CT_W) * cdiv(H, CT_H), 256, 0, st>>>(d_bin, d_cls, d_L, H, W, d_hist, ncls);
         const int nby = (H - 1) / CT_H, nbx = (W - 1) / CT_W;
         if (nby * W + nbx * H > 0)
             ccl_border_kernel<MODE><<<cdiv(nby * W + nbx * H, 256), 256, 0, st>>>(d_bin, d_cls, d_L, H, W, nby, nbx);
     }
-    ccl_compress_kernel<<<grid, 256, 0, st>>>(d_L, n, d_hist, ncls);
+    // the vote (d_hist given, tile path) resolves and compresses the labels inside its counting pass: one pass over L less
+    if (!d_hist || PSEG_KNOB("PSEG_CCL_GLOBAL")) ccl_compress_kernel<<<grid, 256, 0, st>>>(d_L, n, d_hist, ncls);
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
 }
@@ -266,7 +272,7 @@ int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hi
 // instead of a page-sized memset.
 constexpr int VT = 32, VSLOTS = 2048;
 template <typename LT>
-__global__ __launch_bounds__(256) void vote_count_kernel(const int* L, const LT* pred, int* hist, int H, int W, int ncls) {
+__global__ __launch_bounds__(256) void vote_count_kernel(int* L, const LT* pred, int* hist, int H, int W, int ncls) {
     __shared__ int keys[VSLOTS];
     __shared__ int vals[VSLOTS];
     for (int i = threadIdx.x; i < VSLOTS; i += 256) { keys[i] = -1; vals[i] = 0; }
@@ -289,7 +295,12 @@ __global__ __launch_bounds__(256) void vote_count_kernel(const int* L, const LT*
             int k = -1;
             if (x < W) {
                 const size_t p = (size_t)y * W + x;
-                const int r = L[p];
+                int r = L[p];
+                if (r >= 0) {                                        // resolve to the component's root and leave it in L for the apply pass
+                    const int r0 = r;
+                    r = uf_find(L, r);
+                    if (r != r0) L[p] = r;
+                }
                 const int64_t c = (int64_t)pred[p];
                 if (r >= 0 && c >= 0 && c < ncls) k = r * ncls + (int)c;
             }

@@ -43,6 +43,12 @@ struct TrainState {
     std::vector<size_t> tbytes;
     float* d_wd = nullptr;       // scratch: transformed weights for dgrad
     size_t wd_bytes = 0;
+    float* d_wpart = nullptr;    // scratch: per-strip partial weight / bias gradients of the layer being reduced (deterministic sums)
+    size_t wpart_bytes = 0;
+    float* d_mpart = nullptr;    // scratch: per-block partial loss / metric sums
+    size_t mpart_bytes = 0;
+    void* d_bpart = nullptr;     // scratch: per-block partial bias gradients of a transposed conv (float64)
+    size_t bpart_bytes = 0;
     float* d_tmp = nullptr;      // scratch: data gradient at the conv's input extent (upsampled / pre-activation sources)
     float* d_tmp2 = nullptr;     // scratch: zero-dilated output gradient (stride-2 convs)
     size_t tmp_bytes = 0, tmp2_bytes = 0;
@@ -65,6 +71,7 @@ void train_free(Engine& e) {
     (void)hipFree(t->d_part); (void)hipFree(t->d_slice_nblk); (void)hipFree(t->d_slice_pi);
     for (auto p : t->tgrad) (void)hipFree(p);
     (void)hipFree(t->d_wd); (void)hipFree(t->d_logits); (void)hipFree(t->d_dlogits);
+    (void)hipFree(t->d_wpart); (void)hipFree(t->d_mpart); (void)hipFree(t->d_bpart);
     (void)hipFree(t->d_mask); (void)hipFree(t->d_img); (void)hipFree(t->d_tmp); (void)hipFree(t->d_tmp2);
     delete t;
     e.train = nullptr;
@@ -74,35 +81,54 @@ void train_free(Engine& e) {
 // kernels
 // ---------------------------------------------------------------------------------------------
 // acc layout: [0] sum loss, [1] count correct, [2..2+C) intersection_c, [2+C..2+2C) sum_c
-__global__ void ce_metrics_kernel(const float* logits, const uint8_t* labels, int n, int C, float inv_n,
-                                  float* dlogits, float* acc) {
-    __shared__ float sh[2 + 2 * PSEG_MAXC];
-    if (threadIdx.x < 2 + 2 * PSEG_MAXC) sh[threadIdx.x] = 0.0f;
-    __syncthreads();
+// Deterministic: a thread's terms are reduced inside its wave by a butterfly, the four waves in order, and the block's
+// sums go to ITS row of `part` ([block][2 + 2C]); metrics_final_kernel adds the rows in a fixed tree.  (LDS and global float
+// atomics made the last bits of the reported loss -- and with dice / jaccard losses the gradient -- depend on arrival order.)
+__global__ __launch_bounds__(256) void ce_metrics_kernel(const float* logits, const uint8_t* labels, int n, int C, float inv_n,
+                                                         float* dlogits, float* part) {
+    __shared__ float ws[4][2 + 2 * PSEG_MAXC];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) {
-        const float* z = logits + (size_t)p * C;
-        const int y = labels[p];
-        float m = z[0];
-        int am = 0;
-        for (int c = 1; c < C; ++c)
-            if (z[c] > m) { m = z[c]; am = c; }
-        float s = 0.0f;
-        for (int c = 0; c < C; ++c) s += expf(z[c] - m);
-        const float lse = logf(s) + m;
-        const float zy = (y < C) ? z[y] : 0.0f;
-        atomicAdd(&sh[0], lse - zy);
-        atomicAdd(&sh[1], am == y ? 1.0f : 0.0f);
-        for (int c = 0; c < C; ++c) {
-            const float pr = expf(z[c] - m) / s;
-            const float oh = (c == y) ? 1.0f : 0.0f;
-            dlogits[(size_t)p * C + c] = (pr - oh) * inv_n;
-            atomicAdd(&sh[2 + c], oh * pr);
-            atomicAdd(&sh[2 + C + c], oh + pr);
-        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool live = p < n;
+    const float* z = logits + (size_t)(live ? p : 0) * C;
+    const int y = live ? labels[p] : 0;
+    float m = z[0];
+    int am = 0;
+    for (int c = 1; c < C; ++c)
+        if (z[c] > m) { m = z[c]; am = c; }
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += expf(z[c] - m);
+    const float lse = logf(s) + m;
+    const float zy = (y < C) ? z[y] : 0.0f;
+    auto wsum = [&](float v) {
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        return v;
+    };
+    const float t0 = wsum(live ? lse - zy : 0.0f), t1 = wsum(live && am == y ? 1.0f : 0.0f);
+    if (lane == 0) { ws[wave][0] = t0; ws[wave][1] = t1; }
+    for (int c = 0; c < C; ++c) {
+        const float pr = expf(z[c] - m) / s;
+        const float oh = (c == y) ? 1.0f : 0.0f;
+        if (live) dlogits[(size_t)p * C + c] = (pr - oh) * inv_n;
+        const float u0 = wsum(live ? oh * pr : 0.0f), u1 = wsum(live ? oh + pr : 0.0f);
+        if (lane == 0) { ws[wave][2 + c] = u0; ws[wave][2 + C + c] = u1; }
     }
     __syncthreads();
-    if (threadIdx.x < 2 + 2 * C) atomicAdd(&acc[threadIdx.x], sh[threadIdx.x]);
+    if ((int)threadIdx.x < 2 + 2 * C)
+        part[(size_t)blockIdx.x * (2 + 2 * C) + threadIdx.x] = ((ws[0][threadIdx.x] + ws[1][threadIdx.x]) + ws[2][threadIdx.x]) + ws[3][threadIdx.x];
+}
+// acc[slot] = sum over the blocks' rows, strided over the threads in order, then a fixed tree (one workgroup per slot)
+__global__ __launch_bounds__(256) void metrics_final_kernel(const float* part, int nblk, int nslot, float* acc) {
+    __shared__ float sh[256];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += part[(size_t)i * nslot + blockIdx.x];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc[blockIdx.x] = sh[0];
 }
 
 // Gradient of the alternative losses of lib/metrics.py:72-112 with respect to the logits (second pass:
@@ -263,7 +289,56 @@ struct WgradArgs {
     // read through a nearest x2 upsample (Hx, Wx are then the upsampled extents, xpitch the stored row pitch),
     // pre-activation ReLU on X (res_unet)
     int stride = 1, xup = 0, in_relu = 0;
+    // Deterministic form (default): a workgroup does not add its strip's partial sums into dW / dB with float atomics (whose
+    // arrival order, and with it the last bits of the sum, changed from run to run) but stores them -- every element of its
+    // (tap, channel block) exactly once -- into its own row of a scratch array, part[strip][tap][ci][co] (XC channels of this
+    // launch) and partB[strip * 4 + wave][co]; wgrad_reduce_kernel then sums the strips in index order.
+    float* part = nullptr;
+    float* partB = nullptr;
+    size_t pstride = 0;      // floats per strip row of `part` = taps * XC * Cout
 };
+
+// one weight-gradient element / one bias partial of a strip leaves the kernel
+__device__ __forceinline__ void wg_out(const WgradArgs& a, int strip, int tap, int ci, int co, float v) {
+    if (a.part) a.part[(size_t)strip * a.pstride + ((size_t)tap * a.XC + ci) * a.Cout + co] = v;
+    else atomicAdd(&a.dW[((size_t)tap * a.Cin + a.ci0 + ci) * a.Cout + co], v);
+}
+__device__ __forceinline__ void wg_out_bias(const WgradArgs& a, int strip, int wave, int co, float v) {
+    if (a.partB) a.partB[((size_t)strip * 4 + wave) * a.Cout + co] = v;
+    else atomicAdd(&a.dB[co], v);
+}
+
+// dW[tap][ci0 + ci][co] = sum over the strips of part[strip][tap][ci][co] in a FIXED association: groups of WGR_GROUP
+// consecutive strips are summed in strip order (wgrad_reduce_groups_kernel, in place into the group's first row: one thread
+// per (element, group), so a 15 000-element layer with 340 strips still fills the chip), then the groups in group order.
+// dB[co] = the same over the 4 * nstrips bias rows, in float64 (a bias gradient is a sum of a signed map that cancels heavily).
+constexpr int WGR_GROUP = 16;
+__global__ void wgrad_reduce_groups_kernel(float* part, size_t pstride, int nstrips) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= pstride) return;
+    const int k0 = blockIdx.y * WGR_GROUP, k1 = min(k0 + WGR_GROUP, nstrips);
+    float s = 0.0f;
+    for (int k = k0; k < k1; ++k) s += part[(size_t)k * pstride + e];
+    part[(size_t)k0 * pstride + e] = s;
+}
+__global__ void wgrad_reduce_kernel(const float* part, size_t pstride, int nstrips, int taps, int XC, int Cout, int Cin, int ci0, float* dW,
+                                    const float* partB, float* dB) {
+    const size_t n = (size_t)taps * XC * Cout;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int k = 0; k < nstrips; k += WGR_GROUP) s += part[(size_t)k * pstride + e];
+        const int co = (int)(e % Cout);
+        const size_t tc = e / Cout;
+        const int ci = (int)(tc % XC), tap = (int)(tc / XC);
+        dW[((size_t)tap * Cin + ci0 + ci) * Cout + co] = s;
+    }
+    if (partB && blockIdx.x == 0)
+        for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
+            double s = 0.0;
+            for (int k = 0; k < 4 * nstrips; ++k) s += (double)partB[(size_t)k * Cout + co];
+            dB[co] = (float)s;
+        }
+}
 
 constexpr int WG_PC = 32;  // pixels per LDS chunk
 
@@ -341,12 +416,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ci = tci * 4 + i, co = tco * 4 + j;
-                    if (ci < a.XC && co < a.Cout)
-                        atomicAdd(&a.dW[((size_t)tap * a.Cin + a.ci0 + ci) * a.Cout + co], acc[q][i * 4 + j]);
+                    if (ci < a.XC && co < a.Cout) wg_out(a, blockIdx.x, tap, ci, co, acc[q][i * 4 + j]);
                 }
         }
     }
-    if (a.dB && tap == 0 && (int)threadIdx.x < a.Cout) atomicAdd(&a.dB[threadIdx.x], bsum);
+    if (a.dB && tap == 0 && (int)threadIdx.x < a.Cout)
+        for (int w = 0; w < 4; ++w) wg_out_bias(a, blockIdx.x, w, threadIdx.x, w == 0 ? bsum : 0.0f);
 }
 
 // Matrix-core weight gradient.  dW[tap][ci][co] += sum over pixels of X[pixel + tap][ci] * dY[pixel][co]
@@ -474,8 +549,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
                     {
                         const int e = threadIdx.x, row = e >> 4, col = e & 15;
                         const int ci = i * 16 + row, co = j * 16 + col;
-                        if (ci < XCb && co < COb)
-                            atomicAdd(&a.dW[((size_t)(tap0 + k) * a.Cin + a.ci0 + xc0 + ci) * a.Cout + yc0 + co], red[e]);
+                        if (ci < XCb && co < COb) wg_out(a, blockIdx.y, tap0 + k, xc0 + ci, yc0 + co, red[e]);
                     }
                     __syncthreads();
                 }
@@ -485,7 +559,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
             float v = bacc[j];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (g == 0 && j < tiles_co && j * 16 + p16 < COb) atomicAdd(&a.dB[yc0 + j * 16 + p16], v);
+            if (g == 0 && j < tiles_co && j * 16 + p16 < COb) wg_out_bias(a, blockIdx.y, wave, yc0 + j * 16 + p16, v);
         }
     }
 }
@@ -636,8 +710,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradArgs a) {
                     {
                         const int e = threadIdx.x, row = e >> 4, col = e & 15;
                         const int ci = i * 16 + row, co = j * 16 + col;
-                        if (ci < XCb && co < COb)
-                            atomicAdd(&a.dW[((size_t)(tap0 + k) * a.Cin + a.ci0 + xc0 + ci) * a.Cout + yc0 + co], red[e]);
+                        if (ci < XCb && co < COb) wg_out(a, blockIdx.y, tap0 + k, xc0 + ci, yc0 + co, red[e]);
                     }
                     __syncthreads();
                 }
@@ -647,7 +720,7 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradArgs a) {
             float v = bacc[j];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (g == 0 && j < tiles_co && j * 16 + p16 < COb) atomicAdd(&a.dB[yc0 + j * 16 + p16], v);
+            if (g == 0 && j < tiles_co && j * 16 + p16 < COb) wg_out_bias(a, blockIdx.y, wave, yc0 + j * 16 + p16, v);
         }
     }
 }
@@ -742,7 +815,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(WgradArgs a) {
                 {
                     const int e = threadIdx.x, row = e >> 4, col = e & 15;
                     const int tap = i * 16 + row, co = j * 16 + col;
-                    if (tap < KK && co < a.Cout) atomicAdd(&a.dW[((size_t)tap * a.Cin + a.ci0) * a.Cout + co], red[e]);
+                    if (tap < KK && co < a.Cout) wg_out(a, blockIdx.x, tap, 0, co, red[e]);
                 }
                 __syncthreads();
             }
@@ -752,64 +825,107 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(WgradArgs a) {
             float v = bacc[j];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (g == 0 && j < tiles_co && j * 16 + p16 < a.Cout) atomicAdd(&a.dB[j * 16 + p16], v);
+            if (g == 0 && j < tiles_co && j * 16 + p16 < a.Cout) wg_out_bias(a, blockIdx.x, wave, j * 16 + p16, v);
         }
     }
 }
 
-static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
-    // grid = (strips, taps) for the scalar kernel; the matrix-core kernel takes (taps, strips)
-    if (a.XC == 1 && a.mode == 0 && a.stride == 1 && !a.xup && !a.in_relu && a.KW * a.KW <= 32 && a.Cout <= 64 && !PSEG_KNOB("PSEG_WGRAD_NO_C1") &&
-        !PSEG_KNOB("PSEG_WGRAD_SCALAR")) {
-        WgradArgs c = a;
-        c.strip_rows = std::max(1, cdiv(a.Hy, 1024));
-        const int nwg = cdiv(a.Hy, c.strip_rows), tj = cdiv(a.Cout, 16);
-        if (a.KW * a.KW <= 16) {
-            if (tj <= 2) wgrad_c1_kernel<1, 2><<<nwg, 256, 0, st>>>(c);
-            else wgrad_c1_kernel<1, 4><<<nwg, 256, 0, st>>>(c);
-        } else {
-            if (tj <= 2) wgrad_c1_kernel<2, 2><<<nwg, 256, 0, st>>>(c);
-            else wgrad_c1_kernel<2, 4><<<nwg, 256, 0, st>>>(c);
-        }
-        PSEG_HIP(hipGetLastError());
-        return PSEG_OK;
-    }
-    // stride-1 convolutions: the LDS-staged kernel (same instances, same grids)
+// Chooses the kernel instance for a layer, launches it and (deterministic form) sums the strips' partial results.
+// grid = (strips, taps) as the scalar kernel takes it; `scratch` / `scratch_cap` = the train state's partial-sum buffer.
+static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float** scratch, size_t* scratch_cap) {
+    WgradArgs a = a_in;
+    const int itH = a.mode == 0 ? a.Hy : a.Hx;
+    const int taps = (int)grid.y;
+    // ---- which instance, with which strips
+    enum { V_C1, V_KX5, V_TAP, V_WIDE, V_SCALAR } variant;
+    const bool scalar = PSEG_KNOB("PSEG_WGRAD_SCALAR") != nullptr;
     const bool lds = a.mode == 0 && a.stride == 1 && !a.xup && !PSEG_KNOB("PSEG_WGRAD_NO_LDS");
-    if (a.XC <= 16 * WGM_MAXT && a.Cout <= 16 * WGM_MAXT && !PSEG_KNOB("PSEG_WGRAD_SCALAR")) {
-        const int ti = (a.XC + 15) / 16, tj = (a.Cout + 15) / 16;
+    const int ti = (a.XC + 15) / 16, tj = (a.Cout + 15) / 16;
+    if (a.XC == 1 && a.mode == 0 && a.stride == 1 && !a.xup && !a.in_relu && a.KW * a.KW <= 32 && a.Cout <= 64 && !PSEG_KNOB("PSEG_WGRAD_NO_C1") && !scalar) {
+        variant = V_C1;
+        a.strip_rows = std::max(1, cdiv(a.Hy, 1024));
+    } else if (a.XC <= 16 * WGM_MAXT && a.Cout <= 16 * WGM_MAXT && !scalar) {
         // a whole kernel row per workgroup for the small k5 layers (mode 0: taps of a row share dY)
-        if (a.mode == 0 && a.KW == 5 && grid.y % 5 == 0 && !PSEG_KNOB("PSEG_WGRAD_KX1")) {
-            WgradArgs a5 = a;                                  // five times fewer "taps": five times more strips
-            a5.strip_rows = std::max(1, a.strip_rows / 5);
-            const dim3 g5(grid.y / 5, cdiv(a.Hy, a5.strip_rows));
+        if (a.mode == 0 && a.KW == 5 && taps % 5 == 0 && !PSEG_KNOB("PSEG_WGRAD_KX1") && ((ti <= 2 && tj <= 2) || (ti <= 2 && tj <= 3) || (ti <= 1 && tj <= 2))) {
+            variant = V_KX5;                                   // five times fewer "taps": five times more strips
+            a.strip_rows = std::max(1, a.strip_rows / 5);
+        } else {
+            variant = V_TAP;
+        }
+    } else if (!scalar) {
+        variant = V_WIDE;
+    } else {
+        variant = V_SCALAR;
+    }
+    const int nstrips = cdiv(itH, a.strip_rows);
+    // ---- deterministic form: partial sums per strip, then one ordered reduction (PSEG_WGRAD_ATOMIC=1: float atomics)
+    const bool det = !PSEG_KNOB("PSEG_WGRAD_ATOMIC");
+    if (det) {
+        a.pstride = (size_t)taps * a.XC * a.Cout;
+        const size_t need = ((size_t)nstrips * a.pstride + (size_t)4 * nstrips * a.Cout) * sizeof(float);
+        if (*scratch_cap < need) {
+            if (*scratch) { PSEG_HIP(hipStreamSynchronize(st)); (void)hipFree(*scratch); }
+            *scratch = nullptr; *scratch_cap = 0;
+            PSEG_HIP(hipMalloc((void**)scratch, need));
+            *scratch_cap = need;
+        }
+        a.part = *scratch;
+        a.partB = a.dB ? *scratch + (size_t)nstrips * a.pstride : nullptr;
+    }
+    switch (variant) {
+        case V_C1: {
+            if (a.KW * a.KW <= 16) {
+                if (tj <= 2) wgrad_c1_kernel<1, 2><<<nstrips, 256, 0, st>>>(a);
+                else wgrad_c1_kernel<1, 4><<<nstrips, 256, 0, st>>>(a);
+            } else {
+                if (tj <= 2) wgrad_c1_kernel<2, 2><<<nstrips, 256, 0, st>>>(a);
+                else wgrad_c1_kernel<2, 4><<<nstrips, 256, 0, st>>>(a);
+            }
+            break;
+        }
+        case V_KX5: {
+            const dim3 g5(taps / 5, nstrips);
 #define PSEG_WG5(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) {                                                   \
-                if (lds) wgrad_lds_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a5);                                      \
-                else wgrad_mfma_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a5);                                         \
-                PSEG_HIP(hipGetLastError()); return PSEG_OK; }
+                if (lds) wgrad_lds_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a);                                       \
+                else wgrad_mfma_kernel<TI_, TJ_, 5><<<g5, 256, 0, st>>>(a);                                          \
+                break; }
             PSEG_WG5(1, 2) PSEG_WG5(2, 2) PSEG_WG5(2, 3)
 #undef PSEG_WG5
             // (a kernel row per workgroup for the wider layers -- <3,3,5>, <3,4,5>, <4,3,5> on the LDS-staged kernel, 384-497
             // registers, one wave per SIMD -- was measured: 30.17 vs 29.97 ms per step against one tap per workgroup below)
+            return fail(PSEG_EUNSUPPORTED, "no kernel-row weight-gradient instance for %d x %d channels", a.XC, a.Cout);
         }
-        const dim3 g2(grid.y, grid.x);
+        case V_TAP: {
+            const dim3 g2(taps, nstrips);
 #define PSEG_WG(TI_, TJ_) if (ti <= TI_ && tj <= TJ_) {                                                    \
             wgrad_mfma_kernel<TI_, TJ_, 1><<<g2, 256, 0, st>>>(a);   /* one tap per workgroup: the direct kernel is faster than the LDS-staged one */ \
-            PSEG_HIP(hipGetLastError()); return PSEG_OK; }
-        PSEG_WG(1, 2) PSEG_WG(2, 2) PSEG_WG(2, 3) PSEG_WG(3, 3) PSEG_WG(3, 5) PSEG_WG(5, 3) PSEG_WG(5, 5)
+            break; }
+            PSEG_WG(1, 2) PSEG_WG(2, 2) PSEG_WG(2, 3) PSEG_WG(3, 3) PSEG_WG(3, 5) PSEG_WG(5, 3) PSEG_WG(5, 5)
 #undef PSEG_WG
-        return fail(PSEG_EUNSUPPORTED, "no weight-gradient instance for %d x %d channels", a.XC, a.Cout);
-    } else if (!PSEG_KNOB("PSEG_WGRAD_SCALAR")) {
-        // wide layers (unet / res_unet): 64 x 64 channel blocks on blockIdx.z
-        const dim3 g3(grid.y, grid.x, cdiv(a.XC, 64) * cdiv(a.Cout, 64));
-        wgrad_mfma_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
-    } else {
-        const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
-        if (a.stride != 1 || a.xup || a.in_relu || (XCp / 4) * (COp / 4) > 768)
-            return fail(PSEG_EUNSUPPORTED, "the scalar weight-gradient kernel does not cover this layer");
-        wgrad_kernel<<<grid, 256, (size_t)WG_PC * (XCp + COp) * 4, st>>>(a);
+            return fail(PSEG_EUNSUPPORTED, "no weight-gradient instance for %d x %d channels", a.XC, a.Cout);
+        }
+        case V_WIDE: {
+            // wide layers (unet / res_unet): 64 x 64 channel blocks on blockIdx.z
+            const dim3 g3(taps, nstrips, cdiv(a.XC, 64) * cdiv(a.Cout, 64));
+            wgrad_mfma_kernel<4, 4, 1><<<g3, 256, 0, st>>>(a);
+            break;
+        }
+        case V_SCALAR: {
+            const int XCp = (a.XC + 3) & ~3, COp = (a.Cout + 3) & ~3;
+            if (a.stride != 1 || a.xup || a.in_relu || (XCp / 4) * (COp / 4) > 768)
+                return fail(PSEG_EUNSUPPORTED, "the scalar weight-gradient kernel does not cover this layer");
+            wgrad_kernel<<<dim3(nstrips, taps), 256, (size_t)WG_PC * (XCp + COp) * 4, st>>>(a);
+            break;
+        }
     }
     PSEG_HIP(hipGetLastError());
+    if (det) {
+        const size_t n = a.pstride;
+        wgrad_reduce_groups_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)cdiv(nstrips, WGR_GROUP)), 256, 0, st>>>(a.part, a.pstride, nstrips);
+        wgrad_reduce_kernel<<<(int)std::min<size_t>((n + 255) / 256, 2048), 256, 0, st>>>(a.part, a.pstride, nstrips, taps, a.XC, a.Cout, a.Cin, a.ci0, a.dW,
+                                                                                          a.partB, a.dB);
+        PSEG_HIP(hipGetLastError());
+    }
     return PSEG_OK;
 }
 
@@ -852,27 +968,36 @@ __global__ void dilate2_kernel(float* dst, const float* src, const float* maskY,
     }
 }
 
-// dB[co] += sum over pixels of dY' (dY masked by Y > 0 for ReLU layers)
-__global__ void bias_grad_kernel(const float* dY, const float* maskY, size_t npix, int Cout, float* dB) {
-    __shared__ float sh[128];
-    if (threadIdx.x < 128) sh[threadIdx.x] = 0.0f;
-    __syncthreads();
-    const size_t n = npix * Cout;
-    // a bias gradient is a plain sum of a signed map over up to 3.1 M pixels, and it cancels heavily: the thread's running
-    // sum is kept in float64 (a few hundred terms per thread; the kernel is HBM-bound either way)
+// dB[co] = sum over pixels of dY' (dY masked by Y > 0 for ReLU layers), in a fixed order: a thread owns one channel of every
+// (256 / Cout)-th pixel of its block's stripe and sums it in float64 (a bias gradient is a sum of a signed map over up to 3.1 M
+// pixels that cancels heavily), the block's threads of a channel are added in thread order, the blocks in block order.
+constexpr int BG_BLOCKS = 512;
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dY, const float* maskY, size_t npix, int Cout, double* part) {
+    __shared__ double sh[256];
+    const int ppb = 256 / Cout;                        // pixels per block trip
+    const int c = (int)threadIdx.x % Cout, pg = (int)threadIdx.x / Cout;
     double s = 0.0;
-    // each thread keeps one channel: stride is a multiple of Cout
-    const size_t stride = (size_t)gridDim.x * blockDim.x / Cout * Cout;
-    const size_t start = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (start < stride)
-        for (size_t i = start; i < n; i += stride) {
+    if (pg < ppb)
+        for (size_t px = (size_t)blockIdx.x * ppb + pg; px < npix; px += (size_t)gridDim.x * ppb) {
+            const size_t i = px * Cout + c;
             float v = dY[i];
             if (maskY && !(maskY[i] > 0.0f)) v = 0.0f;
             s += (double)v;
         }
-    if (start < stride) atomicAdd(&sh[start % Cout], (float)s);
+    sh[threadIdx.x] = s;
     __syncthreads();
-    if ((int)threadIdx.x < Cout && sh[threadIdx.x] != 0.0f) atomicAdd(&dB[threadIdx.x], sh[threadIdx.x]);
+    if ((int)threadIdx.x < Cout) {
+        double tsum = 0.0;
+        for (int k = 0; k < ppb; ++k) tsum += sh[k * Cout + threadIdx.x];
+        part[(size_t)blockIdx.x * Cout + threadIdx.x] = tsum;
+    }
+}
+__global__ void bias_grad_final_kernel(const double* part, int nblk, int Cout, float* dB) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cout) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * Cout + c];
+    dB[c] = (float)s;
 }
 
 // Sum of squares of one parameter's (scaled) gradient, in a FIXED summation order: per-thread stripes, butterfly inside the
@@ -1065,7 +1190,12 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     // a backward pass starts from zeroed parameter gradients; an evaluation step only resets the metric slots
     if (backward) PSEG_HIP(hipMemsetAsync(t->d_grad, 0, (size_t)t->nflat * 4, st));
     else PSEG_HIP(hipMemsetAsync(acc, 0, (size_t)(t->nflat - t->nparam) * 4, st));
-    ce_metrics_kernel<<<cdiv((int)npx, 256), 256, 0, st>>>(t->d_logits, t->d_mask, (int)npx, C, 1.0f / (float)npx, t->d_dlogits, acc);
+    {
+        const int nblk = cdiv((int)npx, 256), nslot = 2 + 2 * C;
+        PSEG_TRY(ensure_buf((void**)&t->d_mpart, &t->mpart_bytes, (size_t)nblk * nslot * 4));
+        ce_metrics_kernel<<<nblk, 256, 0, st>>>(t->d_logits, t->d_mask, (int)npx, C, 1.0f / (float)npx, t->d_dlogits, t->d_mpart);
+        metrics_final_kernel<<<nslot, 256, 0, st>>>(t->d_mpart, nblk, nslot, acc);
+    }
     if (t->loss_kind != PSEG_LOSS_CE)
         loss_grad_kernel<<<cdiv((int)npx, 256), 256, 0, st>>>(t->loss_kind, t->d_logits, t->d_mask, (int)npx, C, 1.0f / (float)npx,
                                                             acc, t->d_dlogits, acc + 2 + 2 * PSEG_MAXC);
@@ -1135,7 +1265,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.strip_rows = std::max(1, cdiv(Hy * k * k, strips_target));
                 a.dW = gw; a.dB = sidx == 0 ? gb : nullptr;
                 dim3 grid(cdiv(Hy, a.strip_rows), k * k);
-                PSEG_TRY(launch_wgrad(a, grid, st));
+                PSEG_TRY(launch_wgrad(a, grid, st, &t->d_wpart, &t->wpart_bytes));
             }
             // ---- dgrad into the source gradients (skipped for the network input) ----
             // = a stride-1 convolution of the (ReLU-masked, for stride 2 zero-dilated) output gradient with the flipped
@@ -1195,10 +1325,12 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.strip_rows = std::max(1, cdiv(Hx * 4, strips_target));
                 a.dW = gw; a.dB = nullptr;
                 dim3 grid(cdiv(Hx, a.strip_rows), 4);
-                PSEG_TRY(launch_wgrad(a, grid, st));
+                PSEG_TRY(launch_wgrad(a, grid, st, &t->d_wpart, &t->wpart_bytes));
             }
-            if (op.Cout > 128) return fail(PSEG_EUNSUPPORTED, "bias gradient supports at most 128 channels");
-            bias_grad_kernel<<<512, 256, 0, st>>>(dY, op.relu ? Y : nullptr, (size_t)4 * Hx * Wx, op.Cout, gb);
+            if (op.Cout > 256) return fail(PSEG_EUNSUPPORTED, "bias gradient supports at most 256 channels");
+            PSEG_TRY(ensure_buf((void**)&t->d_bpart, &t->bpart_bytes, (size_t)BG_BLOCKS * op.Cout * 8));
+            bias_grad_kernel<<<BG_BLOCKS, 256, 0, st>>>(dY, op.relu ? Y : nullptr, (size_t)4 * Hx * Wx, op.Cout, (double*)t->d_bpart);
+            bias_grad_final_kernel<<<cdiv(op.Cout, 64), 64, 0, st>>>((const double*)t->d_bpart, BG_BLOCKS, op.Cout, gb);
             PSEG_HIP(hipGetLastError());
             for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
                 const int src = sidx == 0 ? op.src0 : op.src1;

@@ -78,13 +78,17 @@ def test_config3_full_size_train_step_matches_torch_autograd(gpu):
         scale = float(np.abs(want).max()) + 1e-12
         # float32 products and partial sums over up to 3.1 M pixels against a float64 referee
         assert float(np.abs(g[k] - want).max()) <= 2e-3 * scale, k
-    # >= 20 further steps (Adam lr 1e-4 is lib/network.py:23's default; 1e-3 here so that 20 steps move the loss):
-    # two engines fed the same pages stay together (the weight-gradient kernels accumulate with float atomics, so the order
-    # of their partial sums -- not the sums' terms -- varies from run to run: ~1e-7 relative per step), the loss goes down
+    # >= 20 further steps (Adam lr 1e-4 is lib/network.py:23's default; 1e-3 here so that 20 steps move the loss): two engines
+    # fed the same pages stay BIT-IDENTICAL -- every reduction of the step (weight / bias gradients: per-strip partial sums
+    # added in strip order; loss and metrics: per-block rows added in a fixed tree; clip norms) has a fixed order since round 3
+    # (rounds 1-2 accumulated with float atomics and drifted up to 5 % in the loss by step 19) -- and the loss goes down
     eng2 = gpu.Engine("fcn_skip", C, mode=gpu.MODE_F32_EXACT)
     eng2.set_weights(Wt)
     eng2.train_init(clipnorm=1.0)
-    eng2.train_forward_backward(img, mask)
+    m2 = eng2.train_forward_backward(img, mask)
+    assert tuple(m2) == (loss, acc, jac, dice)
+    g2 = eng2.gradients()
+    assert all(np.array_equal(g[k], g2[k]) for k in g), [k for k in g if not np.array_equal(g[k], g2[k])]
     pages = [(img, mask)] + [synth.synth_page(i, H, W, C)[::2] for i in (1, 2)]
     losses = [loss]
     eng.train_apply(1e-3)
@@ -93,13 +97,13 @@ def test_config3_full_size_train_step_matches_torch_autograd(gpu):
         im, mk = pages[it % len(pages)]
         l1 = eng.train_forward_backward(im, mk)[0]
         l2 = eng2.train_forward_backward(im, mk)[0]
-        assert abs(l1 - l2) <= 0.15 * abs(l1), (it, l1, l2)          # the tiny differences compound through Adam (lr 1e-3): observed up to 5 % at step 19
+        assert l1 == l2, (it, l1, l2)
         eng.train_apply(1e-3)
         eng2.train_apply(1e-3)
         losses.append(l1)
     assert np.isfinite(losses).all() and np.mean(losses[-3:]) < 0.8 * np.mean(losses[:3]), losses
     w1, w2 = eng.get_weights(), eng2.get_weights()
-    assert all(np.abs(w1[k] - w2[k]).max() <= 2.2e-2 for k in w1)    # at most 22 Adam steps of <= 1e-3 each apart
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1), [k for k in w1 if not np.array_equal(w1[k], w2[k])]
     eng.close()
     eng2.close()
 

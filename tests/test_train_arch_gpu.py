@@ -101,3 +101,31 @@ def test_trainer_api_with_other_architectures(gpu, tmp_path, arch_name):
     assert (tmp_path / "model.h5").exists()
     net = Network("Predict", n_classes=3, model_constructor=arch, model=str(tmp_path / "model"))
     assert net.predict_single_data(settings.validation_data.data[0])[2].shape == (96, 96)
+
+
+@pytest.mark.parametrize("arch,C,shape", [("fcn_skip", 3, (96, 80)), ("fcn", 6, (64, 96)), ("unet", 3, (64, 64)), ("res_unet", 3, (64, 96))])
+def test_train_steps_are_reproducible_bit_for_bit(gpu, oracle_mod, arch, C, shape):
+    """Two engines fed the same samples hold bit-identical gradients, losses and weights after several steps, for every
+    graph: every reduction of the step runs in a fixed order (no float atomics); PSEG_WGRAD_ATOMIC=1 is the old form."""
+    Wt = oracle_mod.init_weights(arch, C, seed=2, gain=1.0, bias_scale=0.02)
+    samples = [_sample(s, shape[0], shape[1], C) for s in (0, 1)]
+    engines = []
+    for _ in range(2):
+        e = gpu.Engine(arch, C, mode=gpu.MODE_F32_EXACT)
+        e.set_weights(Wt)
+        e.train_init(clipnorm=1.0)
+        if arch == "unet":
+            e.train_set_dropout_seed(5)
+        engines.append(e)
+    for step in range(4):
+        img, mask = samples[step % 2]
+        m = [tuple(e.train_forward_backward(img, mask)) for e in engines]
+        assert m[0] == m[1], (step, m)
+        g0, g1 = engines[0].gradients(), engines[1].gradients()
+        assert all(np.array_equal(g0[k], g1[k]) for k in g0), (step, [k for k in g0 if not np.array_equal(g0[k], g1[k])])
+        for e in engines:
+            e.train_apply(1e-3)
+    w0, w1 = engines[0].get_weights(), engines[1].get_weights()
+    assert all(np.array_equal(w0[k], w1[k]) for k in w0)
+    for e in engines:
+        e.close()

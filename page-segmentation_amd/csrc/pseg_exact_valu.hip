@@ -59,10 +59,12 @@ __global__ __launch_bounds__(256) void conv_first_valu_kernel(ConvArgs a) {
     const size_t opix = (size_t)y * (a.dst_pitch ? a.dst_pitch : a.Wout) + x;
     float* o = a.dst + opix * a.Cout + co0;
     float v[CT];
+    const float* ad = a.add ? a.add + opix * a.Cout + co0 : nullptr;     // residual addend / data-gradient accumulation (may alias dst)
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
         const int co = co0 + j;
         float t = a.bias ? acc[j] + a.bias[co < a.Cout ? co : 0] : acc[j];
+        if (ad && co < a.Cout) t = t + ad[j];
         if (a.relu) t = t > 0.0f ? t : 0.0f;
         v[j] = t;
     }
@@ -238,16 +240,17 @@ static int set_lds_attr(K kernel) {
 // 1 = launched, 0 = not a layer for this kernel
 int launch_conv_first_valu(const ConvArgs& a, hipStream_t st) {
     if (PSEG_KNOB("PSEG_EXACT_NO_VALU")) return 0;
-    if (a.C1 || a.C0 > 3 || a.KH != a.KW || a.stride != 1 || a.up0 || a.in_relu || a.mask || a.add || a.deconv4 || a.pool_dst ||
+    if (a.C1 || a.C0 > 3 || a.KH != a.KW || a.stride != 1 || a.up0 || a.in_relu || a.mask || a.deconv4 || a.pool_dst ||
         a.out_sy || a.out_sx || a.Cout < 8 || a.Cout > 256)
         return 0;
     const int K = a.KH;
     const size_t lds = (size_t)(FV_TH + K - 1) * (FV_TW + K - 1) * a.C0 * 4;
-    int CT = (a.Cout == 20 || a.Cout == 16 || a.Cout == 32) ? a.Cout : ((a.Cout & 31) == 0 ? 32 : ((a.Cout % 20) == 0 ? 20 : 16));
+    int CT = (a.Cout == 20 || a.Cout == 16 || a.Cout == 32) ? a.Cout : ((a.Cout & 31) == 0 ? 32 : ((a.Cout % 20) == 0 ? 20 : ((a.Cout % 30) == 0 ? 30 : 16)));
     dim3 grid(cdiv(a.Wout, FV_TW) * cdiv(a.Hout, FV_TH), cdiv(a.Cout, CT));
     switch (CT) {
         case 16: conv_first_valu_kernel<16><<<grid, 256, lds, st>>>(a); break;
         case 20: conv_first_valu_kernel<20><<<grid, 256, lds, st>>>(a); break;
+        case 30: conv_first_valu_kernel<30><<<grid, 256, lds, st>>>(a); break;
         default: conv_first_valu_kernel<32><<<grid, 256, lds, st>>>(a); break;
     }
     PSEG_HIP(hipGetLastError());

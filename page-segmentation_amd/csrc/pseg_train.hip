@@ -332,12 +332,23 @@ __global__ void wgrad_reduce_kernel(const float* part, size_t pstride, int nstri
         const int ci = (int)(tc % XC), tap = (int)(tc / XC);
         dW[((size_t)tap * Cin + ci0 + ci) * Cout + co] = s;
     }
-    if (partB && blockIdx.x == 0)
-        for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
-            double s = 0.0;
-            for (int k = 0; k < 4 * nstrips; ++k) s += (double)partB[(size_t)k * Cout + co];
-            dB[co] = (float)s;
-        }
+    (void)partB; (void)dB;
+}
+// out[c] = sum of rows[0 .. nrows)[c] in float64 and a fixed order: one workgroup per channel, the rows strided over its
+// threads in order, then a fixed tree (a single thread walking 1 400 rows took 100 us of pure load latency)
+template <typename T>
+__global__ __launch_bounds__(256) void column_sum_kernel(const T* rows, int nrows, int C, float* out) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nrows; k += 256) s += (double)rows[(size_t)k * C + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (float)sh[0];
 }
 
 constexpr int WG_PC = 32;  // pixels per LDS chunk
@@ -924,6 +935,7 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
         wgrad_reduce_groups_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)cdiv(nstrips, WGR_GROUP)), 256, 0, st>>>(a.part, a.pstride, nstrips);
         wgrad_reduce_kernel<<<(int)std::min<size_t>((n + 255) / 256, 2048), 256, 0, st>>>(a.part, a.pstride, nstrips, taps, a.XC, a.Cout, a.Cin, a.ci0, a.dW,
                                                                                           a.partB, a.dB);
+        if (a.partB) column_sum_kernel<float><<<a.Cout, 256, 0, st>>>(a.partB, 4 * nstrips, a.Cout, a.dB);
         PSEG_HIP(hipGetLastError());
     }
     return PSEG_OK;
@@ -992,14 +1004,6 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dY, const f
         part[(size_t)blockIdx.x * Cout + threadIdx.x] = tsum;
     }
 }
-__global__ void bias_grad_final_kernel(const double* part, int nblk, int Cout, float* dB) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cout) return;
-    double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * Cout + c];
-    dB[c] = (float)s;
-}
-
 // Sum of squares of one parameter's (scaled) gradient, in a FIXED summation order: per-thread stripes, butterfly inside the
 // wave, the four waves in order through LDS, then the blocks' partial sums in order (sumsq_final_kernel).  Data-parallel
 // replicas clip by this norm: with float atomics its last bit depended on the arrival order and two ranks that hold the
@@ -1330,7 +1334,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
             if (op.Cout > 256) return fail(PSEG_EUNSUPPORTED, "bias gradient supports at most 256 channels");
             PSEG_TRY(ensure_buf((void**)&t->d_bpart, &t->bpart_bytes, (size_t)BG_BLOCKS * op.Cout * 8));
             bias_grad_kernel<<<BG_BLOCKS, 256, 0, st>>>(dY, op.relu ? Y : nullptr, (size_t)4 * Hx * Wx, op.Cout, (double*)t->d_bpart);
-            bias_grad_final_kernel<<<cdiv(op.Cout, 64), 64, 0, st>>>((const double*)t->d_bpart, BG_BLOCKS, op.Cout, gb);
+            column_sum_kernel<double><<<op.Cout, 256, 0, st>>>((const double*)t->d_bpart, BG_BLOCKS, op.Cout, gb);
             PSEG_HIP(hipGetLastError());
             for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
                 const int src = sidx == 0 ? op.src0 : op.src1;

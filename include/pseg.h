@@ -223,6 +223,19 @@ int pseg_train_forward_backward_f32(pseg_engine* e, const float* img, const uint
 int pseg_train_grad_buffer(pseg_engine* e, float** d_grad, int64_t* count);
 int pseg_train_metrics(pseg_engine* e, float metrics[4]);
 
+/* Data-parallel training (the build's only collective; the reference trains in one process,
+ * lib/network.py:235-241): one process per GPU, every rank runs pseg_train_forward_backward on its own page, then ONE
+ * all-reduce(sum) of the flat gradient buffer over RCCL / xGMI, then pseg_train_apply(lr, 1/world) on every rank (clip
+ * after averaging, identical updates).  RCCL is bound at run time (dlopen): libpseg.so does not link it.
+ *   pseg_allreduce_unique_id: rank 0 creates the 128-byte communicator id; the caller hands it to the other ranks.
+ *   pseg_allreduce_init:      ncclCommInitRank on the engine's device (collective: every rank calls it).
+ *   pseg_train_allreduce:     the all-reduce, in place, enqueued on the engine's stream (no synchronisation).
+ *   pseg_allreduce_destroy:   releases the communicator (pseg_destroy does it too). */
+int pseg_allreduce_unique_id(uint8_t id[128]);
+int pseg_allreduce_init(pseg_engine* e, int rank, int world, const uint8_t id[128]);
+int pseg_train_allreduce(pseg_engine* e);
+int pseg_allreduce_destroy(pseg_engine* e);
+
 /* Clip + Adam update of every parameter with the (scaled) gradients; t += 1. */
 int pseg_train_apply(pseg_engine* e, float lr, float grad_scale);
 

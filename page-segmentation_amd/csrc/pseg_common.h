@@ -193,6 +193,7 @@ struct Engine {
     void* exact = nullptr;   // ExactState (pseg_exactlabels.hip): float32 companion engine, margin / flag buffers of the label-exact mode
     void* batch = nullptr;   // BatchState (pseg_predict_batch): copy streams, events, two staging slots
     void* chain = nullptr;   // ChainState (pseg_predict_chain): device buffers of the Predictor chain
+    void* dist = nullptr;    // DistState (pseg_allreduce_init): RCCL communicator of the data-parallel train step
     int relaxed_f32 = 0;     // != 0 during a train / eval step: wide float32 layers may run channel-blocked on the matrix cores
     uint32_t drop_key = 0;   // != 0 while a TRAINING forward runs: Dropout layers are live (key = seed / step mix)
     const float* cur_img_f32 = nullptr;   // float32 exact mode: float page (0..255 scale) instead of the uint8 one (augmented training samples)
@@ -266,7 +267,8 @@ bool mfma_tail_emits_margin(const Engine& e);   // the bf16 graph's tail kernel 
 int create_engine(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
                   std::shared_ptr<const KnobSnap> inherit, struct ::pseg_engine** out);   // pseg_create_ex; `inherit` = a parent engine's knob snapshot
 void exact_free(Engine& e);
-void chain_free(Engine& e);                     // Predictor chain buffers (pseg_chain.hip)                     // label-exact mode state (pseg_exactlabels.hip)
+void chain_free(Engine& e);
+void dist_free(Engine& e);                      // RCCL communicator (pseg_dist.hip)                     // Predictor chain buffers (pseg_chain.hip)                     // label-exact mode state (pseg_exactlabels.hip)
 int set_canvas(Engine& e, int H, int W, hipStream_t st);
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs, int64_t* d_labels,
               uint8_t* d_labels_u8, hipStream_t st);

@@ -1062,6 +1062,7 @@ int pseg_destroy(pseg_engine* h) {
     (void)hipSetDevice(e.device);
     if (e.stream) (void)hipStreamSynchronize(e.stream);
     train_free(e);
+    dist_free(e);
     exact_free(e);
     chain_free(e);
     batch_free(e);

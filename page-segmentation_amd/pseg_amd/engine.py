@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = (
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
     "pseg_train_init", "pseg_train_set_optimizer", "pseg_train_set_loss", "pseg_train_set_dropout_seed", "pseg_train_forward_backward", "pseg_train_forward_backward_f32", "pseg_train_grad_buffer", "pseg_train_metrics",
     "pseg_train_apply", "pseg_train_get_gradient", "pseg_eval_step",
+    "pseg_allreduce_unique_id", "pseg_allreduce_init", "pseg_train_allreduce", "pseg_allreduce_destroy",
     "pseg_cc_vote", "pseg_cc_vote_device", "pseg_cc_vote_device_u8", "pseg_release_workspace", "pseg_bbox_fill",
     "pseg_masks", "pseg_masks_device", "pseg_masks_device_u8", "pseg_bbox_fill_device_u8",
     "pseg_otsu_char_height",
@@ -99,6 +100,10 @@ def lib():
     L.pseg_train_apply.argtypes = [vp, f, f]
     L.pseg_train_get_gradient.argtypes = [vp, c.c_char_p, vp, i64]
     L.pseg_eval_step.argtypes = [vp, vp, vp, i, i, c.POINTER(f)]
+    L.pseg_allreduce_unique_id.argtypes = [vp]
+    L.pseg_allreduce_init.argtypes = [vp, i, i, vp]
+    L.pseg_train_allreduce.argtypes = [vp]
+    L.pseg_allreduce_destroy.argtypes = [vp]
     L.pseg_cc_vote.argtypes = [i, vp, vp, i, i, i]
     d = c.c_double
     L.pseg_rescale_shape.argtypes = [i, i, d, c.POINTER(i), c.POINTER(i)]
@@ -415,6 +420,23 @@ class Engine:
     def train_init(self, beta1=0.9, beta2=0.999, eps=1e-7, clipnorm=1.0, clipvalue=0.0):
         """Keras Adam defaults; clipnorm is per tensor (lib/network.py:97), <= 0 disables."""
         _check(lib().pseg_train_init(self._h, beta1, beta2, eps, clipnorm, clipvalue))
+
+    # -- data-parallel training through the C ABI (RCCL bound at run time; pseg_amd.parallel offers torch.distributed instead)
+    @staticmethod
+    def allreduce_unique_id():
+        buf = (ctypes.c_uint8 * 128)()
+        _check(lib().pseg_allreduce_unique_id(buf))
+        return bytes(buf)
+
+    def allreduce_init(self, rank, world, unique_id):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().pseg_allreduce_init(self._h, int(rank), int(world), buf))
+
+    def train_allreduce(self):
+        _check(lib().pseg_train_allreduce(self._h))
+
+    def allreduce_destroy(self):
+        _check(lib().pseg_allreduce_destroy(self._h))
 
     OPTIMIZERS = {"adam": 0, "adamax": 1, "adadelta": 2, "adagrad": 3, "rmsprop": 4, "sgd": 5, "nadam": 6}
 

@@ -236,3 +236,37 @@ def test_alternative_losses(gpu, oracle_mod, name):
     with pytest.raises(Exception):
         eng.train_set_loss("mse")
     eng.close()
+
+
+def test_c_abi_allreduce_single_rank(gpu, oracle_mod):
+    """pseg_allreduce_init / pseg_train_allreduce (RCCL bound at run time) on a one-rank communicator -- what a one-GPU box
+    can run: the collective initialises on the hardware, the all-reduce is enqueued on the engine's stream between the
+    backward kernels and the update, and a sum over one rank leaves the gradients -- and the step that follows -- bit-identical
+    to the plain step."""
+    from pseg_amd import synth
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=3, gain=1.0, bias_scale=0.02)
+    img, _, mask = synth.synth_page(1, 96, 128, 3)
+    engines = []
+    for dp in (False, True):
+        e = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_F32_EXACT)
+        e.set_weights(Wt)
+        e.train_init(clipnorm=1.0)
+        if dp:
+            e.allreduce_init(0, 1, gpu.Engine.allreduce_unique_id())
+        engines.append(e)
+    for step in range(3):
+        for dp, e in zip((False, True), engines):
+            e.train_forward_backward(img, mask)
+            if dp:
+                e.train_allreduce()
+        g0, g1 = engines[0].gradients(), engines[1].gradients()
+        assert all(np.array_equal(g0[k], g1[k]) for k in g0)
+        for e in engines:
+            e.train_apply(1e-3, 1.0)
+    w0, w1 = engines[0].get_weights(), engines[1].get_weights()
+    assert all(np.array_equal(w0[k], w1[k]) for k in w0)
+    engines[1].allreduce_destroy()
+    with pytest.raises(gpu.PsegError):
+        engines[1].train_allreduce()
+    for e in engines:
+        e.close()

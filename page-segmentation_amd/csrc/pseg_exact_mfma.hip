@@ -330,7 +330,7 @@ constexpr int XCP = XCB + 2;     // LDS pixel pitch in floats
 // registers, four waves per SIMD).  One (tap, four channels) k-step = MT ds_read_b32 + NT global loads for MT x NT MFMAs of
 // 32 cycles each; the k-steps of a slab form ONE software-pipelined stream across taps (the fragments of step q + 1 are
 // requested before the MFMAs of step q; a per-tap pipeline would expose a load latency every four k-steps).
-template <int MT, int NT>
+template <int MT, int NT, int TAILK>
 __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int TWH, unsigned inv_twh) {
     extern __shared__ __attribute__((aligned(16))) float xt[];   // [THH][TWH][XCP]
     constexpr int RW = MT / 2;            // output rows per wave
@@ -380,6 +380,37 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
         constexpr int SU = 8;
         if (PSEG_DIAG && (a.dbg & 1)) {                 // timing ablation (diagnostic build): no staging loads
             for (int i = tid; i < npx * XCP; i += 256) xt[i] = 0.0f;
+        } else if (pairs && !a.mask) {
+            // the common form (forward layers, data gradients without a ReLU mask): no mask values to keep in flight
+            const int sp = lane >> 3, c2 = (lane & 7) * 2;
+            const int ch = cb + c2;
+            const bool chok = ch < Cin;
+            const bool second = ch >= a.C0;
+            const float* const sb = second ? a.src1 : a.src0;
+            const int C = second ? a.C1 : a.C0, chl = second ? ch - a.C0 : ch, up = second ? a.up1 : a.up0;
+            const int Ws = a.Win >> up;
+            const int ngrp = (npx + 7) >> 3;
+            for (int g0 = wave; g0 < ngrp; g0 += 4 * SU) {
+                float2 v[SU];
+                int dsto[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int grp = g0 + 4 * u, p = grp * 8 + sp;
+                    const bool valid = grp < ngrp && p < npx;
+                    const int r = (int)(((unsigned)p * inv_twh) >> 20), c = p - r * TWH;
+                    const int iy = iy0 + r, ix = ix0 + c;
+                    dsto[u] = valid ? p * XCP + c2 : -1;
+                    v[u] = make_float2(0.0f, 0.0f);
+                    if (valid && chok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
+                        v[u] = *(const float2*)(sb + ((size_t)(iy >> up) * Ws + (ix >> up)) * C + chl);
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    float2 x = v[u];
+                    if (a.in_relu) { x.x = x.x > 0.0f ? x.x : 0.0f; x.y = x.y > 0.0f ? x.y : 0.0f; }
+                    if (dsto[u] >= 0) *(float2*)(xt + dsto[u]) = x;
+                }
+            }
         } else if (pairs) {
             const int sp = lane >> 3, c2 = (lane & 7) * 2;
             const int ch = cb + c2;
@@ -390,11 +421,12 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
             const int Ws = a.Win >> up;
             const float* const mb = second ? nullptr : a.mask;
             const int ngrp = (npx + 7) >> 3;
-            for (int g0 = wave; g0 < ngrp; g0 += 4 * SU) {
-                float2 v[SU], mv[SU];
-                int dsto[SU];
+            constexpr int SM = 4;
+            for (int g0 = wave; g0 < ngrp; g0 += 4 * SM) {
+                float2 v[SM], mv[SM];
+                int dsto[SM];
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
+                for (int u = 0; u < SM; ++u) {
                     const int grp = g0 + 4 * u, p = grp * 8 + sp;
                     const bool valid = grp < ngrp && p < npx;
                     const int r = (int)(((unsigned)p * inv_twh) >> 20), c = p - r * TWH;
@@ -409,7 +441,7 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
+                for (int u = 0; u < SM; ++u) {
                     float2 x = v[u];
                     if (a.in_relu) { x.x = x.x > 0.0f ? x.x : 0.0f; x.y = x.y > 0.0f ? x.y : 0.0f; }
                     x.x = mv[u].x > 0.0f ? x.x : 0.0f;
@@ -531,11 +563,15 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
 #pragma unroll
             for (int s4 = 0; s4 < NKS; ++s4) mma(s4);
         };
-        switch (nks) {
-            case 4: slab(std::integral_constant<int, 4>{}); break;
-            case 3: slab(std::integral_constant<int, 3>{}); break;
-            case 2: slab(std::integral_constant<int, 2>{}); break;
-            default: slab(std::integral_constant<int, 1>{}); break;
+        // TAILK (a template constant, picked by the host from the layer's channel count): k-steps per tap of the last slab
+        // when that slab is shorter than 16 channels, 0 when every slab is full.  One instance therefore holds at most two
+        // forms of the tap loop -- with all four the accumulators were allocated more than twice over (80 AGPRs for 32
+        // accumulator registers at NT = 2, 156 for 64 at NT = 4: two waves per SIMD instead of three or four).
+        if constexpr (TAILK == 0) {
+            slab(std::integral_constant<int, 4>{});
+        } else {
+            if (nks == 4) slab(std::integral_constant<int, 4>{});
+            else slab(std::integral_constant<int, TAILK>{});
         }
     }   // slabs
 
@@ -640,16 +676,16 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
     }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int TAILK>
 static int launch_xb(const ConvArgs& a, int THH, int TWH, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     PSEG_HIP(hipGetDevice(&dev));
     if (!attr_set[dev & 63]) {
-        PSEG_HIP(hipFuncSetAttribute((const void*)conv_xb_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PSEG_HIP(hipFuncSetAttribute((const void*)conv_xb_kernel<MT, NT, TAILK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev & 63] = true;
     }
-    conv_xb_kernel<MT, NT><<<grid, 256, lds, st>>>(a, THH, TWH, (1u << 20) / (unsigned)TWH + 1u);
+    conv_xb_kernel<MT, NT, TAILK><<<grid, 256, lds, st>>>(a, THH, TWH, (1u << 20) / (unsigned)TWH + 1u);
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
 }
@@ -719,9 +755,16 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     if (const char* fv = PSEG_KNOB("PSEG_EXACT_NT")) { NT = std::max(1, std::min(4, atoi(fv))); nblk = cdiv(ntall, NT); }
     const size_t lds = lds_of(MT);
     dim3 grid(tiles, nblk);
+    const int tail_ch = Cin % XCB;                              // channels of the last slab (0: a full one)
+    const int tailk = (tail_ch == 0 || tail_ch > 12) ? 0 : (tail_ch + 3) / 4;
 #define PSEG_XB(MT_, NT_)                                                                        \
     if (MT == MT_ && NT == NT_) {                                                                \
-        PSEG_TRY((launch_xb<MT_, NT_>(a, THH, TWH, grid, lds, st)));                             \
+        switch (tailk) {                                                                         \
+            case 0: PSEG_TRY((launch_xb<MT_, NT_, 0>(a, THH, TWH, grid, lds, st))); break;       \
+            case 1: PSEG_TRY((launch_xb<MT_, NT_, 1>(a, THH, TWH, grid, lds, st))); break;       \
+            case 2: PSEG_TRY((launch_xb<MT_, NT_, 2>(a, THH, TWH, grid, lds, st))); break;       \
+            default: PSEG_TRY((launch_xb<MT_, NT_, 3>(a, THH, TWH, grid, lds, st))); break;      \
+        }                                                                                        \
         return pooled ? 2 : 1;                                                                   \
     }
     PSEG_XB(4, 1) PSEG_XB(4, 2) PSEG_XB(4, 3) PSEG_XB(4, 4)

@@ -371,7 +371,12 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
     }
     const bool pairs = ((a.C0 | a.C1) & 1) == 0;     // even channel counts: a lane stages two channels with 8-byte accesses
 
-    for (int cb = 0; cb < Cin; cb += XCB) {
+    // One slab = stage 16 channels of the halo tile, run every tap over them.  `nks_tag` carries the k-steps per tap as a
+    // compile-time constant.  The full slabs run in the loop below (four k-steps per tap); a shorter last slab (TAILK, picked
+    // by the host from the channel count) follows the loop as straight-line code -- with both forms inside one loop the
+    // accumulators were allocated more than twice over (80 AGPRs for 32 accumulator registers at NT = 2, 156 for 64 at
+    // NT = 4: two waves per SIMD instead of three or four).
+    auto process_slab = [&](const int cb, auto nks_tag) {
         const int cn = min(XCB, Cin - cb);
         if (cb) __syncthreads();                     // every wave is done reading the previous slab
         // ---- stage the slab: channels cb .. cb+15 of the halo tile (zeros outside the image and past the layer's channels).
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
         // (The first version computed a 64-bit address and an exec-masked select per weight load and a shift-add per LDS
         // read: ~22 vector ALU instructions per 8 MFMAs.  Vector ALU and matrix instructions share a SIMD's issue port:
         // with the fragment loads switched off that build ran 1131 instead of 1430 us on conv2 -- tools/ab_f32.sh.)
-        const int nks = (cn + 3) >> 2;
+        (void)cn;
         const int KHW = a.deconv4 ? 1 : a.KH * a.KW;
         const int KWe = a.deconv4 ? 1 : a.KW;
         int kx_ = 0, toff = 0;                                 // wave-uniform walk state: LDS float offset of the tap ...
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
         // the per-k-step branches cut the body into basic blocks and the compiler issued each tap's loads right in front
         // of its own MFMAs).  ONE register set, one tap of lead: k-step s of tap T + 1 is requested into the registers of
         // k-step s of tap T as soon as that step's MFMAs have been issued.
-        auto slab = [&](auto nks_c) {
+        auto run_ksteps = [&](auto nks_c) {
             constexpr int NKS = decltype(nks_c)::value;
             const float* xp[MT];
             auto point = [&]() {                                // fragment pointers / weight offset of the tap the walk is at
@@ -563,17 +568,12 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
 #pragma unroll
             for (int s4 = 0; s4 < NKS; ++s4) mma(s4);
         };
-        // TAILK (a template constant, picked by the host from the layer's channel count): k-steps per tap of the last slab
-        // when that slab is shorter than 16 channels, 0 when every slab is full.  One instance therefore holds at most two
-        // forms of the tap loop -- with all four the accumulators were allocated more than twice over (80 AGPRs for 32
-        // accumulator registers at NT = 2, 156 for 64 at NT = 4: two waves per SIMD instead of three or four).
-        if constexpr (TAILK == 0) {
-            slab(std::integral_constant<int, 4>{});
-        } else {
-            if (nks == 4) slab(std::integral_constant<int, 4>{});
-            else slab(std::integral_constant<int, TAILK>{});
-        }
-    }   // slabs
+        run_ksteps(nks_tag);
+
+    };
+    const int nfull = (TAILK == 0) ? (Cin + XCB - 1) / XCB : Cin / XCB;     // (TAILK == 0: a last slab of 13..15 channels also takes four k-steps)
+    for (int sb = 0; sb < nfull; ++sb) process_slab(sb * XCB, std::integral_constant<int, 4>{});
+    if constexpr (TAILK != 0) process_slab(nfull * XCB, std::integral_constant<int, TAILK>{});
 
     // ---- epilogue: acc + bias (+ add), ReLU; lane owns n = 4g..4g+3 of pixel p16 in every tile.  The lane's four values are
     // consecutive output channels of one pixel (of one sub-pixel, for the transposed GEMM: Cout % 4 == 0 keeps a quad inside

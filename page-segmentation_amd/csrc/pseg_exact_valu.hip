@@ -84,7 +84,7 @@ constexpr int DV_PX = 64;     // input pixels per workgroup: four waves = the fo
 template <int CT, int NCT>      // NCT: 0 = plain transposed conv; else logits classes rounded up to 3 / 4 / 6 / 8
 __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
     constexpr bool TAIL = NCT > 0;
-    extern __shared__ float xs[];          // [DV_PX][Cin + 1] (+ [4 * DV_PX][Cs + 1] skip pixels for the tail)
+    extern __shared__ float xs[];          // [DV_PX][Cin + 1]; the tail reuses it as [4 * DV_PX][Cs + 1] skip pixels
     const int Cin = a.C0 + a.C1, P = Cin + 1;
     // a workgroup takes (up to) DV_PX consecutive pixels of ONE input row: its outputs are two runs of 2 * np pixels
     const int segs = (a.Win + DV_PX - 1) / DV_PX;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
             }
         }
     }
-    float* const sks = xs + DV_PX * P;       // tail: the skip tensor's pixels of this workgroup, [a][2 * lane + b][Cs + 1]
+    float* const sks = xs;                   // tail: the skip tensor's pixels of this workgroup, [a][2 * lane + b][Cs + 1] -- in the x tile's place once the transposed conv is done with it (50 -> 32 KB of LDS: five workgroups per CU instead of three)
     // Tail: the logits layer's second source for the 4 * np output pixels is two contiguous runs (output rows 2i, 2i + 1) of
     // 2 * np pixels x Cs floats.  They are REQUESTED here, coalesced, into registers and land in LDS only after the transposed
     // conv below has been computed: their latency hides under its ~700 packed FMAs (read per thread straight from memory, a
@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
         // ncls .. NCT-1 ride along on the neighbouring weights (finite; the weight buffer carries zero slack behind its
         // end) and are never looked at.
         {
+            __syncthreads();                             // every thread has read its x pixel: the tile's LDS is free
             const int PS = a.Cs + 1;
             const int n = 2 * np * a.Cs;
             const unsigned long long inv = a.Cs > 0 ? (1ull << 32) / (unsigned)a.Cs + 1ull : 0ull;
@@ -262,7 +263,7 @@ int launch_deconv2_valu(const TailArgs& a, bool tail, hipStream_t st) {
     if (PSEG_KNOB("PSEG_EXACT_NO_VALU")) return 0;
     const int Cin = a.C0 + a.C1;
     if (Cin < 1 || Cin > 512 || a.Cout < 4 || (size_t)a.Hin * a.Win > 0x3fffffff) return 0;
-    const size_t lds = (size_t)DV_PX * (Cin + 1) * 4 + (tail ? (size_t)4 * DV_PX * (a.Cs + 1) * 4 : 0);
+    const size_t lds = std::max((size_t)DV_PX * (Cin + 1) * 4, tail ? (size_t)4 * DV_PX * (a.Cs + 1) * 4 : (size_t)0);
     static bool attr[64] = {false};
     int dev = 0;
     PSEG_HIP(hipGetDevice(&dev));

@@ -752,6 +752,10 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     int nblk = cdiv(ntall, 4), NT = cdiv(ntall, nblk);
     while (NT > 1 && tiles * nblk < 1024) { --NT; nblk = cdiv(ntall, NT); }
     NT = cdiv(ntall, nblk);                    // even split: 4 tiles over 2 blocks are 2 + 2, not 3 + 1 (idle MFMAs on the empty tiles)
+    // quarter-resolution layers of a 2048x1536 page (768 tiles): the chip holds 768 three- or four-tile workgroups at once (three
+    // waves per SIMD), so one cout block beats two -- 3 tiles cannot split evenly (2 + 1 with a dead tile: deconv3 612 -> 461 us),
+    // 4 tiles as 2 + 2 stage every slab twice (conv5 / conv6 226 -> 218, 326 -> 308 us).  PSEG_EXACT_SPLIT=1: the split forms.
+    if ((ntall == 3 || ntall == 4) && nblk == 2 && tiles >= 512 && !PSEG_KNOB("PSEG_EXACT_SPLIT")) { NT = ntall; nblk = 1; }
     if (const char* fv = PSEG_KNOB("PSEG_EXACT_NT")) { NT = std::max(1, std::min(4, atoi(fv))); nblk = cdiv(ntall, NT); }
     const size_t lds = lds_of(MT);
     dim3 grid(tiles, nblk);

@@ -29,8 +29,8 @@ extern "C" {
 /* lib/architecture.py:6-11 -- the in-scope Architecture members. */
 enum { PSEG_ARCH_FCN_SKIP = 0, PSEG_ARCH_FCN = 1, PSEG_ARCH_UNET = 2, PSEG_ARCH_RES_UNET = 3 };
 
-/* Arithmetic mode.  F32_EXACT: float32 tensors, sequential-fmaf accumulation in (ky,kx,ci)
- * order -- bit-identical to oracle/pseg_oracle.c.  BF16: bf16 activations + bf16 kernels,
+/* Arithmetic mode.  F32_EXACT: float32 tensors, one sequential fmaf chain per output -- slabs of 16 input
+ * channels, (ky,kx,ci) inside a slab -- bit-identical to oracle/pseg_oracle.c.  BF16: bf16 activations + bf16 kernels,
  * float32 MFMA accumulation (throughput mode, BASELINE.json configs[1]). */
 enum { PSEG_MODE_F32_EXACT = 0, PSEG_MODE_BF16 = 1 };
 

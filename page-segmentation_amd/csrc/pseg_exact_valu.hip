@@ -60,17 +60,38 @@ __global__ __launch_bounds__(256) void conv_first_valu_kernel(ConvArgs a) {
     float* o = a.dst + opix * a.Cout + co0;
     float v[CT];
     const float* ad = a.add ? a.add + opix * a.Cout + co0 : nullptr;     // residual addend / data-gradient accumulation (may alias dst)
+    const bool whole = co0 + CT <= a.Cout;
+    const bool vec4 = (a.Cout & 3) == 0 && (CT & 3) == 0 && whole, vec2 = (a.Cout & 1) == 0 && (CT & 1) == 0 && whole;
+    float av[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) av[j] = 0.0f;
+    if (ad) {                                                            // (a pixel's channels are one contiguous run: wide loads)
+        if (vec4) {
+#pragma unroll
+            for (int j = 0; j < CT; j += 4) { const float4 q = *(const float4*)(ad + j); av[j] = q.x; av[j + 1] = q.y; av[j + 2] = q.z; av[j + 3] = q.w; }
+        } else if (vec2) {
+#pragma unroll
+            for (int j = 0; j < CT; j += 2) { const float2 q = *(const float2*)(ad + j); av[j] = q.x; av[j + 1] = q.y; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+                if (co0 + j < a.Cout) av[j] = ad[j];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
         const int co = co0 + j;
         float t = a.bias ? acc[j] + a.bias[co < a.Cout ? co : 0] : acc[j];
-        if (ad && co < a.Cout) t = t + ad[j];
+        if (ad) t = t + av[j];
         if (a.relu) t = t > 0.0f ? t : 0.0f;
         v[j] = t;
     }
-    if ((a.Cout & 3) == 0 && (CT & 3) == 0 && co0 + CT <= a.Cout) {
+    if (vec4) {
 #pragma unroll
         for (int j = 0; j < CT; j += 4) *(float4*)(o + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+    } else if (vec2) {
+#pragma unroll
+        for (int j = 0; j < CT; j += 2) *(float2*)(o + j) = make_float2(v[j], v[j + 1]);
     } else {
 #pragma unroll
         for (int j = 0; j < CT; ++j)

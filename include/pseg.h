@@ -135,8 +135,9 @@ int pseg_predict_chain(pseg_engine* e, const uint8_t* img, int H, int W, int Ho,
  * d_labels (int64) and d_margin are optional outputs.  pseg_label_exact_stats: {tau, calibration logit error,
  * flagged pixel fraction, refereed block fraction, refereed area (with halos) / page area, tau escalations,
  * whole-page fallback (0/1), labels changed by the referee} of the last call; pseg_label_exact_stats_ex appends
- * {running margin error, rectangles refereed, cost-model price of the crops / price of the whole page, block edge}
- * (`cap` doubles are written). */
+ * {running margin error, rectangles refereed, cost-model price of the crops / price of the whole page, block edge,
+ * 1 when the page went to the float32 engine directly -- after three whole-page referees in a row the next eight pages
+ * skip the bf16 pass --} (`cap` doubles are written). */
 int pseg_predict_margin_device(pseg_engine* e, const uint8_t* d_img, int H, int W, uint8_t* d_labels_u8,
                                float* d_margin, void* stream);
 int pseg_predict_exact_labels_device(pseg_engine* e, const uint8_t* d_img, int H, int W, uint8_t* d_labels_u8,

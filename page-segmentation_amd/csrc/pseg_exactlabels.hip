@@ -42,6 +42,7 @@ struct ExactState {
     float margin_err = 0.0f;             // running max change of the top-2 margin between the bf16 pass and the referee (all refereed pixels since the last weight change)
     int calib_Hp = 0, calib_Wp = 0;      // canvas the calibration crops were taken from
     int pages_since_calib = 0;
+    int fallback_streak = 0, skip_left = 0;   // pages in a row that went through the float32 engine whole / pages left to send there directly
     float* d_margin = nullptr; size_t margin_bytes = 0;
     uint8_t* d_flags = nullptr; size_t flags_bytes = 0;
     float* d_blockmin = nullptr; size_t blockmin_bytes = 0;
@@ -55,7 +56,7 @@ struct ExactState {
     unsigned* d_counters = nullptr;      // [0] unflagged-but-different pixels, [1] flagged pixels, [2] max |dlogit| / largest flipped margin bits, [3] labels changed, [4] max margin change bits
     std::vector<uint8_t> h_flags, h_done;
     // statistics of the last call (pseg_label_exact_stats)
-    double st_flag_px = 0, st_blocks = 0, st_area = 0, st_escal = 0, st_full = 0, st_rects = 0, st_changed = 0, st_cost = 0;
+    double st_flag_px = 0, st_blocks = 0, st_area = 0, st_escal = 0, st_full = 0, st_rects = 0, st_changed = 0, st_cost = 0, st_direct = 0;
 };
 
 static int xensure(void** p, size_t* cap, size_t bytes) {
@@ -157,6 +158,7 @@ static int sync_weights(Engine& e, ExactState& x) {
     }
     x.tau = 0.0f;   // recalibrate
     x.margin_err = 0.0f;
+    x.fallback_streak = x.skip_left = 0;
     e.exact_dirty = false;
     return PSEG_OK;
 }
@@ -295,7 +297,19 @@ static int exact_labels(Engine& e, const uint8_t* d_img, int H, int W, uint8_t* 
     float* d_margin = d_margin_out;
     if (!d_margin) { PSEG_TRY(xensure((void**)&x.d_margin, &x.margin_bytes, npx * 4)); d_margin = x.d_margin; }
     uint8_t* lab = d_labels_u8;
-    x.st_flag_px = x.st_blocks = x.st_area = x.st_escal = x.st_full = x.st_rects = x.st_changed = x.st_cost = 0;
+    x.st_flag_px = x.st_blocks = x.st_area = x.st_escal = x.st_full = x.st_rects = x.st_changed = x.st_cost = x.st_direct = 0;
+    // A stream of pages that all end in the whole-page referee (text pages: a class boundary in every block) does not need
+    // the bf16 pass in front of it: after three such pages in a row the next eight go to the float32 engine directly
+    // (10 % of the page's cost), then one page probes again.  Not when the caller wants the margin map.
+    if (x.skip_left > 0 && !d_margin_out && !PSEG_KNOB("PSEG_EXACT_TAU")) {
+        --x.skip_left;
+        KnobScope ks(x.f32->e);
+        PSEG_TRY(predict_device(x.f32->e, d_img, H, W, nullptr, nullptr, nullptr, lab, st, nullptr));
+        x.st_full = 1; x.st_area = 1.0; x.st_blocks = 1.0; x.st_cost = 1.0; x.st_direct = 1;
+        if (d_labels) widen_u8_kernel<<<(int)std::min<size_t>((npx + 255) / 256, 8192), 256, 0, st>>>(lab, d_labels, npx);
+        PSEG_HIP(hipGetLastError());
+        return PSEG_OK;
+    }
     // calibration: after a weight change, and again when the canvas has changed (another page format may carry other
     // content) -- at most every eighth page of a mixed-size stream: the running margin error from the refereed crops of
     // EVERY page is what tracks the stream, the calibration crops only seed it
@@ -389,6 +403,9 @@ static int exact_labels(Engine& e, const uint8_t* d_img, int H, int W, uint8_t* 
         x.st_full = 1;
         x.st_area = 1.0;
         x.st_blocks = 1.0;
+        if (++x.fallback_streak >= 3) { x.skip_left = 8; x.fallback_streak = 0; }
+    } else {
+        x.fallback_streak = 0;
     }
     if (d_labels) widen_u8_kernel<<<(int)std::min<size_t>((npx + 255) / 256, 8192), 256, 0, st>>>(lab, d_labels, npx);
     PSEG_HIP(hipGetLastError());
@@ -453,10 +470,10 @@ int pseg_label_exact_stats(const pseg_engine* h, double out[8]) {
 
 int pseg_label_exact_stats_ex(const pseg_engine* h, double* out, int cap) {
     if (!h || !out || cap < 0) return fail(PSEG_EINVAL, "bad argument");
-    double v[12] = {0};
+    double v[13] = {0};
     PSEG_TRY(pseg_label_exact_stats(h, v));
-    if (const auto* x = (const ExactState*)h->e.exact) { v[8] = x->margin_err; v[9] = x->st_rects; v[10] = x->st_cost; v[11] = XB; }
-    for (int i = 0; i < cap; ++i) out[i] = i < 12 ? v[i] : 0.0;
+    if (const auto* x = (const ExactState*)h->e.exact) { v[8] = x->margin_err; v[9] = x->st_rects; v[10] = x->st_cost; v[11] = XB; v[12] = x->st_direct; }
+    for (int i = 0; i < cap; ++i) out[i] = i < 13 ? v[i] : 0.0;
     return PSEG_OK;
 }
 

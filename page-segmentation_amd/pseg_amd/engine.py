@@ -339,12 +339,12 @@ class Engine:
 
     def label_exact_stats(self):
         """Statistics of the last predict_exact_labels[_device] call."""
-        v = (ctypes.c_double * 12)()
-        _check(lib().pseg_label_exact_stats_ex(self._h, v, 12))
+        v = (ctypes.c_double * 13)()
+        _check(lib().pseg_label_exact_stats_ex(self._h, v, 13))
         return {"tau": float(v[0]), "calib_logit_err": float(v[1]), "flagged_px_frac": float(v[2]), "referee_tile_frac": float(v[3]),
                 "referee_area_frac": float(v[4]), "tau_escalations": int(v[5]), "whole_page_fallback": int(v[6]),
                 "labels_changed": int(v[7]), "margin_err_running": float(v[8]), "referee_rects": int(v[9]),
-                "referee_cost_vs_full_page": float(v[10]), "flag_block": int(v[11])}
+                "referee_cost_vs_full_page": float(v[10]), "flag_block": int(v[11]), "direct_float32": int(v[12])}
 
     POST_OPS = {"cc_vote": 1, "bbox": 2}
 

@@ -219,3 +219,42 @@ def test_network_labels_mode_and_default_is_float32(gpu, oracle_mod):
     assert np.array_equal(l2, pr) and l2.dtype == np.int64
     assert np.abs(z2 - lo).max() <= 0.02 * max(1.0, float(np.abs(lo).max()))
     assert [np.array_equal(a, pr) for a in net2.predict_labels([img, img])] == [True, True]
+
+
+def test_label_exact_stream_of_whole_page_referees_skips_the_bf16_pass(gpu, oracle_mod):
+    """After three pages in a row whose referee took the whole page, the next eight go to the float32 engine directly (the
+    bf16 pass in front of a whole-page referee is wasted); every map still equals the float32 engine's, the ninth page
+    probes again, a weight change resets the streak."""
+    from pseg_amd import synth
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=42, gain=1.5, bias_scale=0.05)      # random weights: near-ties everywhere
+    eb = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
+    eb.set_weights(Wt)
+    e32 = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_F32_EXACT)
+    e32.set_weights(Wt)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    H, W = 256, 192
+    direct = []
+    for i in range(13):
+        img = synth.synth_page(20 + i, H, W, 3)[0]
+        d_img = torch.from_numpy(img).to(dev)
+        lab = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        l32 = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        eb.predict_exact_labels_device(d_img.data_ptr(), H, W, lab.data_ptr(), stream=st)
+        e32.predict_device(d_img.data_ptr(), H, W, d_labels_u8=l32.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        assert torch.equal(lab, l32), i
+        s = eb.label_exact_stats()
+        assert s["whole_page_fallback"] == 1
+        direct.append(s["direct_float32"])
+    assert direct == [0, 0, 0] + [1] * 8 + [0, 0], direct
+    eb.set_weights(Wt)
+    img = synth.synth_page(99, H, W, 3)[0]
+    d_img = torch.from_numpy(img).to(dev)
+    lab = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    eb.predict_exact_labels_device(d_img.data_ptr(), H, W, lab.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert eb.label_exact_stats()["direct_float32"] == 0
+    eb.close()
+    e32.close()

@@ -187,3 +187,62 @@ def test_bbox_masks_otsu(oracle_mod):
     g = np.concatenate([np.full(500, 40, np.uint8), np.full(300, 200, np.uint8)]).reshape(20, 40)
     t = oracle_mod.otsu_threshold(g)
     assert 40 <= t < 200
+
+
+
+
+def _round_f32(fr):
+    """Correctly rounded float32 of a Fraction (round-to-nearest-even), without an intermediate float64 rounding."""
+    from fractions import Fraction
+    if fr == 0:
+        return np.float32(0.0)
+    sign = -1 if fr < 0 else 1
+    a = abs(fr)
+    import math
+    e = math.floor(math.log2(a)) if a >= 1 else -math.ceil(-math.log2(a))
+    while Fraction(2) ** e > a:
+        e -= 1
+    while Fraction(2) ** (e + 1) <= a:
+        e += 1
+    e = max(e, -126)                              # subnormals share the smallest exponent
+    q = a / (Fraction(2) ** (e - 23))             # 24 significant bits in the integer part
+    n, rem = divmod(q.numerator, q.denominator)
+    twice = 2 * rem
+    if twice > q.denominator or (twice == q.denominator and (n & 1)):
+        n += 1
+    return np.float32(sign * float(Fraction(n) * Fraction(2) ** (e - 23)))
+
+
+def test_conv_chain_is_blocked_in_slabs_of_16_channels(oracle_mod):
+    """Pins the accumulation order the float32 engine and the C oracle share (oracle/pseg_oracle.c header): acc = +0; for
+    every slab of 16 input channels: for ky, kx, ci in the slab: acc = fmaf(x, w, acc); out = acc + bias.  Restated here with
+    exact rational arithmetic and one correctly rounded float32 per fmaf -- no libm, no C -- and compared bit for bit; the
+    all-channels-inside-each-tap order of rounds 1-2 must differ somewhere (the test discriminates)."""
+    from fractions import Fraction
+    rng = np.random.default_rng(3)
+    for Cin, Cout, k in ((20, 3, 3), (40, 2, 3), (16, 2, 5)):
+        H, W = 5, 6
+        x = rng.standard_normal((H, W, Cin)).astype(np.float32)
+        w = (rng.standard_normal((k, k, Cin, Cout)) * 0.3).astype(np.float32)
+        b = rng.standard_normal(Cout).astype(np.float32)
+        got = oracle_mod.core.conv2d(x, w, b)
+        pt = (k - 1) // 2
+
+        def chain(order):
+            out = np.zeros((H, W, Cout), np.float32)
+            for y in range(H):
+                for xx in range(W):
+                    for co in range(Cout):
+                        acc = np.float32(0.0)
+                        for (ky, kx, ci) in order:
+                            iy, ix = y + ky - pt, xx + kx - pt
+                            if 0 <= iy < H and 0 <= ix < W:
+                                acc = _round_f32(Fraction(float(x[iy, ix, ci])) * Fraction(float(w[ky, kx, ci, co])) + Fraction(float(acc)))
+                        out[y, xx, co] = np.float32(acc + b[co])
+            return out
+        blocked = [(ky, kx, ci) for cb in range(0, Cin, 16) for ky in range(k) for kx in range(k) for ci in range(cb, min(cb + 16, Cin))]
+        plain = [(ky, kx, ci) for ky in range(k) for kx in range(k) for ci in range(Cin)]
+        want = chain(blocked)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (Cin, Cout, k)
+        if Cin > 16:
+            assert not np.array_equal(chain(plain).view(np.uint32), want.view(np.uint32)), "the two orders agree everywhere: the case does not discriminate"

@@ -236,6 +236,13 @@ def leg_f32(torch, pseg_amd, synth, weights, d_img, H, W, C, dev, arch):
            "per_kernel_ms": {s[0]: round(s[1] / s[2], 5) for s in slots},
            "what": "PSEG_MODE_F32_EXACT, %dx%d, %s, uint8 labels left in HBM; peak 157.3 TFLOP/s (dense f32 MFMA)" % (H, W, arch)}
     e32.close()
+    for other in ("unet", "res_unet"):           # the 3x3 stacks in float32 (what the drop-in Network costs for them by default)
+        eo = pseg_amd.Engine(other, C, device=dev.index, mode=pseg_amd.MODE_F32_EXACT)
+        eo.set_weights(synth.glorot_weights(eo.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+        fo = lambda: eo.predict_device(d_img.data_ptr(), H, W, d_labels_u8=lab.data_ptr(), stream=st)
+        to = _sync_time(torch, fo, 3, warm=1)
+        res[other] = {"ms_per_page": round(to * 1e3, 3), "whole_net_frac_f32_peak": round(eo.flops_per_pixel() * H * W / to / 1e12 / PEAK_TFLOPS["f32"], 5)}
+        eo.close()
     return res
 
 

@@ -117,7 +117,7 @@ __global__ void ccl_compress_kernel(int* L, int n, int* hist = nullptr, int ncls
 // tile-local root (the raster-first pixel of the component's part inside the tile).  Only pixels on tile borders then
 // need global unions (8 % of the page), followed by the global compress pass.  Roots are still the component's minimum
 // linear index: the raster-first pixel of a component is the raster-first pixel of its tile part, hence a local root.
-constexpr int CT_H = 16, CT_W = 64;
+constexpr int CT_H = 32, CT_W = 64;
 
 __device__ __forceinline__ int lds_find(const int* lab, int x) {
     int r = __hip_atomic_load(&lab[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -334,7 +334,8 @@ __global__ void vote_apply_kernel(const int* L, const int* hist, LT* pred, int n
 // (Round 3 measured a tile-local variant -- 32 x 64 tiles labelled AND counted in LDS, only components that cross a tile
 // border going through global memory, 4 launches, ~3 B/px of traffic: 0.262 ms against 0.182 ms for the path below on
 // configs[4]'s page, 0.161 against 0.145 ms with the speckled image rectangles blanked.  Its LDS union-find over 2 048
-// pixels per workgroup (112 us) costs more than the 32-bit label traffic it saves; removed again)
+// pixels per workgroup (112 us) costs more than the 32-bit label traffic it saves; removed again, DESIGN.md section 5.
+// Also measured: an apply pass of four pixels per thread that looks at the binarisation before the labels: 0.166 vs 0.160 ms.)
 // Label / histogram workspace of the vote: grow-only, one per device, shared by every caller.  A 4096x3072 6-class
 // page needs 50 + 302 MB; allocating and freeing it per call cost more than the kernels.  Calls are ordered by an
 // event: a call on another stream than the previous user's first waits for that user's kernels, so two streams (or

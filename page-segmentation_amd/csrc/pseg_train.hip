@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include "pseg_common.h"
+#include "pseg_wgrad.h"
 
 namespace pseg {
 
@@ -271,41 +272,6 @@ __global__ void pool_bwd_kernel(const float* X, const float* dY, int H, int W, i
             if (X[o[q]] > bv) { bv = X[o[q]]; best = q; }
         dX[o[best]] += dY[t];
     }
-}
-
-// dW[tap][ci0+ci][co] += sum over the pixel strip of X[src pixel of (p, tap)][ci] * dY'[p][co]
-// mode 0 (conv / logits): p = (y,x) of dY, X pixel = (y + ky - pt, x + kx - pl) (zero outside)
-// mode 1 (deconv k2s2):   p = (i,j) of X,  dY pixel = (2i + a, 2j + b), tap = ab
-struct WgradArgs {
-    const float* X;
-    int XC, ci0, Hx, Wx, xpitch;
-    const float* dY;
-    const float* maskY;
-    int Hy, Wy, ypitch, Cout, Cin;
-    int KW, pt, pl, mode, strip_rows;
-    float* dW;
-    float* dB;   // only written by blocks with tap 0 when non-null
-    // matrix-core kernel only: conv stride (X pixel = y * stride + ky - pt), X stored at half resolution and
-    // read through a nearest x2 upsample (Hx, Wx are then the upsampled extents, xpitch the stored row pitch),
-    // pre-activation ReLU on X (res_unet)
-    int stride = 1, xup = 0, in_relu = 0;
-    // Deterministic form (default): a workgroup does not add its strip's partial sums into dW / dB with float atomics (whose
-    // arrival order, and with it the last bits of the sum, changed from run to run) but stores them -- every element of its
-    // (tap, channel block) exactly once -- into its own row of a scratch array, part[strip][tap][ci][co] (XC channels of this
-    // launch) and partB[strip * 4 + wave][co]; wgrad_reduce_kernel then sums the strips in index order.
-    float* part = nullptr;
-    float* partB = nullptr;
-    size_t pstride = 0;      // floats per strip row of `part` = taps * XC * Cout
-};
-
-// one weight-gradient element / one bias partial of a strip leaves the kernel
-__device__ __forceinline__ void wg_out(const WgradArgs& a, int strip, int tap, int ci, int co, float v) {
-    if (a.part) a.part[(size_t)strip * a.pstride + ((size_t)tap * a.XC + ci) * a.Cout + co] = v;
-    else atomicAdd(&a.dW[((size_t)tap * a.Cin + a.ci0 + ci) * a.Cout + co], v);
-}
-__device__ __forceinline__ void wg_out_bias(const WgradArgs& a, int strip, int wave, int co, float v) {
-    if (a.partB) a.partB[((size_t)strip * 4 + wave) * a.Cout + co] = v;
-    else atomicAdd(&a.dB[co], v);
 }
 
 // dW[tap][ci0 + ci][co] = sum over the strips of part[strip][tap][ci][co] in a FIXED association: groups of WGR_GROUP
@@ -848,11 +814,15 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
     const int itH = a.mode == 0 ? a.Hy : a.Hx;
     const int taps = (int)grid.y;
     // ---- which instance, with which strips
-    enum { V_C1, V_KX5, V_TAP, V_WIDE, V_SCALAR } variant;
+    enum { V_FLAT, V_C1, V_KX5, V_TAP, V_WIDE, V_SCALAR } variant;
     const bool scalar = PSEG_KNOB("PSEG_WGRAD_SCALAR") != nullptr;
+    WgradFlatPlan flat;
     const bool lds = a.mode == 0 && a.stride == 1 && !a.xup && !PSEG_KNOB("PSEG_WGRAD_NO_LDS");
     const int ti = (a.XC + 15) / 16, tj = (a.Cout + 15) / 16;
-    if (a.XC == 1 && a.mode == 0 && a.stride == 1 && !a.xup && !a.in_relu && a.KW * a.KW <= 32 && a.Cout <= 64 && !PSEG_KNOB("PSEG_WGRAD_NO_C1") && !scalar) {
+    if (!scalar && wgrad_flat_plan(a, taps, &flat)) {
+        variant = V_FLAT;                                      // the k5 layers of fcn / fcn_skip (pseg_wgrad_flat.hip)
+        a.strip_rows = flat.strip_rows;
+    } else if (a.XC == 1 && a.mode == 0 && a.stride == 1 && !a.xup && !a.in_relu && a.KW * a.KW <= 32 && a.Cout <= 64 && !PSEG_KNOB("PSEG_WGRAD_NO_C1") && !scalar) {
         variant = V_C1;
         a.strip_rows = std::max(1, cdiv(a.Hy, 1024));
     } else if (a.XC <= 16 * WGM_MAXT && a.Cout <= 16 * WGM_MAXT && !scalar) {
@@ -868,7 +838,7 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
     } else {
         variant = V_SCALAR;
     }
-    const int nstrips = cdiv(itH, a.strip_rows);
+    const int nstrips = variant == V_FLAT ? flat.nstrips : cdiv(itH, a.strip_rows);
     // ---- deterministic form: partial sums per strip, then one ordered reduction (PSEG_WGRAD_ATOMIC=1: float atomics)
     const bool det = !PSEG_KNOB("PSEG_WGRAD_ATOMIC");
     if (det) {
@@ -884,6 +854,7 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
         a.partB = a.dB ? *scratch + (size_t)nstrips * a.pstride : nullptr;
     }
     switch (variant) {
+        case V_FLAT: PSEG_TRY(wgrad_flat_launch(a, flat, st)); break;
         case V_C1: {
             if (a.KW * a.KW <= 16) {
                 if (tj <= 2) wgrad_c1_kernel<1, 2><<<nstrips, 256, 0, st>>>(a);

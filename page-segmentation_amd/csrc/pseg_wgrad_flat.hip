@@ -1,0 +1,276 @@
+// pseg_wgrad_flat.hip -- weight gradient of the stride-1 convolutions of fcn / fcn_skip on the matrix cores, rows flattened.
+//
+//   dW[(tap, ci)][co] = sum over pixels p of X[p + tap][ci] * dY'[p][co]          (dY' = dY under the layer's ReLU mask)
+//
+// is a GEMM with M = taps x Cin rows, N = Cout columns and K = every pixel of the map.  The kernels of pseg_train.hip give
+// each tap its own 16-row tiles (Cin = 20 fills 20 of 32 rows: 37 % of the matrix work multiplies padding) and let every
+// wave keep ALL tiles for a quarter of the pixels (4x the accumulators, a cross-wave reduction at the end, and each tap's
+// workgroup staging the same rows again).  Here the (tap, ci) pairs of KYN kernel rows are ONE row index m = tap * XC + ci,
+// cut into 16-row tiles without regard to tap borders (25 x 20 = 500 rows = 32 tiles, 2 % padding), and the waves of a
+// workgroup split the TILES, not the pixels: a wave keeps MW x NT accumulator tiles, walks every pixel quad of the piece,
+// and nothing is reduced across waves.
+//
+// Data movement.  A workgroup owns a row strip x a column group and walks it column piece by column piece (PW pixels wide),
+// top to bottom.  Per output row it brings ONE new X row piece (PW + KW - 1 pixels x XC channels -- contiguous in NHWC, so
+// the copy is plain 16 / 8-byte vectors with no index arithmetic) into a ring of KYN + 1 row slots in LDS, and one dY row
+// piece (+ its mask) into one of two buffers; the loads are issued before the multiply phase of the previous row and land
+// in registers under it, so a row costs one barrier.  Image borders, the piece's right edge and rows above / below the map
+// are the buffer descriptor's range check (out-of-range dwords read as zero): no compares in the copy.
+// Fragments: lane (c = lane & 15, g = lane >> 4) of tile row m = (ky, kx, ci) reads X slot[ky][pixel 4q + g + kx][ci] --
+// one ds_read_b32 whose address is a per-tile register + a compile-time offset per quad (XC, Cout, KW are template
+// parameters for exactly that reason: the multiply phase issues no VALU address arithmetic; VALU and MFMA share a SIMD's
+// issue port).  Columns >= Cout of the last dY tile read the next pixel's values: they only reach accumulator columns that
+// are never written out.
+//
+// Summation order (pixels in walk order per strip, strips reduced by wgrad_reduce_*): float32, deterministic, not the
+// oracle's order -- the train step is held to a float tolerance against torch autograd (tests/test_train_gpu.py).
+#include <algorithm>
+
+#include "pseg_wgrad.h"
+
+namespace pseg {
+
+typedef __attribute__((ext_vector_type(4))) float wf_f32x4;
+
+template <int VW>
+__device__ __forceinline__ void wf_bload(float* dst, __amdgpu_buffer_rsrc_t r, int voff) {
+    if constexpr (VW == 4) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = __builtin_bit_cast(float, (unsigned)v[k]);
+    } else if constexpr (VW == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+        dst[0] = __builtin_bit_cast(float, (unsigned)v[0]);
+        dst[1] = __builtin_bit_cast(float, (unsigned)v[1]);
+    } else {
+        dst[0] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+    }
+}
+template <int VW>
+__device__ __forceinline__ void wf_lds_store(float* dst, const float* v) {
+    if constexpr (VW == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+    else if constexpr (VW == 2) *(float2*)dst = make_float2(v[0], v[1]);
+    else *dst = v[0];
+}
+
+// XC / CO / KW: the layer (source channels, output channels, kernel width).  KYN: kernel rows per workgroup (1 or KW).
+// NW: waves per workgroup, MW: 16-row tiles per wave (NW * MW >= tiles of KYN * KW * XC rows).  PW: pixels per piece.
+template <int XC, int CO, int KW, int KYN, int NW, int MW, int PW>
+__global__ __launch_bounds__(NW * 64) void wgrad_flat_kernel(WgradArgs a) {
+    constexpr int NT = (CO + 15) / 16, NTHR = NW * 64;
+    constexpr int QU = MW * NT >= 24 ? 2 : 4;              // quads unrolled (>= 48 independent MFMAs in flight; a full unroll hoists every fragment load and doubles the registers)
+    constexpr int MROWS = KYN * KW * XC, MTILES = (MROWS + 15) / 16;
+    static_assert(MTILES <= NW * MW, "tiles do not fit the waves");
+    constexpr int XPX = PW + KW - 1, XROW = XPX * XC, RS = KYN + 1, YSZ = PW * CO;
+    constexpr int VX = XC % 4 == 0 ? 4 : (XC % 2 == 0 ? 2 : 1), VY = CO % 4 == 0 ? 4 : (CO % 2 == 0 ? 2 : 1);
+    constexpr int NXV = XROW / VX, NYV = YSZ / VY;
+    constexpr int EXV = (NXV + NTHR - 1) / NTHR, EYV = (NYV + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) float Xs[RS * XROW];
+    __shared__ __attribute__((aligned(16))) float Ys[2 * YSZ + 16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p16 = lane & 15, g = lane >> 4;
+    const int ky0 = blockIdx.x * KYN;
+    const int strip = blockIdx.y, cgi = strip % a.cgroups, rsi = strip / a.cgroups;
+    const int r0 = rsi * a.strip_rows, nrows = max(0, min(r0 + a.strip_rows, a.Hy) - r0);
+    const int cpr = (a.Wy + PW - 1) / PW, cper = (cpr + a.cgroups - 1) / a.cgroups;
+    const int pc0 = cgi * cper, ncols = max(0, min(pc0 + cper, cpr) - pc0);
+    const int total = nrows + KYN - 1;                       // X rows staged per column piece
+    const int T = nrows > 0 ? ncols * total : 0;
+
+    // tile rows of this lane: m = (ky, kx, ci) -> float offset inside a ring slot (+ the lane's pixel g), and ky
+    int aconst[MW], akyl[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int m = min((wave * MW + i) * 16 + p16, MROWS - 1);   // (padding rows repeat the last row: never written out)
+        const int tapl = m / XC, ci = m - tapl * XC, kyl = tapl / KW, kx = tapl - kyl * KW;
+        aconst[i] = (kx + g) * XC + ci;
+        akyl[i] = kyl;
+    }
+    wf_f32x4 acc[MW][NT];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = wf_f32x4{0.f, 0.f, 0.f, 0.f};
+    float bacc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bacc[j] = 0.0f;
+    const bool want_b = a.dB != nullptr && blockIdx.x == 0 && wave == 0;
+
+    // staging registers + the byte offsets of this thread's vectors inside a row piece (-1 = none)
+    float xr[EXV][VX], yr[EYV][VY], ym[EYV][VY];
+    int xvo[EXV], yvo[EYV];
+#pragma unroll
+    for (int u = 0; u < EXV; ++u) xvo[u] = tid + u * NTHR < NXV ? (tid + u * NTHR) * VX * 4 : -1;
+#pragma unroll
+    for (int u = 0; u < EYV; ++u) yvo[u] = tid + u * NTHR < NYV ? (tid + u * NTHR) * VY * 4 : -1;
+    const bool has_mask = a.maskY != nullptr;
+
+    int fcol = pc0, fs = 0;                                  // the stage the next fetch() brings
+    auto fetch = [&]() {
+        const int x0 = fcol * PW;
+        const int sy = r0 + fs + ky0 - a.pt;
+        const bool rowok = sy >= 0 && sy < a.Hx;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.X + (size_t)(rowok ? sy : 0) * a.xpitch * XC), 0, rowok ? a.Wx * XC * 4 : 0, 0x00020000);
+        const int xb = (x0 - a.pl) * XC * 4;                 // negative at the left border: wraps past the range check -> zeros
+#pragma unroll
+        for (int u = 0; u < EXV; ++u) wf_bload<VX>(xr[u], xrs, xvo[u] < 0 ? -4 : xb + xvo[u]);
+        if (fs >= KYN - 1) {
+            const int y = r0 + fs - (KYN - 1);
+            const int yb = x0 * CO * 4;
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dY + (size_t)y * a.ypitch * CO), 0, a.Wy * CO * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < EYV; ++u) wf_bload<VY>(yr[u], yrs, yvo[u] < 0 ? -4 : yb + yvo[u]);
+            if (has_mask) {
+                const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.maskY + (size_t)y * a.ypitch * CO), 0, a.Wy * CO * 4, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < EYV; ++u) wf_bload<VY>(ym[u], mrs, yvo[u] < 0 ? -4 : yb + yvo[u]);
+            }
+        }
+        if (++fs == total) { fs = 0; ++fcol; }
+    };
+
+    int wslot = 0, ybuf = 0, cs = 0;
+    if (T > 0) fetch();
+    for (int it = 0; it < T; ++it) {
+        // ---- commit the staged row(s)
+        {
+            float* xd = Xs + wslot * XROW;
+#pragma unroll
+            for (int u = 0; u < EXV; ++u)
+                if (xvo[u] >= 0) {
+                    if (a.in_relu)
+#pragma unroll
+                        for (int k = 0; k < VX; ++k) xr[u][k] = xr[u][k] > 0.0f ? xr[u][k] : 0.0f;
+                    wf_lds_store<VX>(xd + (xvo[u] >> 2), xr[u]);
+                }
+            if (cs >= KYN - 1) {
+                float* yd = Ys + ybuf * YSZ;
+#pragma unroll
+                for (int u = 0; u < EYV; ++u)
+                    if (yvo[u] >= 0) {
+                        if (has_mask)
+#pragma unroll
+                            for (int k = 0; k < VY; ++k) yr[u][k] = ym[u][k] > 0.0f ? yr[u][k] : 0.0f;
+                        wf_lds_store<VY>(yd + (yvo[u] >> 2), yr[u]);
+                    }
+            }
+        }
+        __syncthreads();
+        if (it + 1 < T) fetch();                             // lands under the multiplies below
+        if (cs >= KYN - 1) {
+            int sb = wslot - (KYN - 1);
+            if (sb < 0) sb += RS;
+            const float* xa_p[MW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                int s = sb + akyl[i];
+                if (s >= RS) s -= RS;
+                xa_p[i] = Xs + s * XROW + aconst[i];
+            }
+            const float* yb_p = Ys + ybuf * YSZ + g * CO + p16;
+#pragma unroll QU
+            for (int q = 0; q < PW / 4; ++q) {
+                float xa[MW], yb[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) yb[j] = yb_p[q * 4 * CO + j * 16];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) xa[i] = xa_p[i][q * 4 * XC];
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+                if (want_b)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bacc[j] += yb[j];
+            }
+            ybuf ^= 1;
+        }
+        wslot = wslot + 1 == RS ? 0 : wslot + 1;
+        if (++cs == total) cs = 0;
+    }
+
+    // ---- D tile: lane holds rows 4g .. 4g+3, column p16 -- straight into this strip's row of `part` (or atomics)
+    const int tap0 = ky0 * KW;
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = (wave * MW + i) * 16 + 4 * g + r, co = j * 16 + p16;
+                if (m < MROWS && co < CO) {
+                    if (a.part) a.part[(size_t)strip * a.pstride + ((size_t)tap0 * XC + m) * CO + co] = acc[i][j][r];
+                    else { const int tl = m / XC; wg_out(a, strip, tap0 + tl, m - tl * XC, co, acc[i][j][r]); }
+                }
+            }
+    if (a.dB != nullptr && blockIdx.x == 0 && wave < 4) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float v = bacc[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0 && j * 16 + p16 < CO) wg_out_bias(a, strip, wave, j * 16 + p16, wave == 0 ? v : 0.0f);
+        }
+    }
+}
+
+// ---- instance table: one fully specialised kernel per layer shape of fcn / fcn_skip (lib/model.py:50-85)
+struct FlatInstance {
+    int XC, CO, KW, KYN, NW, PW;
+    int wg_per_cu;                                           // workgroups of this instance a CU holds (LDS / registers): sizes the grid
+    void (*kernel)(WgradArgs);
+};
+#define PSEG_FLAT(XC_, CO_, KW_, KYN_, NW_, MW_, PW_, OCC_) {XC_, CO_, KW_, KYN_, NW_, PW_, OCC_, wgrad_flat_kernel<XC_, CO_, KW_, KYN_, NW_, MW_, PW_>}
+static const FlatInstance g_flat[] = {
+    PSEG_FLAT(20, 30, 5, 5, 4, 8, 64, 3),    // conv2:  500 rows = 32 tiles
+    PSEG_FLAT(30, 40, 5, 5, 8, 6, 32, 2),    // conv3:  750 rows = 47 tiles
+    PSEG_FLAT(40, 40, 5, 5, 8, 8, 32, 2),    // conv4: 1000 rows = 63 tiles
+    PSEG_FLAT(40, 60, 5, 5, 8, 8, 32, 2),    // conv5
+    PSEG_FLAT(60, 60, 5, 1, 4, 5, 64, 3),    // conv6:  300 rows = 19 tiles per kernel row
+    PSEG_FLAT(60, 80, 5, 1, 4, 5, 64, 2),    // conv7
+    PSEG_FLAT(80, 80, 5, 1, 4, 7, 64, 2),    // deconv1 (k5 s1): 400 rows = 25 tiles
+    PSEG_FLAT(60, 40, 5, 1, 4, 5, 64, 3),    // deconv3 (k5 s1), both sources of its concat
+};
+#undef PSEG_FLAT
+
+bool wgrad_flat_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan) {
+    if (a.mode != 0 || a.stride != 1 || a.xup || taps != a.KW * a.KW || PSEG_KNOB("PSEG_WGRAD_NO_FLAT")) return false;
+    if ((size_t)a.Wx * a.XC * 4 >= (1ull << 31) || (size_t)a.Wy * a.Cout * 4 >= (1ull << 31)) return false;   // 32-bit buffer offsets per row
+    for (int k = 0; k < (int)(sizeof(g_flat) / sizeof(g_flat[0])); ++k) {
+        const FlatInstance& f = g_flat[k];
+        if (f.XC != a.XC || f.CO != a.Cout || f.KW != a.KW) continue;
+        const int kyg = f.KW / f.KYN;
+        const int cpr = cdiv(a.Wy, f.PW);
+        // one column piece per workgroup where the map is tall enough to keep the ring primed for many rows; the strips are
+        // sized for one resident round of workgroups
+        const int target = 256 * f.wg_per_cu;
+        int cgroups = cpr;
+        int rows = std::max(1, cdiv(a.Hy * cgroups * kyg, target));
+        const int min_rows = f.KYN > 1 ? 8 : 2;               // a strip shorter than this mostly primes its ring
+        while (rows < min_rows && cgroups > 1) {
+            cgroups = cdiv(cgroups, 2);
+            rows = std::max(1, cdiv(a.Hy * cgroups * kyg, target));
+        }
+        cgroups = cdiv(cpr, cdiv(cpr, cgroups));              // no empty group
+        plan->instance = k;
+        plan->strip_rows = rows;
+        plan->cgroups = cgroups;
+        plan->nstrips = cdiv(a.Hy, rows) * cgroups;
+        return true;
+    }
+    return false;
+}
+
+int wgrad_flat_launch(const WgradArgs& a_in, const WgradFlatPlan& plan, hipStream_t st) {
+    const FlatInstance& f = g_flat[plan.instance];
+    WgradArgs a = a_in;
+    a.strip_rows = plan.strip_rows;
+    a.cgroups = plan.cgroups;
+    const dim3 grid(f.KW / f.KYN, plan.nstrips);
+    hipLaunchKernelGGL(f.kernel, grid, dim3(f.NW * 64), 0, st, a);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+}  // namespace pseg

@@ -242,15 +242,29 @@ bool wgrad_flat_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan) {
         if (f.XC != a.XC || f.CO != a.Cout || f.KW != a.KW) continue;
         const int kyg = f.KW / f.KYN;
         const int cpr = cdiv(a.Wy, f.PW);
-        // one column piece per workgroup where the map is tall enough to keep the ring primed for many rows; the strips are
-        // sized for one resident round of workgroups
-        const int target = 256 * f.wg_per_cu;
-        int cgroups = cpr;
-        int rows = std::max(1, cdiv(a.Hy * cgroups * kyg, target));
+        // Every workgroup does the same work per row, so the grid is sized to ONE resident round: as many workgroups as the
+        // chip holds at this instance's occupancy (asked of the runtime once), never a few more -- 528 workgroups on 512
+        // slots ran three rounds for the work of two (conv4: 740 us against 500).  One column piece per workgroup where the
+        // map is tall enough to keep the ring primed for many rows; shorter maps give a workgroup several pieces.
+        static int wg_per_cu[sizeof(g_flat) / sizeof(g_flat[0])];
+        if (wg_per_cu[k] == 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)f.kernel, f.NW * 64, 0) != hipSuccess || n < 1) n = f.wg_per_cu;
+            wg_per_cu[k] = n;
+        }
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0, n = 0;
+            ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        }
+        const int target = ncu * wg_per_cu[k];
         const int min_rows = f.KYN > 1 ? 8 : 2;               // a strip shorter than this mostly primes its ring
-        while (rows < min_rows && cgroups > 1) {
+        int cgroups = cpr, rows = 1;
+        for (;;) {
+            const int nrs = std::max(1, target / (cgroups * kyg));   // row strips that fit the round
+            rows = cdiv(a.Hy, nrs);
+            if (rows >= min_rows || cgroups == 1) break;
             cgroups = cdiv(cgroups, 2);
-            rows = std::max(1, cdiv(a.Hy * cgroups * kyg, target));
         }
         cgroups = cdiv(cpr, cdiv(cpr, cgroups));              // no empty group
         plan->instance = k;

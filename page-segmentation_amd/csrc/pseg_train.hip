@@ -820,12 +820,16 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
     const int itH = a.mode == 0 ? a.Hy : a.Hx;
     const int taps = (int)grid.y;
     // ---- which instance, with which strips
-    enum { V_FLAT, V_C1, V_KX5, V_TAP, V_WIDE, V_SCALAR } variant;
+    enum { V_PAIR, V_FLAT, V_C1, V_KX5, V_TAP, V_WIDE, V_SCALAR } variant;
     const bool scalar = PSEG_KNOB("PSEG_WGRAD_SCALAR") != nullptr;
     WgradFlatPlan flat;
     const bool lds = a.mode == 0 && a.stride == 1 && !a.xup && !PSEG_KNOB("PSEG_WGRAD_NO_LDS");
     const int ti = (a.XC + 15) / 16, tj = (a.Cout + 15) / 16;
-    if (!scalar && wgrad_flat_plan(a, taps, &flat)) {
+    if (a.XC0 > 0) {                                          // both concat sources + the bias gradient in one pass (pseg_wgrad_flat.hip)
+        if (!wgrad_pair_plan(a, taps, &flat)) return fail(PSEG_EINVAL, "no two-source weight-gradient instance for this layer");
+        variant = V_PAIR;
+        a.strip_rows = flat.strip_rows;
+    } else if (!scalar && wgrad_flat_plan(a, taps, &flat)) {
         variant = V_FLAT;                                      // the k5 layers of fcn / fcn_skip (pseg_wgrad_flat.hip)
         a.strip_rows = flat.strip_rows;
     } else if (a.XC == 1 && a.mode == 0 && a.stride == 1 && !a.xup && !a.in_relu && a.KW * a.KW <= 32 && a.Cout <= 64 && !PSEG_KNOB("PSEG_WGRAD_NO_C1") && !scalar) {
@@ -844,7 +848,7 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
     } else {
         variant = V_SCALAR;
     }
-    const int nstrips = variant == V_FLAT ? flat.nstrips : cdiv(itH, a.strip_rows);
+    const int nstrips = (variant == V_FLAT || variant == V_PAIR) ? flat.nstrips : cdiv(itH, a.strip_rows);
     // ---- deterministic form: partial sums per strip, then one ordered reduction (PSEG_WGRAD_ATOMIC=1: float atomics)
     const bool det = !PSEG_KNOB("PSEG_WGRAD_ATOMIC");
     if (det) {
@@ -860,6 +864,7 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
         a.partB = a.dB ? *scratch + (size_t)nstrips * a.pstride : nullptr;
     }
     switch (variant) {
+        case V_PAIR: PSEG_TRY(wgrad_pair_launch(a, flat, st)); break;
         case V_FLAT: PSEG_TRY(wgrad_flat_launch(a, flat, st)); break;
         case V_C1: {
             if (a.KW * a.KW <= 16) {
@@ -1207,6 +1212,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
         return ensure_buf((void**)&t->d_wd, &t->wd_bytes, (floats + COT) * 4);
     };
     const int strips_target = 1536;
+    const bool scalar_wgrad = PSEG_KNOB("PSEG_WGRAD_SCALAR") != nullptr;
 
     for (int oi = (int)e.ops.size() - 1; oi >= 0; --oi) {
         Op& op = e.ops[oi];
@@ -1243,7 +1249,20 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 accum_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(t->tgrad[op.add], dY, maskY, nullptr, n);
             }
             // ---- wgrad + bias grad ----
-            for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
+            bool paired = false;
+            if (lg && !scalar_wgrad) {   // the 1x1 logits layer: both sources and the bias in one pass over dY
+                WgradArgs a{};
+                a.X = (const float*)s0.d; a.XC0 = C0; a.X1 = s1 ? (const float*)s1->d : nullptr; a.XC = C0 + C1; a.ci0 = 0;
+                a.Hx = Hx; a.Wx = Wx; a.xpitch = Wx; a.xup = 0; a.stride = 1; a.in_relu = op.in_relu;
+                a.dY = dY; a.maskY = maskY; a.Hy = Hy; a.Wy = Wy; a.ypitch = Wy; a.Cout = op.Cout; a.Cin = op.Cin;
+                a.KW = k; a.pt = pt; a.pl = pl; a.mode = 0; a.strip_rows = 1; a.dW = gw; a.dB = gb;
+                WgradFlatPlan pp;
+                if (!op.up0 && !op.up1 && st_ == 1 && wgrad_pair_plan(a, k * k, &pp)) {
+                    PSEG_TRY(launch_wgrad(a, dim3(1, k * k), st, &t->d_wpart, &t->wpart_bytes));
+                    paired = true;
+                }
+            }
+            for (int sidx = 0; sidx < (paired ? 0 : (s1 ? 2 : 1)); ++sidx) {
                 const Tensor& sx = sidx == 0 ? s0 : *s1;
                 const int up = sidx == 0 ? op.up0 : op.up1;
                 WgradArgs a{};
@@ -1306,7 +1325,21 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
             const float* dY = t->tgrad[op.dst];
             const float* Y = (const float*)e.tensors[op.dst].d;
             const int Hx = e.tH(s0), Wx = e.tW(s0);
-            for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
+            bool paired = false;
+            if (!scalar_wgrad) {   // both sources and the bias gradient in one pass over dY
+                WgradArgs a{};
+                a.X = (const float*)s0.d; a.XC0 = C0; a.X1 = s1 ? (const float*)s1->d : nullptr; a.XC = C0 + C1; a.ci0 = 0;
+                a.Hx = Hx; a.Wx = Wx; a.xpitch = Wx;
+                a.dY = dY; a.maskY = op.relu ? Y : nullptr;
+                a.Hy = 2 * Hx; a.Wy = 2 * Wx; a.ypitch = 2 * Wx; a.Cout = op.Cout; a.Cin = op.Cin;
+                a.KW = 2; a.mode = 1; a.strip_rows = 1; a.dW = gw; a.dB = gb;
+                WgradFlatPlan pp;
+                if (wgrad_pair_plan(a, 4, &pp)) {
+                    PSEG_TRY(launch_wgrad(a, dim3(1, 4), st, &t->d_wpart, &t->wpart_bytes));
+                    paired = true;
+                }
+            }
+            for (int sidx = 0; sidx < (paired ? 0 : (s1 ? 2 : 1)); ++sidx) {
                 const Tensor& sx = sidx == 0 ? s0 : *s1;
                 WgradArgs a{};
                 a.X = (const float*)sx.d; a.XC = sx.C; a.ci0 = sidx == 0 ? 0 : C0; a.Hx = Hx; a.Wx = Wx; a.xpitch = Wx;
@@ -1318,10 +1351,12 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 dim3 grid(cdiv(Hx, a.strip_rows), 4);
                 PSEG_TRY(launch_wgrad(a, grid, st, &t->d_wpart, &t->wpart_bytes));
             }
+            if (!paired) {
             if (op.Cout > 256) return fail(PSEG_EUNSUPPORTED, "bias gradient supports at most 256 channels");
             PSEG_TRY(ensure_buf((void**)&t->d_bpart, &t->bpart_bytes, (size_t)BG_BLOCKS * op.Cout * 8));
             bias_grad_kernel<<<BG_BLOCKS, 256, 0, st>>>(dY, op.relu ? Y : nullptr, (size_t)4 * Hx * Wx, op.Cout, (double*)t->d_bpart);
             column_sum_kernel<double><<<op.Cout, 256, 0, st>>>((const double*)t->d_bpart, BG_BLOCKS, op.Cout, gb);
+            }
             PSEG_HIP(hipGetLastError());
             for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
                 const int src = sidx == 0 ? op.src0 : op.src1;

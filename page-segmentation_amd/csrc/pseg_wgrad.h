@@ -28,6 +28,9 @@ struct WgradArgs {
     float* partB = nullptr;
     size_t pstride = 0;      // floats per strip row of `part` = taps * XC * Cout
     int cgroups = 1;         // flattened-row kernel: column groups a row strip is cut into (strip index = row strip * cgroups + group)
+    // two-source kernel (wgrad_pair_kernel): XC = XC0 + XC1 channels of the concatenated input, the first XC0 from X, the rest from X1
+    const float* X1 = nullptr;
+    int XC0 = 0;
 };
 
 // one weight-gradient element / one bias partial of a strip leaves the kernel
@@ -49,6 +52,10 @@ struct WgradFlatPlan {
     int strip_rows = 0, cgroups = 0;
 };
 bool wgrad_flat_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan);
+// ... and of the layers whose time is the tensors they read: the k2 s2 transposed convs and the 1x1 logits layer, both concat
+// sources and the bias gradient in ONE pass over dY (a: X / XC0 = first source, X1 / XC - XC0 = second, dB set)
+bool wgrad_pair_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan);
+int wgrad_pair_launch(const WgradArgs& a, const WgradFlatPlan& plan, hipStream_t st);
 int wgrad_flat_launch(const WgradArgs& a, const WgradFlatPlan& plan, hipStream_t st);
 
 }  // namespace pseg

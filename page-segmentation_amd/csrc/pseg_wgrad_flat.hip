@@ -46,6 +46,7 @@ __device__ __forceinline__ void wf_bload(float* dst, __amdgpu_buffer_rsrc_t r, i
         dst[0] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
     }
 }
+__device__ __forceinline__ int itW_x(const WgradArgs& a, int mode) { return mode == 1 ? a.Wx : a.Wy; }
 template <int VW>
 __device__ __forceinline__ void wf_lds_store(float* dst, const float* v) {
     if constexpr (VW == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
@@ -283,6 +284,263 @@ int wgrad_flat_launch(const WgradArgs& a_in, const WgradFlatPlan& plan, hipStrea
     a.cgroups = plan.cgroups;
     const dim3 grid(f.KW / f.KYN, plan.nstrips);
     hipLaunchKernelGGL(f.kernel, grid, dim3(f.NW * 64), 0, st, a);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-source weight gradient of the layers whose time is the tensors they read, not their arithmetic:
+//   MODE 1  Conv2DTranspose k2 s2 (lib/model.py:71,79,83):  dW[ab][ci][co] = sum over input pixels (y, x) of
+//           X[y][x][ci] * dY'[2y + a][2x + b][co]  --  fcn_skip's deconv5 reads a 252 MB dY for 8.8 GFLOP;
+//   MODE 0  the 1x1 logits layer (lib/model.py:85-88):      dW[ci][co] = sum over pixels of X[p][ci] * dY[p][co].
+// The kernels of pseg_train.hip ran one launch per concat source (each re-reading dY) plus, for the transposed convs, a
+// third pass over dY for the bias gradient: 0.35 + 0.35 + 0.33 ms for deconv5 / deconv4 / the logits layer and their biases.
+// Here one launch stages, per input row piece, BOTH sources side by side ([pixel][XC0 + XC1] in LDS) and the dY rows once:
+// rows m = input channel of the concatenated input (the MFMA A operand), columns n = (a, b, co) -- the two output pixels
+// of an input pixel are 2 * CO contiguous floats of a dY row, so the copy is again plain vectors -- or n = co padded to one
+// 16-column tile for the logits layer.  The waves split the (M tile, N tile) grid (WM x WN waves, MW x NTW tiles each); the
+// bias gradient is the column sum of the same B fragments (waves with wm == 0), left as partB[strip * 4 + ab][co].
+// One barrier per step: the next piece's loads are issued before the multiplies and committed to the other LDS buffer after.
+template <int MODE, int XC0, int XC1, int CO, int WM, int WN, int MW, int NTW, int PW>
+__global__ __launch_bounds__(WM * WN * 64) void wgrad_pair_kernel(WgradArgs a) {
+    constexpr int NW = WM * WN, NTHR = NW * 64, XCT = XC0 + XC1;
+    constexpr int NCOLS = MODE == 1 ? 4 * CO : 16;              // MODE 0: CO is the column PITCH of the LDS copy (16), a.Cout the live columns
+    constexpr int YPX = MODE == 1 ? 2 * PW : PW;                // dY pixels per staged row
+    constexpr int YROW = YPX * CO, NYR = MODE == 1 ? 2 : 1;     // floats per staged dY row, rows per step
+    static_assert(WM * MW * 16 >= XCT && WN * NTW * 16 >= NCOLS, "tiles do not fit the waves");
+    static_assert(MODE == 1 || CO == 16, "logits instance: 16-column LDS pitch");
+    constexpr int VX = (XC0 % 4 == 0 && XC1 % 4 == 0) ? 4 : ((XC0 % 2 == 0 && XC1 % 2 == 0) ? 2 : 1);
+    constexpr int VY = MODE == 1 ? (CO % 2 == 0 ? (CO % 4 == 0 ? 4 : 2) : 1) : 1;
+    constexpr int NX0V = PW * XC0 / VX, NX1V = PW * XC1 / VX, NYV = MODE == 1 ? YROW / VY : PW * 16;
+    constexpr int EX0 = (NX0V + NTHR - 1) / NTHR, EX1 = (NX1V + NTHR - 1) / NTHR, EY = (NYV + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) float Xs[2][PW * XCT];
+    __shared__ __attribute__((aligned(16))) float Ys[2][NYR * YROW + 16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p16 = lane & 15, g = lane >> 4;
+    const int wm = wave % WM, wn = wave / WM;
+    const int strip = blockIdx.x, cgi = strip % a.cgroups, rsi = strip / a.cgroups;
+    const int itH = MODE == 1 ? a.Hx : a.Hy, itW = MODE == 1 ? a.Wx : a.Wy;     // the walk is over input pixels (MODE 1) / pixels (MODE 0)
+    const int r0 = rsi * a.strip_rows, nrows = max(0, min(r0 + a.strip_rows, itH) - r0);
+    const int cpr = (itW + PW - 1) / PW, cper = (cpr + a.cgroups - 1) / a.cgroups;
+    const int pc0 = cgi * cper, ncols = max(0, min(pc0 + cper, cpr) - pc0);
+    const int T = nrows * ncols;
+    const int co_live = MODE == 1 ? CO : a.Cout;
+
+    int aoff[MW], boff[NTW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) aoff[i] = g * XCT + min((wm * MW + i) * 16 + p16, XCT - 1);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = min((wn * NTW + j) * 16 + p16, NCOLS - 1);
+        if constexpr (MODE == 1) { const int ar = n / (2 * CO); boff[j] = ar * YROW + (n - ar * 2 * CO) + g * 2 * CO; }
+        else boff[j] = g * 16 + n;
+    }
+    wf_f32x4 acc[MW][NTW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = wf_f32x4{0.f, 0.f, 0.f, 0.f};
+    float bacc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bacc[j] = 0.0f;
+    const bool want_b = a.dB != nullptr && wm == 0;
+    const bool has_mask = a.maskY != nullptr;
+
+    // this thread's vectors of a piece: source byte offset inside the row piece and destination float offset in LDS (-1: none)
+    float x0r[EX0 > 0 ? EX0 : 1][VX], x1r[EX1 > 0 ? EX1 : 1][VX], yr[NYR][EY][VY], ym[NYR][EY][VY];
+    int x0s[EX0 > 0 ? EX0 : 1], x0d[EX0 > 0 ? EX0 : 1], x1s[EX1 > 0 ? EX1 : 1], x1d[EX1 > 0 ? EX1 : 1], ys[EY], yd[EY];
+#pragma unroll
+    for (int u = 0; u < EX0; ++u) {
+        const int v = tid + u * NTHR, e = v * VX, px = e / (XC0 > 0 ? XC0 : 1), c = e - px * XC0;
+        x0s[u] = v < NX0V ? e * 4 : -1;
+        x0d[u] = px * XCT + c;
+    }
+#pragma unroll
+    for (int u = 0; u < EX1; ++u) {
+        const int v = tid + u * NTHR, e = v * VX, px = e / (XC1 > 0 ? XC1 : 1), c = e - px * XC1;
+        x1s[u] = v < NX1V ? e * 4 : -1;
+        x1d[u] = px * XCT + XC0 + c;
+    }
+#pragma unroll
+    for (int u = 0; u < EY; ++u) {
+        const int v = tid + u * NTHR;
+        if constexpr (MODE == 1) { ys[u] = v < NYV ? v * VY * 4 : -1; yd[u] = v * VY; }
+        else { const int px = v >> 4, c = v & 15; ys[u] = (v < NYV && c < co_live) ? (px * co_live + c) * 4 : -1; yd[u] = v; }
+    }
+    if constexpr (MODE == 0) {     // columns >= Cout of the padded copy stay zero
+        for (int i = tid; i < 2 * (YROW + 16); i += NTHR) (&Ys[0][0])[i] = 0.0f;
+    }
+
+    int frow = 0, fcol = 0;
+    auto fetch = [&]() {
+        const int y = r0 + frow, x0 = (pc0 + fcol) * PW;
+        if constexpr (EX0 > 0) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (size_t)y * a.xpitch * XC0), 0, itW_x(a, MODE) * XC0 * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < EX0; ++u) wf_bload<VX>(x0r[u], r, x0s[u] < 0 ? -4 : x0 * XC0 * 4 + x0s[u]);
+        }
+        if constexpr (EX1 > 0) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X1 + (size_t)y * a.xpitch * XC1), 0, itW_x(a, MODE) * XC1 * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < EX1; ++u) wf_bload<VX>(x1r[u], r, x1s[u] < 0 ? -4 : x0 * XC1 * 4 + x1s[u]);
+        }
+#pragma unroll
+        for (int ar = 0; ar < NYR; ++ar) {
+            const int yy = MODE == 1 ? 2 * y + ar : y;
+            const int xb = (MODE == 1 ? 2 * x0 : x0) * co_live * 4;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dY + (size_t)yy * a.ypitch * co_live), 0, a.Wy * co_live * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < EY; ++u) wf_bload<VY>(yr[ar][u], r, ys[u] < 0 ? -4 : xb + ys[u]);
+            if (has_mask) {
+                const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.maskY + (size_t)yy * a.ypitch * co_live), 0, a.Wy * co_live * 4, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < EY; ++u) wf_bload<VY>(ym[ar][u], rm, ys[u] < 0 ? -4 : xb + ys[u]);
+            }
+        }
+        if (++fcol == ncols) { fcol = 0; ++frow; }
+    };
+
+    int buf = 0;
+    if (T > 0) fetch();
+    if constexpr (MODE == 0) __syncthreads();          // the zero fill is done before the first commit
+    for (int it = 0; it < T; ++it) {
+        {
+            float* xd = Xs[buf];
+#pragma unroll
+            for (int u = 0; u < EX0; ++u) if (x0s[u] >= 0) wf_lds_store<VX>(xd + x0d[u], x0r[u]);
+#pragma unroll
+            for (int u = 0; u < EX1; ++u) if (x1s[u] >= 0) wf_lds_store<VX>(xd + x1d[u], x1r[u]);
+#pragma unroll
+            for (int ar = 0; ar < NYR; ++ar) {
+                float* ydst = Ys[buf] + ar * YROW;
+#pragma unroll
+                for (int u = 0; u < EY; ++u)
+                    if (ys[u] >= 0) {
+                        if (has_mask)
+#pragma unroll
+                            for (int k = 0; k < VY; ++k) yr[ar][u][k] = ym[ar][u][k] > 0.0f ? yr[ar][u][k] : 0.0f;
+                        wf_lds_store<VY>(ydst + yd[u], yr[ar][u]);
+                    }
+            }
+        }
+        __syncthreads();
+        if (it + 1 < T) fetch();
+        {
+            const float* xb_ = Xs[buf];
+            const float* yb_ = Ys[buf];
+            constexpr int YQ = MODE == 1 ? 4 * 2 * CO : 4 * 16;      // floats a pixel quad advances the dY copy by
+#pragma unroll 4
+            for (int q = 0; q < PW / 4; ++q) {
+                float xa[MW], yb[NTW];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) yb[j] = yb_[boff[j] + q * YQ];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) xa[i] = xb_[aoff[i] + q * 4 * XCT];
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+                if (want_b)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) bacc[j] += yb[j];
+            }
+        }
+        buf ^= 1;
+    }
+
+    // ---- D tile: lane holds rows 4g .. 4g + 3 (input channel), column p16
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = (wm * MW + i) * 16 + 4 * g + r, n = (wn * NTW + j) * 16 + p16;
+                if (m < XCT && n < (MODE == 1 ? NCOLS : co_live)) {
+                    const int tap = MODE == 1 ? n / CO : 0, co = MODE == 1 ? n - tap * CO : n;
+                    wg_out(a, strip, tap, m, co, acc[i][j][r]);
+                }
+            }
+    if (a.dB != nullptr && wm == 0) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            float v = bacc[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int n = (wn * NTW + j) * 16 + p16;
+            if (g == 0 && n < (MODE == 1 ? NCOLS : co_live)) {
+                if constexpr (MODE == 1) { const int tap = n / CO; wg_out_bias(a, strip, tap, n - tap * CO, v); }
+                else { wg_out_bias(a, strip, 0, n, v); wg_out_bias(a, strip, 1, n, 0.0f); wg_out_bias(a, strip, 2, n, 0.0f); wg_out_bias(a, strip, 3, n, 0.0f); }
+            }
+        }
+    }
+}
+
+struct PairInstance {
+    int mode, XC0, XC1, CO, NW, PW, wg_per_cu;
+    void (*kernel)(WgradArgs);
+};
+#define PSEG_PAIR(MODE_, XC0_, XC1_, CO_, WM_, WN_, MW_, NTW_, PW_, OCC_) \
+    {MODE_, XC0_, XC1_, (MODE_ == 1 ? CO_ : 0), WM_ * WN_, PW_, OCC_, wgrad_pair_kernel<MODE_, XC0_, XC1_, CO_, WM_, WN_, MW_, NTW_, PW_>}
+static const PairInstance g_pair[] = {
+    PSEG_PAIR(1, 30, 40, 20, 1, 5, 5, 1, 32, 3),    // fcn_skip deconv5: [deconv4, conv3] -> 20: 70 rows = 5 tiles, 80 columns = 5 tiles
+    PSEG_PAIR(1, 40, 60, 30, 1, 8, 7, 1, 32, 2),    // fcn_skip deconv4: [deconv3, conv5] -> 30: 100 rows = 7 tiles, 120 columns = 8 tiles
+    PSEG_PAIR(1, 80, 0, 60, 1, 8, 5, 2, 32, 2),     // deconv2: 80 -> 60: 5 x 15 tiles
+    PSEG_PAIR(1, 30, 0, 20, 1, 5, 2, 1, 32, 3),     // fcn deconv5
+    PSEG_PAIR(1, 40, 0, 30, 1, 8, 3, 1, 32, 2),     // fcn deconv4
+    PSEG_PAIR(0, 20, 30, 16, 4, 1, 1, 1, 64, 4),    // fcn_skip logits: [deconv5, conv2] -> classes (<= 16)
+    PSEG_PAIR(0, 20, 0, 16, 2, 1, 1, 1, 64, 4),     // fcn logits
+};
+#undef PSEG_PAIR
+
+bool wgrad_pair_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan) {
+    if (a.stride != 1 || a.xup || a.in_relu || PSEG_KNOB("PSEG_WGRAD_NO_PAIR")) return false;
+    if ((size_t)a.Wx * a.XC * 4 >= (1ull << 31) || (size_t)a.Wy * a.Cout * 4 >= (1ull << 31)) return false;
+    for (int k = 0; k < (int)(sizeof(g_pair) / sizeof(g_pair[0])); ++k) {
+        const PairInstance& f = g_pair[k];
+        if (f.mode != a.mode || f.XC0 != a.XC0 || f.XC1 != a.XC - a.XC0 || (f.XC1 > 0) != (a.X1 != nullptr)) continue;
+        if (f.mode == 1 ? (f.CO != a.Cout || taps != 4 || a.KW != 2) : (a.Cout > 16 || taps != 1 || a.KW != 1 || a.maskY != nullptr)) continue;
+        if (a.Cin != a.XC || a.ci0 != 0) continue;
+        const int itH = a.mode == 1 ? a.Hx : a.Hy, itW = a.mode == 1 ? a.Wx : a.Wy;
+        static int wg_per_cu[sizeof(g_pair) / sizeof(g_pair[0])];
+        if (wg_per_cu[k] == 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)f.kernel, f.NW * 64, 0) != hipSuccess || n < 1) n = f.wg_per_cu;
+            wg_per_cu[k] = n;
+        }
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0, n = 0;
+            ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        }
+        // these layers are bound by the bytes they read: a workgroup per slot of ONE resident round, whole rows per workgroup
+        const int target = ncu * wg_per_cu[k];
+        const int cpr = cdiv(itW, f.PW);
+        // (row strips x column groups) with at most `target` workgroups and the fewest steps for the busiest one
+        int best_cg = 1, best_rows = itH, best_steps = 1 << 30;
+        for (int cg = 1; cg <= cpr; ++cg) {
+            const int cper = cdiv(cpr, cg), cge = cdiv(cpr, cper);
+            const int nrs = std::max(1, std::min(itH, target / cge));
+            const int rows = cdiv(itH, nrs), steps = rows * cper;
+            if (steps < best_steps) { best_steps = steps; best_cg = cge; best_rows = rows; }
+        }
+        const int cgroups = best_cg;
+        plan->instance = k;
+        plan->strip_rows = best_rows;
+        plan->cgroups = cgroups;
+        plan->nstrips = cdiv(itH, plan->strip_rows) * cgroups;
+        return true;
+    }
+    return false;
+}
+
+int wgrad_pair_launch(const WgradArgs& a_in, const WgradFlatPlan& plan, hipStream_t st) {
+    const PairInstance& f = g_pair[plan.instance];
+    WgradArgs a = a_in;
+    a.strip_rows = plan.strip_rows;
+    a.cgroups = plan.cgroups;
+    hipLaunchKernelGGL(f.kernel, dim3(plan.nstrips), dim3(f.NW * 64), 0, st, a);
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
 }

@@ -19,6 +19,14 @@
 
 namespace pseg {
 
+// CT consecutive floats of a wave-uniform row: one batch of wide scalar loads (an index select per element -- "co < Cout ?
+// co : 0" -- made them twenty dependent single loads with a wait each)
+template <int CT>
+__device__ __forceinline__ void ld_row(float (&w)[CT], const float* row) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j) w[j] = row[j];
+}
+
 // ---- first layer: Cin <= 3, k x k, stride 1 ---------------------------------------------------------------------------
 constexpr int FV_TH = 8, FV_TW = 32;      // output tile of a 256-thread workgroup: one pixel per thread
 
@@ -78,10 +86,19 @@ __global__ __launch_bounds__(256) void conv_first_valu_kernel(ConvArgs a) {
                 if (co0 + j < a.Cout) av[j] = ad[j];
         }
     }
+    float bz[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) bz[j] = 0.0f;
+    if (a.bias) {
+        if (whole) ld_row<CT>(bz, a.bias + co0);
+        else {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) bz[j] = a.bias[co0 + j < a.Cout ? co0 + j : 0];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
-        const int co = co0 + j;
-        float t = a.bias ? acc[j] + a.bias[co < a.Cout ? co : 0] : acc[j];
+        float t = a.bias ? acc[j] + bz[j] : acc[j];
         if (ad) t = t + av[j];
         if (a.relu) t = t > 0.0f ? t : 0.0f;
         v[j] = t;
@@ -174,12 +191,19 @@ __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
     const int oy = 2 * i + (ab >> 1), ox = 2 * j0 + (ab & 1);
     const size_t opix = (size_t)oy * (2 * a.Win) + ox;
     float v[CT];
+    {
+        float bz[CT];
+        if (co0 + CT <= a.Cout) ld_row<CT>(bz, a.bias + co0);
+        else {
 #pragma unroll
-    for (int j = 0; j < CT; ++j) {
-        const int co = co0 + j;
-        float t = acc[j] + a.bias[co < a.Cout ? co : 0];
-        if (a.relu) t = t > 0.0f ? t : 0.0f;
-        v[j] = t;
+            for (int j = 0; j < CT; ++j) bz[j] = a.bias[co0 + j < a.Cout ? co0 + j : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            float t = acc[j] + bz[j];
+            if (a.relu) t = t > 0.0f ? t : 0.0f;
+            v[j] = t;
+        }
     }
     if (live) {
         float* o = a.dst + opix * a.Cout + co0;
@@ -219,18 +243,47 @@ __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
         float z[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) z[c] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            const float* wr = a.wl + (size_t)j * a.ncls;
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) z[c] = __builtin_fmaf(v[j], wr[c], z[c]);
-        }
         const float* sp = sks + ((ab >> 1) * 2 * DV_PX + 2 * (live ? lane : 0) + (ab & 1)) * (a.Cs + 1);
-        for (int s0 = 0; s0 < a.Cs; ++s0) {
-            const float sv = sp[s0];
-            const float* wr = a.wl + (size_t)(CT + s0) * a.ncls;
+        if (a.ncls == NCT) {
+            // rows of exactly NCT weights are one contiguous block: the deconv channels' CT rows in one batch of wide scalar
+            // loads, the skip channels five rows per batch (a row per iteration was a scalar-cache round trip per channel)
+            float wl0[CT * NCT];
+            ld_row<CT * NCT>(wl0, a.wl);
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) z[c] = __builtin_fmaf(sv, wr[c], z[c]);
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) z[c] = __builtin_fmaf(v[j], wl0[j * NCT + c], z[c]);
+            constexpr int G = 5;
+            const float* ws = a.wl + (size_t)CT * NCT;
+            int s0 = 0;
+            for (; s0 + G <= a.Cs; s0 += G) {
+                float wg[G * NCT], sv[G];
+                ld_row<G * NCT>(wg, ws + (size_t)s0 * NCT);
+#pragma unroll
+                for (int u = 0; u < G; ++u) sv[u] = sp[s0 + u];
+#pragma unroll
+                for (int u = 0; u < G; ++u)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) z[c] = __builtin_fmaf(sv[u], wg[u * NCT + c], z[c]);
+            }
+            for (; s0 < a.Cs; ++s0) {
+                const float sv = sp[s0];
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) z[c] = __builtin_fmaf(sv, ws[(size_t)s0 * NCT + c], z[c]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const float* wr = a.wl + (size_t)j * a.ncls;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) z[c] = __builtin_fmaf(v[j], wr[c], z[c]);
+            }
+            for (int s0 = 0; s0 < a.Cs; ++s0) {
+                const float sv = sp[s0];
+                const float* wr = a.wl + (size_t)(CT + s0) * a.ncls;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) z[c] = __builtin_fmaf(sv, wr[c], z[c]);
+            }
         }
         int best = 0;
         float bv = z[0] + a.bl[0];

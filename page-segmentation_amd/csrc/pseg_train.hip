@@ -1206,6 +1206,9 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
             t->tgrad[i] = nullptr;
             PSEG_HIP(hipMalloc((void**)&t->tgrad[i], bytes));
             t->tbytes[i] = bytes;
+            // a new buffer starts as NaNs (once, not per step): a region no writer covers then shows in every gradient
+            // test instead of depending on what the allocator hands back
+            PSEG_HIP(hipMemsetAsync(t->tgrad[i], 0xFF, bytes, st));
         }
     }
     auto ensure_wd = [&](size_t floats) -> int {
@@ -1307,6 +1310,8 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.mask = maskd;
                 a.relaxed = PSEG_KNOB("PSEG_TRAIN_STRICT") ? 0 : 1;
                 a.dst = direct ? t->tgrad[src] : t->d_tmp;
+                // (the logits layer writes the page extent only: on a padded canvas the rest of the gradient must be zeros)
+                if (direct && lg && (H != Hx || W != Wx)) PSEG_TRY(zero_if_fresh(src));
                 a.add = (direct && !fresh[src]) ? t->tgrad[src] : nullptr;
                 if (direct) fresh[src] = 0; else PSEG_TRY(zero_if_fresh(src));
                 a.dst_pitch = Wx;

@@ -205,13 +205,17 @@ __global__ __launch_bounds__(NW * 64) void wgrad_flat_kernel(WgradArgs a) {
                     else { const int tl = m / XC; wg_out(a, strip, tap0 + tl, m - tl * XC, co, acc[i][j][r]); }
                 }
             }
-    if (a.dB != nullptr && blockIdx.x == 0 && wave < 4) {
+    if (a.dB != nullptr && blockIdx.x == 0 && wave == 0) {     // (every wave saw every pixel: wave 0 leaves the strip's four bias rows)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float v = bacc[j];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (g == 0 && j * 16 + p16 < CO) wg_out_bias(a, strip, wave, j * 16 + p16, wave == 0 ? v : 0.0f);
+            if (g == 0 && j * 16 + p16 < CO) {
+                wg_out_bias(a, strip, 0, j * 16 + p16, v);
+                if (a.partB)
+                    for (int w = 1; w < 4; ++w) wg_out_bias(a, strip, w, j * 16 + p16, 0.0f);
+            }
         }
     }
 }
@@ -224,6 +228,7 @@ struct FlatInstance {
 };
 #define PSEG_FLAT(XC_, CO_, KW_, KYN_, NW_, MW_, PW_, OCC_) {XC_, CO_, KW_, KYN_, NW_, PW_, OCC_, wgrad_flat_kernel<XC_, CO_, KW_, KYN_, NW_, MW_, PW_>}
 static const FlatInstance g_flat[] = {
+    PSEG_FLAT(1, 20, 5, 5, 2, 1, 64, 8),     // conv1:  25 rows (the taps) = 2 tiles; bound by the 2 x 252 MB of dY and its mask
     PSEG_FLAT(20, 30, 5, 5, 4, 8, 64, 3),    // conv2:  500 rows = 32 tiles
     PSEG_FLAT(30, 40, 5, 5, 8, 6, 32, 2),    // conv3:  750 rows = 47 tiles
     PSEG_FLAT(40, 40, 5, 5, 8, 8, 32, 2),    // conv4: 1000 rows = 63 tiles

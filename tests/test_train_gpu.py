@@ -13,7 +13,10 @@ def _sample(seed, H, W, C):
     return img, mask
 
 
-@pytest.mark.parametrize("arch,C,shape", [("fcn_skip", 3, (64, 96)), ("fcn_skip", 6, (70, 50)), ("fcn", 3, (96, 64)), ("fcn_skip", 24, (64, 64))])
+# (160 x 288 / 144 x 272 -- a page smaller than its canvas: several row pieces per map -- 4.5 at full, 2.25 at quarter resolution -- and row strips cut into column
+# groups: the walk of the flattened-row and two-source weight-gradient kernels beyond a single piece, with ragged right edges)
+@pytest.mark.parametrize("arch,C,shape", [("fcn_skip", 3, (64, 96)), ("fcn_skip", 6, (70, 50)), ("fcn", 3, (96, 64)), ("fcn_skip", 24, (64, 64)),
+                                          ("fcn_skip", 3, (160, 288)), ("fcn", 4, (144, 272))])
 def test_loss_metrics_and_gradients(gpu, oracle_mod, arch, C, shape):
     from oracle.train_ref import fcn_loss_and_grads
     Wt = oracle_mod.init_weights(arch, C, seed=11, gain=1.5, bias_scale=0.05)

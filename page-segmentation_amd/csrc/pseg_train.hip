@@ -845,6 +845,12 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
         }
     } else if (!scalar) {
         variant = V_WIDE;
+        // wide layers sit on small maps and get their parallelism from the 64 x 64 channel blocks and the taps: few strips
+        // (every strip is a full copy of the layer's gradient in the partial-sum buffer -- 19 MB for 512 -> 1024 channels; at one
+        // row per strip the reduction of unet's partials alone took 2 ms of a 25 ms step)
+        const int nblk = cdiv(a.XC, 64) * cdiv(a.Cout, 64);
+        const int want = std::max(1, 2048 / std::max(1, taps * nblk));
+        a.strip_rows = std::max(a.strip_rows, cdiv(itH, want));
     } else {
         variant = V_SCALAR;
     }
@@ -1300,7 +1306,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 const int c0 = sidx == 0 ? 0 : C0, nc = sidx == 0 ? C0 : C1;
                 const bool direct = !up && !op.in_relu;
                 PSEG_TRY(ensure_wd((size_t)k * k * op.Cout * nc));
-                wd_conv_kernel<<<64, 256, 0, st>>>(op.d_w, k, k, op.Cin, op.Cout, c0, nc, t->d_wd);
+                wd_conv_kernel<<<(int)std::min<size_t>(((size_t)k * k * op.Cout * nc + 255) / 256, 2048), 256, 0, st>>>(op.d_w, k, k, op.Cin, op.Cout, c0, nc, t->d_wd);   // (64 blocks took 49 us for unet's 4.7 M-element kernels)
                 if (!direct) PSEG_TRY(ensure_buf((void**)&t->d_tmp, &t->tmp_bytes, (size_t)Hx * Wx * nc * 4));
                 ConvArgs a{};
                 a.src0 = dYd; a.C0 = op.Cout; a.Hin = st_ == 2 ? Hx : Hy; a.Win = st_ == 2 ? Wx : Wy;
@@ -1367,7 +1373,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 const int src = sidx == 0 ? op.src0 : op.src1;
                 const int c0 = sidx == 0 ? 0 : C0, nc = sidx == 0 ? C0 : C1;
                 PSEG_TRY(ensure_wd((size_t)4 * op.Cout * nc));
-                wd_deconv_kernel<<<64, 256, 0, st>>>(op.d_w, op.Cin, op.Cout, c0, nc, t->d_wd);
+                wd_deconv_kernel<<<(int)std::min<size_t>(((size_t)4 * op.Cout * nc + 255) / 256, 2048), 256, 0, st>>>(op.d_w, op.Cin, op.Cout, c0, nc, t->d_wd);
                 // = a k2 stride-2 convolution of the (ReLU-masked) output gradient with wd[ab][co][c],
                 // accumulated in place: the matrix-core kernel when its tile fits, else the scalar one
                 ConvArgs c{};

@@ -13,6 +13,29 @@ def _sample(seed, H, W, C):
     return img, mask
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch,C,shape", [("fcn_skip", 3, (32, 32)), ("fcn_skip", 3, (33, 17)), ("fcn", 2, (24, 200)), ("fcn_skip", 5, (200, 24))])
+def test_gradients_tiny_and_ragged_pages(gpu, oracle_mod, arch, C, shape):
+    """One canvas tile, pages smaller than a row piece, one-piece-wide and one-strip-tall maps: the edge cases of the strip /
+    column-group walk of the weight-gradient kernels and of the first-writer-stores gradient buffers (canvas padding)."""
+    from oracle.train_ref import fcn_loss_and_grads
+    rng = np.random.RandomState(5)
+    Wt = oracle_mod.init_weights(arch, C, seed=11, gain=1.5, bias_scale=0.05)
+    img = rng.randint(0, 256, size=shape).astype(np.uint8)
+    mask = rng.randint(0, C, size=shape).astype(np.uint8)
+    loss_o, _, _, _, g_o = fcn_loss_and_grads(arch, Wt, img, mask)
+    eng = gpu.Engine(arch, C, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    eng.train_init(clipnorm=1.0)
+    for _ in range(2):                                  # twice: the second step runs on used gradient buffers
+        loss = eng.train_forward_backward(img, mask)[0]
+        assert abs(loss - loss_o) <= 1e-4 * abs(loss_o)
+        g = eng.gradients()
+        for k in g_o:
+            assert np.isfinite(g[k]).all(), k
+            assert np.abs(g[k] - g_o[k]).max() <= 2e-3 * np.abs(g_o[k]).max() + 1e-9, k
+
+
 # (160 x 288 / 144 x 272 -- a page smaller than its canvas: several row pieces per map -- 4.5 at full, 2.25 at quarter resolution -- and row strips cut into column
 # groups: the walk of the flattened-row and two-source weight-gradient kernels beyond a single piece, with ragged right edges)
 @pytest.mark.parametrize("arch,C,shape", [("fcn_skip", 3, (64, 96)), ("fcn_skip", 6, (70, 50)), ("fcn", 3, (96, 64)), ("fcn_skip", 24, (64, 64)),

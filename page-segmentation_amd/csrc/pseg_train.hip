@@ -61,6 +61,9 @@ struct TrainState {
     uint8_t* d_img = nullptr;
     size_t logits_bytes = 0, mask_bytes = 0, img_bytes = 0;
     int H = 0, W = 0;
+    // weight gradients run on a stream of their own beside the data gradients (both only read dY; see train_forward_backward)
+    hipStream_t wstream = nullptr;
+    hipEvent_t ev_dy = nullptr, ev_wdone = nullptr;
 };
 
 static TrainState* TS(Engine& e) { return (TrainState*)e.train; }
@@ -74,6 +77,9 @@ void train_free(Engine& e) {
     (void)hipFree(t->d_wd); (void)hipFree(t->d_logits); (void)hipFree(t->d_dlogits);
     (void)hipFree(t->d_wpart); (void)hipFree(t->d_mpart); (void)hipFree(t->d_bpart);
     (void)hipFree(t->d_mask); (void)hipFree(t->d_img); (void)hipFree(t->d_tmp); (void)hipFree(t->d_tmp2);
+    if (t->wstream) { (void)hipStreamSynchronize(t->wstream); (void)hipStreamDestroy(t->wstream); }
+    if (t->ev_dy) (void)hipEventDestroy(t->ev_dy);
+    if (t->ev_wdone) (void)hipEventDestroy(t->ev_wdone);
     delete t;
     e.train = nullptr;
 }
@@ -1222,6 +1228,23 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
     };
     const int strips_target = 1536;
     const bool scalar_wgrad = PSEG_KNOB("PSEG_WGRAD_SCALAR") != nullptr;
+    // Second stream for the weight gradients.  A layer's weight gradient and its data gradient both only READ the layer's output
+    // gradient, and nothing downstream of a weight gradient runs before the optimizer: the weight-gradient kernels (and their
+    // ordered reductions) go to `ws`, gated by an event recorded on the main stream once dY is final; the main stream carries on
+    // with the data gradients and joins at the end.  Two MFMA-bound kernels of 65-85 % pipe-busy each fill each other's gaps.
+    hipStream_t ws = st;
+    if (!PSEG_KNOB("PSEG_TRAIN_ONE_STREAM")) {
+        if (!t->wstream) {
+            PSEG_HIP(hipStreamCreateWithFlags(&t->wstream, hipStreamNonBlocking));
+            PSEG_HIP(hipEventCreateWithFlags(&t->ev_dy, hipEventDisableTiming));
+            PSEG_HIP(hipEventCreateWithFlags(&t->ev_wdone, hipEventDisableTiming));
+        }
+        ws = t->wstream;
+    }
+    auto dy_ready = [&]() -> int {      // everything enqueued on the main stream so far is visible to the next kernel on ws
+        if (ws != st) { PSEG_HIP(hipEventRecord(t->ev_dy, st)); PSEG_HIP(hipStreamWaitEvent(ws, t->ev_dy, 0)); }
+        return PSEG_OK;
+    };
 
     for (int oi = (int)e.ops.size() - 1; oi >= 0; --oi) {
         Op& op = e.ops[oi];
@@ -1267,7 +1290,8 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.KW = k; a.pt = pt; a.pl = pl; a.mode = 0; a.strip_rows = 1; a.dW = gw; a.dB = gb;
                 WgradFlatPlan pp;
                 if (!op.up0 && !op.up1 && st_ == 1 && wgrad_pair_plan(a, k * k, &pp)) {
-                    PSEG_TRY(launch_wgrad(a, dim3(1, k * k), st, &t->d_wpart, &t->wpart_bytes));
+                    PSEG_TRY(dy_ready());
+                    PSEG_TRY(launch_wgrad(a, dim3(1, k * k), ws, &t->d_wpart, &t->wpart_bytes));
                     paired = true;
                 }
             }
@@ -1283,7 +1307,8 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.strip_rows = std::max(1, cdiv(Hy * k * k, strips_target));
                 a.dW = gw; a.dB = sidx == 0 ? gb : nullptr;
                 dim3 grid(cdiv(Hy, a.strip_rows), k * k);
-                PSEG_TRY(launch_wgrad(a, grid, st, &t->d_wpart, &t->wpart_bytes));
+                PSEG_TRY(dy_ready());
+                PSEG_TRY(launch_wgrad(a, grid, ws, &t->d_wpart, &t->wpart_bytes));
             }
             // ---- dgrad into the source gradients (skipped for the network input) ----
             // = a stride-1 convolution of the (ReLU-masked, for stride 2 zero-dilated) output gradient with the flipped
@@ -1346,7 +1371,8 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.KW = 2; a.mode = 1; a.strip_rows = 1; a.dW = gw; a.dB = gb;
                 WgradFlatPlan pp;
                 if (wgrad_pair_plan(a, 4, &pp)) {
-                    PSEG_TRY(launch_wgrad(a, dim3(1, 4), st, &t->d_wpart, &t->wpart_bytes));
+                    PSEG_TRY(dy_ready());
+                    PSEG_TRY(launch_wgrad(a, dim3(1, 4), ws, &t->d_wpart, &t->wpart_bytes));
                     paired = true;
                 }
             }
@@ -1360,13 +1386,15 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 a.strip_rows = std::max(1, cdiv(Hx * 4, strips_target));
                 a.dW = gw; a.dB = nullptr;
                 dim3 grid(cdiv(Hx, a.strip_rows), 4);
-                PSEG_TRY(launch_wgrad(a, grid, st, &t->d_wpart, &t->wpart_bytes));
+                PSEG_TRY(dy_ready());
+                PSEG_TRY(launch_wgrad(a, grid, ws, &t->d_wpart, &t->wpart_bytes));
             }
             if (!paired) {
             if (op.Cout > 256) return fail(PSEG_EUNSUPPORTED, "bias gradient supports at most 256 channels");
             PSEG_TRY(ensure_buf((void**)&t->d_bpart, &t->bpart_bytes, (size_t)BG_BLOCKS * op.Cout * 8));
-            bias_grad_kernel<<<BG_BLOCKS, 256, 0, st>>>(dY, op.relu ? Y : nullptr, (size_t)4 * Hx * Wx, op.Cout, (double*)t->d_bpart);
-            column_sum_kernel<double><<<op.Cout, 256, 0, st>>>((const double*)t->d_bpart, BG_BLOCKS, op.Cout, gb);
+            PSEG_TRY(dy_ready());
+            bias_grad_kernel<<<BG_BLOCKS, 256, 0, ws>>>(dY, op.relu ? Y : nullptr, (size_t)4 * Hx * Wx, op.Cout, (double*)t->d_bpart);
+            column_sum_kernel<double><<<op.Cout, 256, 0, ws>>>((const double*)t->d_bpart, BG_BLOCKS, op.Cout, gb);
             }
             PSEG_HIP(hipGetLastError());
             for (int sidx = 0; sidx < (s1 ? 2 : 1); ++sidx) {
@@ -1408,6 +1436,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
         }
     }
     (void)producer_of;
+    if (ws != st) { PSEG_HIP(hipEventRecord(t->ev_wdone, ws)); PSEG_HIP(hipStreamWaitEvent(st, t->ev_wdone, 0)); }   // the optimizer / all-reduce / readers see every gradient
     return PSEG_OK;
 }
 

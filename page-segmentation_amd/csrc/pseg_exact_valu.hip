@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256) void conv_first_valu_kernel(ConvArgs a) {
                 for (int j = 0; j < CT; ++j) acc[j] = __builtin_fmaf(xv, wr[j], acc[j]);     // (out-of-image x = 0: acc unchanged)
             }
         }
-    if (y >= a.Hout || x >= a.Wout) return;
+    // Whole-pixel outputs without an addend leave through LDS: a lane's CT floats are 80-128 bytes at an 80-128-byte stride, so a
+    // direct store instruction touches 64 cache lines for 16 bytes each; transposed through a per-wave LDS patch the same bytes go
+    // out as fully contiguous 1 KiB store instructions (a wave's two tile rows are two contiguous runs of 32 pixels).
+    const bool lds_store = CT == a.Cout && !a.add && (CT & 1) == 0;
+    if (!lds_store && (y >= a.Hout || x >= a.Wout)) return;
     const size_t opix = (size_t)y * (a.dst_pitch ? a.dst_pitch : a.Wout) + x;
     float* o = a.dst + opix * a.Cout + co0;
     float v[CT];
@@ -103,7 +107,31 @@ __global__ __launch_bounds__(256) void conv_first_valu_kernel(ConvArgs a) {
         if (a.relu) t = t > 0.0f ? t : 0.0f;
         v[j] = t;
     }
-    if (vec4) {
+    if (lds_store) {
+        constexpr int V = (CT & 3) == 0 ? 4 : 2;                  // floats per vector
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        float* ys = xs + ((THH * rowf + 3) & ~3) + wave * (64 * CT);     // this wave's patch: [2 rows x 32 pixels][CT]
+        {
+            float* d = ys + lane * CT;                             // lane = (row & 1) * 32 + lx: the patch is in memory order
+#pragma unroll
+            for (int j = 0; j < CT; j += V) {
+                if (V == 4) *(float4*)(d + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+                else *(float2*)(d + j) = make_float2(v[j], v[j + 1]);
+            }
+        }
+        const int pitch = a.dst_pitch ? a.dst_pitch : a.Wout;
+        constexpr int RV = 32 * CT / V;                            // vectors per tile row
+#pragma unroll
+        for (int u = 0; u < CT / V; ++u) {
+            const int i = lane + 64 * u, rr = i / RV, k = i - rr * RV;
+            const int yy = oy0 + 2 * wave + rr, px = (k * V) / CT;
+            if (yy < a.Hout && ox0 + px < a.Wout) {
+                float* g = a.dst + ((size_t)yy * pitch + ox0) * CT + (size_t)k * V;
+                if (V == 4) *(float4*)g = *(const float4*)(ys + i * 4);
+                else *(float2*)g = *(const float2*)(ys + i * 2);
+            }
+        }
+    } else if (vec4) {
 #pragma unroll
         for (int j = 0; j < CT; j += 4) *(float4*)(o + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
     } else if (vec2) {
@@ -319,9 +347,10 @@ int launch_conv_first_valu(const ConvArgs& a, hipStream_t st) {
         a.out_sy || a.out_sx || a.Cout < 8 || a.Cout > 256)
         return 0;
     const int K = a.KH;
-    const size_t lds = (size_t)(FV_TH + K - 1) * (FV_TW + K - 1) * a.C0 * 4;
+    size_t lds = (size_t)(FV_TH + K - 1) * (FV_TW + K - 1) * a.C0 * 4;
     int CT = (a.Cout == 20 || a.Cout == 16 || a.Cout == 32) ? a.Cout : ((a.Cout & 31) == 0 ? 32 : ((a.Cout % 20) == 0 ? 20 : ((a.Cout % 30) == 0 ? 30 : 16)));
     dim3 grid(cdiv(a.Wout, FV_TW) * cdiv(a.Hout, FV_TH), cdiv(a.Cout, CT));
+    if (CT == a.Cout && !a.add && (CT & 1) == 0) lds = ((lds + 15) & ~(size_t)15) + (size_t)256 * CT * 4;   // the store patches (see the kernel)
     switch (CT) {
         case 16: conv_first_valu_kernel<16><<<grid, 256, lds, st>>>(a); break;
         case 20: conv_first_valu_kernel<20><<<grid, 256, lds, st>>>(a); break;

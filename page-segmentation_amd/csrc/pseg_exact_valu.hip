@@ -233,7 +233,34 @@ __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
             v[j] = t;
         }
     }
-    if (live) {
+    // whole-pixel outputs leave through LDS (as in the first-layer kernel): the two waves of a sub-pixel row interleave their
+    // pixels into one contiguous run of 2 * np pixels in the x tile's place, then every wave stores a contiguous half of a row
+    const bool lds_store = CT == a.Cout && (CT & 1) == 0;
+    if (lds_store) {
+        constexpr int V = (CT & 3) == 0 ? 4 : 2;
+        __syncthreads();                                   // every thread has read its x pixel: the tile's LDS is free
+        {
+            float* d = xs + ((ab >> 1) * 2 * DV_PX + 2 * lane + (ab & 1)) * CT;
+#pragma unroll
+            for (int j = 0; j < CT; j += V) {
+                if (V == 4) *(float4*)(d + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+                else *(float2*)(d + j) = make_float2(v[j], v[j + 1]);
+            }
+        }
+        __syncthreads();
+        const int arow = ab >> 1, half = ab & 1;           // this wave stores pixels [half * DV_PX, + DV_PX) of output row 2i + arow
+        const float* ps = xs + (arow * 2 * DV_PX + half * DV_PX) * CT;
+        float* g = a.dst + ((size_t)(2 * i + arow) * (2 * a.Win) + 2 * jseg + half * DV_PX) * CT;
+        const int nvalid = 2 * np - half * DV_PX;          // pixels of this half that exist
+#pragma unroll
+        for (int u = 0; u < CT / V; ++u) {
+            const int k = lane + 64 * u;                   // vector index inside the half row
+            if ((k * V) / CT < nvalid) {
+                if (V == 4) *(float4*)(g + (size_t)k * 4) = *(const float4*)(ps + k * 4);
+                else *(float2*)(g + (size_t)k * 2) = *(const float2*)(ps + k * 2);
+            }
+        }
+    } else if (live) {
         float* o = a.dst + opix * a.Cout + co0;
         if ((a.Cout & 3) == 0 && (CT & 3) == 0 && co0 + CT <= a.Cout) {
 #pragma unroll
@@ -366,7 +393,11 @@ int launch_deconv2_valu(const TailArgs& a, bool tail, hipStream_t st) {
     if (PSEG_KNOB("PSEG_EXACT_NO_VALU")) return 0;
     const int Cin = a.C0 + a.C1;
     if (Cin < 1 || Cin > 512 || a.Cout < 4 || (size_t)a.Hin * a.Win > 0x3fffffff) return 0;
-    const size_t lds = std::max((size_t)DV_PX * (Cin + 1) * 4, tail ? (size_t)4 * DV_PX * (a.Cs + 1) * 4 : (size_t)0);
+    size_t lds = std::max((size_t)DV_PX * (Cin + 1) * 4, tail ? (size_t)4 * DV_PX * (a.Cs + 1) * 4 : (size_t)0);
+    {   // the store patch of a whole-pixel instance (CT == Cout: 2 rows x 2 * DV_PX pixels x Cout)
+        const int ct = tail ? 20 : ((a.Cout % 30) == 0 ? 30 : ((a.Cout % 20) == 0 ? 20 : ((a.Cout & 31) == 0 ? 32 : 16)));
+        if (ct == a.Cout) lds = std::max(lds, (size_t)4 * DV_PX * a.Cout * 4);
+    }
     static bool attr[64] = {false};
     int dev = 0;
     PSEG_HIP(hipGetDevice(&dev));

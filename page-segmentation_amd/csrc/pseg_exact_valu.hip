@@ -161,6 +161,28 @@ __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
         const int C = srcsel ? a.C1 : a.C0, cbase = srcsel ? a.C0 : 0;
         const float* p = (srcsel ? a.src1 : a.src0) + (size_t)p0 * C;
         const int n = np * C;
+        if ((C & 1) == 0) {
+            // even channel counts: 8-byte loads, one index split per channel PAIR (half the loads and half the vector ALU work of
+            // the 4-byte walk; the two floats of a pair belong to one pixel)
+            const int n2 = n >> 1, C2 = C >> 1;
+            const unsigned long long inv = (1ull << 32) / (unsigned)C2 + 1ull;   // k / C2 exact while k * C2 < 2^32
+            const float2* p2 = (const float2*)p;
+            for (int k0 = 0; k0 < n2; k0 += 256 * 8) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * 256 + (int)threadIdx.x;
+                    v[u] = k < n2 ? p2[k] : make_float2(0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * 256 + (int)threadIdx.x;
+                    const int px = (int)(((unsigned long long)(unsigned)k * inv) >> 32), c = 2 * (k - px * C2);
+                    if (k < n2) { float* d = xs + px * P + cbase + c; d[0] = v[u].x; d[1] = v[u].y; }
+                }
+            }
+            continue;
+        }
         const unsigned long long inv = (1ull << 32) / (unsigned)C + 1ull;    // e / C exact while e * C < 2^32
         for (int e0 = 0; e0 < n; e0 += 256 * 8) {
             float v[8];
@@ -190,6 +212,16 @@ __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
 #pragma unroll
         for (int arow = 0; arow < 2; ++arow) {
             const float* p = a.skip + ((size_t)(2 * i + arow) * (2 * a.Win) + 2 * jseg) * a.Cs;
+            if ((a.Cs & 1) == 0) {                         // even: channel pairs, 8-byte loads (slot u holds pair u * 256 + thread)
+                const float2* p2 = (const float2*)p;
+#pragma unroll
+                for (int u = 0; u < SKR / 2; ++u) {
+                    const int k = u * 256 + (int)threadIdx.x;
+                    const float2 q = (a.Cs > 0 && 2 * k < n) ? p2[k] : make_float2(0.0f, 0.0f);
+                    skv[arow][2 * u] = q.x; skv[arow][2 * u + 1] = q.y;
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < SKR; ++u) {
                 const int e = u * 256 + (int)threadIdx.x;
@@ -283,6 +315,22 @@ __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
             __syncthreads();                             // every thread has read its x pixel: the tile's LDS is free
             const int PS = a.Cs + 1;
             const int n = 2 * np * a.Cs;
+            if (a.Cs > 0 && (a.Cs & 1) == 0) {
+                const int C2 = a.Cs >> 1;
+                const unsigned long long inv2 = (1ull << 32) / (unsigned)C2 + 1ull;
+#pragma unroll
+                for (int u = 0; u < SKR / 2; ++u) {
+                    const int k = u * 256 + (int)threadIdx.x;
+                    const int px = (int)(((unsigned long long)(unsigned)k * inv2) >> 32), c = 2 * (k - px * C2);
+                    if (2 * k < n) {
+#pragma unroll
+                        for (int arow = 0; arow < 2; ++arow) {
+                            float* d = sks + (arow * 2 * DV_PX + px) * PS + c;
+                            d[0] = skv[arow][2 * u]; d[1] = skv[arow][2 * u + 1];
+                        }
+                    }
+                }
+            } else {
             const unsigned long long inv = a.Cs > 0 ? (1ull << 32) / (unsigned)a.Cs + 1ull : 0ull;
 #pragma unroll
             for (int arow = 0; arow < 2; ++arow)
@@ -292,6 +340,7 @@ __global__ __launch_bounds__(256) void deconv2_valu_kernel(TailArgs a) {
                     const int px = (int)(((unsigned long long)(unsigned)e * inv) >> 32), c = e - px * a.Cs;
                     if (e < n) sks[(arow * 2 * DV_PX + px) * PS + c] = skv[arow][u];
                 }
+            }
             __syncthreads();
         }
         const bool inside = live && oy < a.H && ox < a.W;

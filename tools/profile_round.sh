@@ -15,7 +15,11 @@ stats() {   # stats <name> <program args...>
 }
 stats bf16 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra || exit 1
 stats f32 python3 bench.py --mode f32 --steps 10 --warmup 3 --no-cpu-baseline --no-extra || exit 2
+# (one stream for the trace: with the weight gradients on their second stream two kernels share the chip and a kernel's duration is
+# no longer its own cost)
+export PSEG_TRAIN_ONE_STREAM=1
 stats train python3 tools/bench_train.py --height 2048 --width 1536 --steps 6 --warmup 2 || exit 3
+unset PSEG_TRAIN_ONE_STREAM
 stats unet python3 bench.py --arch unet --steps 5 --warmup 2 --no-cpu-baseline --no-extra || exit 4
 stats res_unet python3 bench.py --arch res_unet --steps 5 --warmup 2 --no-cpu-baseline --no-extra || exit 5
 stats config5 python3 tools/bench_config5.py || exit 6

@@ -27,6 +27,7 @@ namespace pseg {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
 
 constexpr int TW = 32;          // output tile width (two 16-pixel MFMA column tiles)
 constexpr int MAX_TAB = 1024;   // k-chunks per channel block (KS*KS*nc + padding)
@@ -997,6 +998,18 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
         const int y = oy0 + wave * (MT / 2) + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
         pixoff[m] = (y < a.Hout && x < a.Wout) ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) : OOBS;
     }
+    // Stores through LDS (plain conv instances).  A direct store instruction carries 16 pixels x 32 bytes: sixteen cache lines
+    // for half a KiB, and switching the epilogue off showed what that costs -- unet's full-resolution layers 339 -> 201 us, the
+    // quarter-resolution layers of fcn_skip 5-12 us each (every workgroup of a one-round kernel stores at the same moment).  The
+    // waves therefore write their packed tiles into an LDS patch laid out like the tensor ([row][pixel][this N block's NT * 32
+    // bytes], pixel pitch + 8 bytes: conflict-free 8-byte writes) -- the input tile and the weight ring are free once every wave
+    // has left the k-loop -- and read it back as 16-byte pieces of consecutive addresses: a store instruction is then 1 KiB of
+    // whole 128-byte lines.  Same bytes, same bounds (descriptor range check).
+    constexpr bool c_lst = FIXED && MODE_ == MODE_CONV && MT == 4 && (FL_ & (FL_ADD | FL_SKIPLOG | FL_LOGITS | FL_DQ | FL_PERSIST | FL_FUSE1)) == 0;
+    constexpr int LST_PP = NT * 32 + 8;                                   // patch bytes per pixel
+    const bool lst = c_lst && !a.dst2 && a.dst_bytes != 0u && !(a.dbg & 32);
+    char* const patch = smem + wave * ((MT / 2) * TW * LST_PP);           // this wave's rows
+    if (lst) lds_barrier();
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = (nb * NT + t) * 16 + 4 * g;
@@ -1028,7 +1041,9 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             const uint2 pk = make_uint2(pk_bf16(v[m][0], v[m][1]),
                                         pk_bf16(v[m][2], v[m][3]));
             if constexpr (c_skiplog) pks[t < 2 ? t : 0][m] = pk;     // consumed by the logits MFMA below instead of memory
-            else {
+            else if (lst) {
+                *(uint2*)(patch + ((m >> 1) * TW + (m & 1) * 16 + p16) * LST_PP + t * 32 + g * 8) = pk;
+            } else {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
                 if (a.dst2) {   // (wave-uniform) the ReLU'd copy the pre-activation readers stage as it is
                     const uint2 pr = make_uint2(relu_pk_bf16(pk.x, 0u), relu_pk_bf16(pk.y, 0u));
@@ -1054,6 +1069,23 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
                                             pk_bf16(q[2], q[3]));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rp, o, 0, 0);
             }
+        }
+    }
+    if (lst) {
+        // read back: piece i = lane + 64 u of this wave's rows = 16 bytes c of pixel px of row r (pieces in address order)
+        constexpr int PPX = NT * 2;                                       // 16-byte pieces per pixel
+        constexpr int NP = (MT / 2) * TW * PPX;                           // pieces of this wave
+        const int nbyte0 = nb * NT * 32;                                  // this N block's first byte inside a pixel
+#pragma unroll
+        for (int u = 0; u < NP / 64; ++u) {
+            const int i = lane + 64 * u;
+            const int px = i / PPX, c = i - px * PPX, r = px / TW, xx = px - r * TW;
+            const char* sp = patch + px * LST_PP + c * 16;
+            const uint2 lo = *(const uint2*)sp, hi = *(const uint2*)(sp + 8);
+            const int y = oy0 + wave * (MT / 2) + r, x = ox0 + xx;
+            const bool ok = y < a.Hout && x < a.Wout && nbyte0 + c * 16 < CsO * 2;
+            const unsigned o = ok ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) + (unsigned)(nbyte0 + c * 16) : OOBS;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_uint4(lo.x, lo.y, hi.x, hi.y)), rd, o, 0, 0);
         }
     }
     if constexpr (c_skiplog) {
@@ -1423,7 +1455,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if constexpr (SKIPLOG) wq = *(const bf16x8*)(a.tail_wa + lane * 8);
     const int CsO = a.nch_out * 8;
     constexpr unsigned OOBS = 0xfffffff0u;
-    typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, a.dst_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)a.pool_dst, 0, a.pool_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(SKIPLOG ? (void*)a.skip_logits : (void*)a.dst), 0,
@@ -3286,6 +3317,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->lds_w_off = round_up(in_bytes, 16);
     P->lds_tab_off = P->lds_w_off + NB * GK * NT * 1024;
     P->lds_bytes = P->lds_tab_off + tab_bytes + 16;
+    if (!deconv && P->MT == 4)   // the epilogue's store patch (plain conv instances) lives in the tile's and the ring's place
+        P->lds_bytes = std::max(P->lds_bytes, P->NW * (P->MT / 2) * TW * (NT * 32 + 8));
     if (op.fuse1 >= 0) {   // two bf16 copies of the (TH+8) x 48 uint8 tile
         P->lds_f1_off = round_up(P->lds_bytes, 16);
         P->lds_bytes = P->lds_f1_off + 2 * (TH + 8) * 96;
@@ -3710,6 +3743,7 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.nb_total = P.nblocks_n;
     a.dbg = PSEG_DIAG_KNOB("PSEG_DBG") ? atoi(PSEG_DIAG_KNOB("PSEG_DBG")) : 0;   // wrong-result ablations: diagnostic build only
     if (PSEG_KNOB("PSEG_INRELU_VGPR")) a.dbg |= 16;
+    if (PSEG_KNOB("PSEG_NO_LDS_STORE")) a.dbg |= 32;   // direct 8-byte stores instead of the LDS patch (same bytes)
 }
 
 int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {

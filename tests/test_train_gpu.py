@@ -36,6 +36,30 @@ def test_gradients_tiny_and_ragged_pages(gpu, oracle_mod, arch, C, shape):
             assert np.abs(g[k] - g_o[k]).max() <= 2e-3 * np.abs(g_o[k]).max() + 1e-9, k
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", ["PSEG_WGRAD_ATOMIC", "PSEG_WGRAD_NO_FLAT", "PSEG_WGRAD_NO_PAIR", "PSEG_TRAIN_ONE_STREAM"])
+def test_gradients_alternative_kernel_paths(gpu, oracle_mod, monkeypatch, knob):
+    """The switches that select the other weight-gradient kernels (float atomics; the round-2 kernels instead of the
+    flattened-row / two-source ones) and the single-stream backward: same gradients within the float bar."""
+    from oracle.train_ref import fcn_loss_and_grads
+    rng = np.random.RandomState(9)
+    shape, C = (72, 104), 3
+    Wt = oracle_mod.init_weights("fcn_skip", C, seed=11, gain=1.5, bias_scale=0.05)
+    img = rng.randint(0, 256, size=shape).astype(np.uint8)
+    mask = rng.randint(0, C, size=shape).astype(np.uint8)
+    loss_o, _, _, _, g_o = fcn_loss_and_grads("fcn_skip", Wt, img, mask)
+    monkeypatch.setenv(knob, "1")                       # an engine keeps the PSEG_* snapshot it is created under
+    eng = gpu.Engine("fcn_skip", C, mode=gpu.MODE_F32_EXACT)
+    monkeypatch.delenv(knob)
+    eng.set_weights(Wt)
+    eng.train_init(clipnorm=1.0)
+    loss = eng.train_forward_backward(img, mask)[0]
+    assert abs(loss - loss_o) <= 1e-4 * abs(loss_o)
+    g = eng.gradients()
+    for k in g_o:
+        assert np.abs(g[k] - g_o[k]).max() <= 2e-3 * np.abs(g_o[k]).max() + 1e-9, (knob, k)
+
+
 # (160 x 288 / 144 x 272 -- a page smaller than its canvas: several row pieces per map -- 4.5 at full, 2.25 at quarter resolution -- and row strips cut into column
 # groups: the walk of the flattened-row and two-source weight-gradient kernels beyond a single piece, with ragged right edges)
 @pytest.mark.parametrize("arch,C,shape", [("fcn_skip", 3, (64, 96)), ("fcn_skip", 6, (70, 50)), ("fcn", 3, (96, 64)), ("fcn_skip", 24, (64, 64)),

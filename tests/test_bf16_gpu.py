@@ -357,6 +357,35 @@ def test_bf16_ping_pong_mid_layer_kernel_is_bit_identical(gpu, monkeypatch, arch
     assert np.abs(res[0][2]).max() > 0
 
 
+@pytest.mark.parametrize("arch,shape", [("fcn_skip", (300, 420)), ("unet", (96, 160)), ("res_unet", (70, 50)), ("fcn", (1056, 1000))])
+def test_bf16_epilogue_store_patch_is_bit_identical(gpu, monkeypatch, arch, shape):
+    """The conv epilogue's stores through LDS (packed tiles written into a patch laid out like the tensor, read back as
+    whole-line 16-byte pieces) against the direct 8-byte stores (PSEG_NO_LDS_STORE): the same bytes -- logits, labels and
+    every stored activation, ragged page edges and channel counts that do not fill their last cout tile included."""
+    from pseg_amd import synth
+    img = synth.synth_page(7, shape[0], shape[1], 3)[0]
+    res = []
+    for knob in (None, "PSEG_NO_LDS_STORE"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        e = gpu.Engine(arch, 3, mode=gpu.MODE_BF16)
+        e.set_weights(synth.glorot_weights(e.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+        z, _, l = e.predict(img, want_probs=False)
+        acts = []
+        for name in dict.fromkeys(spec[0].split('/')[0] for spec in e.weight_specs()):
+            try:
+                acts.append(e.activation(name))
+            except Exception:
+                pass                                     # a tensor the plan fused away
+        res.append([z, l] + acts)
+        e.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    assert len(res[0]) == len(res[1]) and len(res[0]) > 4
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("arch,shape", [("fcn_skip", (256, 320)), ("fcn", (96, 64)), ("fcn_skip", (1024, 768)), ("fcn_skip", (70, 50))])
 def test_bf16_transposed_conv_behind_its_producer(gpu, oracle_mod, monkeypatch, arch, shape):
     """deconv2 (Conv2DTranspose k2 s2) runs on deconv1's accumulators in deconv1's epilogue (FL_DQ): against the engine with the

@@ -225,6 +225,7 @@ struct ConvArgs {
     int dbg;             // MFMA kernel only: timing experiments (PSEG_XM_DBG: 1 no staging loads, 2 no stores, 4 no k-loop) -- wrong results
     float* pool_dst;     // blocked MFMA kernel, 8-row tiles only: also store the 2x2 max-pool of the output ((Hout/2) x (Wout/2) x Cout)
     int relaxed;         // MFMA kernel only: the caller accepts a channel-blocked summation order (train step) for layers whose all-channel tile does not fit LDS
+    const float* wrem = nullptr;   // blocked MFMA kernel, set by its launcher: the left-over output channels' kernel, shifted copies [KH][KW + DX - 1][Cin][16] (conv_xb_kernel REM)
 };
 int launch_conv_exact(const ConvArgs& a, hipStream_t st, bool* pooled = nullptr);   // *pooled: ConvArgs.pool_dst was written by the conv kernel
 // HBM-bound float32 layers on the vector ALU (pseg_exact_valu.hip): first layer; Conv2DTranspose k2 s2, optionally with the

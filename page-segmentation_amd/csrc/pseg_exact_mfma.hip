@@ -330,7 +330,14 @@ constexpr int XCP = XCB + 2;     // LDS pixel pitch in floats
 // registers, four waves per SIMD).  One (tap, four channels) k-step = MT ds_read_b32 + NT global loads for MT x NT MFMAs of
 // 32 cycles each; the k-steps of a slab form ONE software-pipelined stream across taps (the fragments of step q + 1 are
 // requested before the MFMAs of step q; a per-tap pipeline would expose a load latency every four k-steps).
-template <int MT, int NT, int TAILK>
+// REM (0, 4 or 8): output channels left over behind the NT full tiles.  A 16-row tile for 4 or 8 channels multiplies
+// padding (Cout = 40 on three tiles: 17 %, Cout = 20 on two: 37 %).  The left-over rows are instead filled with the same
+// channels of DX = 16 / REM horizontally neighbouring pixels: row (dx, j) of the tile is channel 16 NT + j of pixel
+// DX * p + dx, its columns are pixel groups p, and its kernel is the layer's kernel shifted by dx along kx (zero outside:
+// KW + DX - 1 taps per kernel row; a.wrem, built by wrem_kernel).  Each output still sees its own taps in (slab, ky, kx, ci)
+// order with exact-zero products in between -- the same bits -- and the tile covers DX times the pixels: 6/5 x 1/2 (REM 8)
+// or 8/5 x 1/4 (REM 4) of a padded tile's MFMAs.
+template <int MT, int NT, int TAILK, int REM = 0>
 __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int TWH, unsigned inv_twh) {
     extern __shared__ __attribute__((aligned(16))) float xt[];   // [THH][TWH][XCP]
     constexpr int RW = MT / 2;            // output rows per wave
@@ -370,6 +377,23 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
         voff[t] = n < Ntot ? (unsigned)(ab * Cin * a.Cout + (n - ab * a.Cout) + g * a.Cout) * 4u : 0x7ffffff0u;
     }
     const bool pairs = ((a.C0 | a.C1) & 1) == 0;     // even channel counts: a lane stages two channels with 8-byte accesses
+    // left-over channels (REM): RT tiles per wave over its RW rows -- pixel pairs of one row each (REM 8) or pixel quads of
+    // both rows (REM 4: columns 0-7 the upper row's quads, 8-15 the lower row's)
+    constexpr int DX = REM ? 16 / REM : 1;
+    constexpr int RT = REM == 8 ? RW : (REM == 4 ? RW / 2 : 0);
+    static_assert(REM == 0 || (MT == 4 && (REM == 4 || REM == 8)), "left-over channel tiles: 8-row workgroup tiles only");
+    f32x4 accr[RT ? RT : 1];
+    int xrbase[RT ? RT : 1];
+#pragma unroll
+    for (int rt = 0; rt < (RT ? RT : 1); ++rt) {
+        accr[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int row = REM == 8 ? wave * RW + rt : wave * RW + rt * 2 + (p16 >> 3);
+        const int col = REM == 8 ? 2 * p16 : 4 * (p16 & 7);
+        xrbase[rt] = (row * TWH + col) * XCP + g;
+    }
+    const int KWR = a.KW + DX - 1;
+    const __amdgpu_buffer_rsrc_t wrrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(REM ? a.wrem : a.w), 0, REM ? (unsigned)((size_t)a.KH * KWR * Cin * 16 * 4) : 0u, 0x00020000);
+    const unsigned voffr = (unsigned)(g * 16 + p16) * 4u;
 
     // One slab = stage 16 channels of the halo tile, run every tap over them.  `nks_tag` carries the k-steps per tap as a
     // compile-time constant.  The full slabs run in the loop below (four k-steps per tap); a shorter last slab (TAILK, picked
@@ -570,6 +594,50 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
         };
         run_ksteps(nks_tag);
 
+        // ---- the left-over channels' tile(s): the same walk over KH x (KW + DX - 1) taps of the shifted kernel
+        if constexpr (REM != 0) {
+            constexpr int NKS = decltype(nks_tag)::value;
+            int kxr = 0, toffr = 0;
+            unsigned wsr = (unsigned)(cb * 16) * 4u;
+            const unsigned wstepr = (unsigned)(Cin * 16) * 4u, kstepr = 4u * 16u * 4u;
+            const int ntapr = (PSEG_DIAG && (a.dbg & 4)) ? 0 : a.KH * KWR;
+            float xq[4][RT], wq[4];
+            const float* xpr[RT];
+            auto pointr = [&]() {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) xpr[rt] = xt + xrbase[rt] + toffr;
+            };
+            auto advancer = [&]() {
+                toffr += XCP;
+                wsr += wstepr;
+                if (++kxr == KWR) { kxr = 0; toffr += (TWH - KWR) * XCP; }
+            };
+            auto requestr = [&](int s4, unsigned wo) {
+                wq[s4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrrsrc, voffr, wo + (unsigned)s4 * kstepr, 0));
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) xq[s4][rt] = xpr[rt][4 * s4];
+            };
+            auto mmar = [&](int s4) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) accr[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s4], xq[s4][rt], accr[rt], 0, 0, 0);
+            };
+            if (ntapr > 0) {
+                pointr();
+#pragma unroll
+                for (int s4 = 0; s4 < NKS; ++s4) requestr(s4, wsr);
+                for (int tap = 0; tap + 1 < ntapr; ++tap) {
+                    advancer();
+                    pointr();
+#pragma unroll
+                    for (int s4 = 0; s4 < NKS; ++s4) {
+                        mmar(s4);
+                        requestr(s4, wsr);
+                    }
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < NKS; ++s4) mmar(s4);
+            }
+        }
     };
     const int nfull = (TAILK == 0) ? (Cin + XCB - 1) / XCB : Cin / XCB;     // (TAILK == 0: a last slab of 13..15 channels also takes four k-steps)
     for (int sb = 0; sb < nfull; ++sb) process_slab(sb * XCB, std::integral_constant<int, 4>{});
@@ -630,6 +698,30 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
             }
         }
     }
+    if constexpr (REM != 0) {
+        // left-over channels: lane (p16, g) holds rows 4g .. 4g+3 = channels 16 NT + j0 .. + 3 of pixel DX * column + dx
+        const int dx = (4 * g) / REM, j0 = (4 * g) % REM;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int y = REM == 8 ? oy0 + wave * RW + rt : oy0 + wave * RW + rt * 2 + (p16 >> 3);
+            const int x = REM == 8 ? ox0 + 2 * p16 + dx : ox0 + 4 * (p16 & 7) + dx;
+            if (y >= a.Hout || x >= a.Wout || (PSEG_DIAG && (a.dbg & 2) && accr[rt][0] != 123.456f)) continue;
+            const int n0 = NT * 16 + j0;
+            const size_t off0 = ((size_t)y * pitch + (size_t)x) * a.Cout + n0;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = a.bias ? accr[rt][r] + a.bias[n0 + r] : accr[rt][r];
+            if (a.add) {
+                const float4 ad = *(const float4*)(a.add + off0);
+                v[0] = v[0] + ad.x; v[1] = v[1] + ad.y; v[2] = v[2] + ad.z; v[3] = v[3] + ad.w;
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+            }
+            *(float4*)(a.dst + off0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
     // ---- fused MaxPooling2D 2x2 (lib/model.py:54,59,64) of the tensor just stored: a wave holds both rows of its pixel
     // pairs (accumulator tiles m and m + 2), the horizontal neighbour sits in lane p16 ^ 1.  The same comparisons in the same
     // order as pool_exact_kernel -- (x, x+1) of the upper row, of the lower row, then the two winners -- so the same bits
@@ -676,18 +768,31 @@ __global__ __launch_bounds__(256) void conv_xb_kernel(ConvArgs a, int THH, int T
     }
 }
 
-template <int MT, int NT, int TAILK>
+template <int MT, int NT, int TAILK, int REM = 0>
 static int launch_xb(const ConvArgs& a, int THH, int TWH, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     PSEG_HIP(hipGetDevice(&dev));
     if (!attr_set[dev & 63]) {
-        PSEG_HIP(hipFuncSetAttribute((const void*)conv_xb_kernel<MT, NT, TAILK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PSEG_HIP(hipFuncSetAttribute((const void*)conv_xb_kernel<MT, NT, TAILK, REM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[dev & 63] = true;
     }
-    conv_xb_kernel<MT, NT, TAILK><<<grid, 256, lds, st>>>(a, THH, TWH, (1u << 20) / (unsigned)TWH + 1u);
+    conv_xb_kernel<MT, NT, TAILK, REM><<<grid, 256, lds, st>>>(a, THH, TWH, (1u << 20) / (unsigned)TWH + 1u);
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
+}
+
+// wr[ky][kxp][ci][dx * rem + j] = w[ky][kxp - dx][ci][cmain + j] (0 when kxp - dx is not a tap): the left-over channels'
+// kernel as DX shifted copies, one per pixel of the group a tile column stands for (see conv_xb_kernel, REM)
+__global__ void wrem_kernel(const float* w, int KH, int KW, int Cin, int Cout, int cmain, int rem, float* wr) {
+    const int dxn = 16 / rem, KWR = KW + dxn - 1;
+    const int n = KH * KWR * Cin * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int row = i & 15, ci = (i >> 4) % Cin, t = (i >> 4) / Cin;
+        const int kxp = t % KWR, ky = t / KWR;
+        const int dx = row / rem, j = row - dx * rem, kx = kxp - dx;
+        wr[i] = (kx >= 0 && kx < KW) ? w[((size_t)(ky * KW + kx) * Cin + ci) * Cout + cmain + j] : 0.0f;
+    }
 }
 
 template <int MT, int NT, bool FLAT>
@@ -761,6 +866,36 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     dim3 grid(tiles, nblk);
     const int tail_ch = Cin % XCB;                              // channels of the last slab (0: a full one)
     const int tailk = (tail_ch == 0 || tail_ch > 12) ? 0 : (tail_ch + 3) / 4;
+    // left-over output channels (Cout = 16 k + 4 or + 8) as shifted-pixel tiles instead of a padded cout tile
+    {
+        const int rem = a.Cout % 16, ntm = a.Cout / 16;
+        if ((rem == 4 || rem == 8) && (ntm == 1 || ntm == 2) && MT == 4 && !a.deconv4 && a.stride == 1 && !a.out_sy && !a.out_sx && (tiles >= 512 || PSEG_KNOB("PSEG_EXACT_REM_ANY")) &&
+            !PSEG_KNOB("PSEG_EXACT_NO_REM") && !PSEG_KNOB("PSEG_EXACT_NT")) {
+            const int dxn = 16 / rem;
+            const size_t wbytes = (size_t)a.KH * (a.KW + dxn - 1) * Cin * 16 * 4;
+            float* wr = nullptr;
+            PSEG_HIP(hipMallocAsync((void**)&wr, wbytes, st));
+            wrem_kernel<<<(int)std::min<size_t>((wbytes / 4 + 255) / 256, 1024), 256, 0, st>>>(a.w, a.KH, a.KW, Cin, a.Cout, ntm * 16, rem, wr);
+            a.wrem = wr;
+            a.pool_dst = nullptr;                               // (the caller pools: return code 1)
+            const dim3 g1(tiles, 1);
+            int rc = PSEG_OK;
+#define PSEG_XR(NT_, REM_)                                                                        \
+            if (ntm == NT_ && rem == REM_) {                                                          \
+                switch (tailk) {                                                                      \
+                    case 0: rc = launch_xb<4, NT_, 0, REM_>(a, THH, TWH, g1, lds, st); break;         \
+                    case 1: rc = launch_xb<4, NT_, 1, REM_>(a, THH, TWH, g1, lds, st); break;         \
+                    case 2: rc = launch_xb<4, NT_, 2, REM_>(a, THH, TWH, g1, lds, st); break;         \
+                    default: rc = launch_xb<4, NT_, 3, REM_>(a, THH, TWH, g1, lds, st); break;        \
+                }                                                                                     \
+            }
+            PSEG_XR(1, 4) PSEG_XR(2, 8) PSEG_XR(1, 8) PSEG_XR(2, 4)
+#undef PSEG_XR
+            PSEG_HIP(hipFreeAsync(wr, st));
+            if (rc != PSEG_OK) return rc;
+            return 1;
+        }
+    }
 #define PSEG_XB(MT_, NT_)                                                                        \
     if (MT == MT_ && NT == NT_) {                                                                \
         switch (tailk) {                                                                         \

@@ -52,6 +52,28 @@ def test_exact_mode_layer_activations(gpu, oracle_mod):
     eng.close()
 
 
+@pytest.mark.parametrize("arch", ["fcn_skip", "fcn"])
+def test_exact_mode_leftover_channel_tiles(gpu, oracle_mod, monkeypatch, arch):
+    """Cout = 40 / 20 layers on the shifted-pixel tiles (conv_xb_kernel REM: the 8 / 4 channels behind the full cout tiles share
+    a 16-row tile with the same channels of the neighbouring pixels).  Pages of a few tiles take the padded tile by default;
+    PSEG_EXACT_REM_ANY sends them through the new form: logits and every activation bit-identical to the oracle, ragged pages
+    included (pixel pairs / quads that straddle the right edge)."""
+    rng = np.random.default_rng(11)
+    Wt = oracle_mod.init_weights(arch, 3, seed=5, gain=1.5, bias_scale=0.05)
+    monkeypatch.setenv("PSEG_EXACT_REM_ANY", "1")
+    eng = gpu.Engine(arch, 3, mode=gpu.MODE_F32_EXACT)
+    monkeypatch.delenv("PSEG_EXACT_REM_ANY")
+    eng.set_weights(Wt)
+    for (H, W) in [(70, 50), (64, 96), (33, 1), (1, 37), (130, 67)]:
+        img = _page(rng, H, W)
+        z_o, acts = oracle_mod.forward(arch, Wt, img, "f32", return_acts=True)
+        z = eng.predict(img)[0]
+        assert np.array_equal(z, z_o), (H, W)
+        for name in ("conv2d_2", "conv2d_3", "conv2d_transpose_2"):
+            assert np.array_equal(eng.activation(name), acts[name]), (H, W, name)
+    eng.close()
+
+
 def test_predict_errors(gpu, oracle_mod):
     eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_F32_EXACT)
     with pytest.raises(gpu.PsegError):      # weights never set

@@ -37,10 +37,11 @@ def test_gradients_tiny_and_ragged_pages(gpu, oracle_mod, arch, C, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob", ["PSEG_WGRAD_ATOMIC", "PSEG_WGRAD_NO_FLAT", "PSEG_WGRAD_NO_PAIR", "PSEG_TRAIN_ONE_STREAM"])
+@pytest.mark.parametrize("knob", ["PSEG_WGRAD_ATOMIC", "PSEG_WGRAD_NO_FLAT", "PSEG_WGRAD_NO_PAIR", "PSEG_TRAIN_ONE_STREAM", "PSEG_EXACT_REM_ANY", "PSEG_EXACT_NO_REM"])
 def test_gradients_alternative_kernel_paths(gpu, oracle_mod, monkeypatch, knob):
     """The switches that select the other weight-gradient kernels (float atomics; the round-2 kernels instead of the
-    flattened-row / two-source ones) and the single-stream backward: same gradients within the float bar."""
+    flattened-row / two-source ones), the single-stream backward, and the shifted-pixel tiles of the data-gradient convs forced
+    on / off: same gradients within the float bar."""
     from oracle.train_ref import fcn_loss_and_grads
     rng = np.random.RandomState(9)
     shape, C = (72, 104), 3

@@ -874,6 +874,19 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
             const int dxn = 16 / rem;
             const size_t wbytes = (size_t)a.KH * (a.KW + dxn - 1) * Cin * 16 * 4;
             float* wr = nullptr;
+            {   // stream-ordered scratch; the device's default pool keeps what it is given back (no OS round trip per layer)
+                static bool pool_set[64] = {false};
+                int dev = 0;
+                PSEG_HIP(hipGetDevice(&dev));
+                if (!pool_set[dev & 63]) {
+                    hipMemPool_t mp = nullptr;
+                    if (hipDeviceGetDefaultMemPool(&mp, dev) == hipSuccess && mp) {
+                        uint64_t keep = ~0ull;
+                        (void)hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &keep);
+                    }
+                    pool_set[dev & 63] = true;
+                }
+            }
             PSEG_HIP(hipMallocAsync((void**)&wr, wbytes, st));
             wrem_kernel<<<(int)std::min<size_t>((wbytes / 4 + 255) / 256, 1024), 256, 0, st>>>(a.w, a.KH, a.KW, Cin, a.Cout, ntm * 16, rem, wr);
             a.wrem = wr;

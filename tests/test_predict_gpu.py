@@ -74,6 +74,23 @@ def test_exact_mode_leftover_channel_tiles(gpu, oracle_mod, monkeypatch, arch):
     eng.close()
 
 
+def test_exact_mode_full_size_page_bit_identical(gpu, oracle_mod):
+    """configs[1]'s page size on the float32 engine against the oracle, bit for bit: at 2048x1536 every layer takes its
+    full-size plan (8-row tiles, unsplit cout blocks, the left-over channel tiles of conv3 / conv4 / deconv3 by default)."""
+    rng = np.random.default_rng(21)
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=9, gain=1.5, bias_scale=0.05)
+    img = _page(rng, 2048, 1536)
+    z_o, acts = oracle_mod.forward("fcn_skip", Wt, img, "f32", return_acts=True)
+    eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_F32_EXACT)
+    eng.set_weights(Wt)
+    z, _, pred = eng.predict(img, want_probs=False)
+    assert np.array_equal(z, z_o)
+    assert np.array_equal(pred, np.argmax(z_o, -1))
+    for name in ("conv2d_1", "conv2d_2", "conv2d_3", "conv2d_6", "conv2d_transpose_2"):
+        assert np.array_equal(eng.activation(name), acts[name]), name
+    eng.close()
+
+
 def test_predict_errors(gpu, oracle_mod):
     eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_F32_EXACT)
     with pytest.raises(gpu.PsegError):      # weights never set

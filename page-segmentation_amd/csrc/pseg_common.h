@@ -123,6 +123,9 @@ struct Op {
     // device weights
     float* d_w = nullptr;     // f32 correlation form [KH][KW][Cin][Cout] (+slack) / [2][2][Cin][Cout]; OP_BN: [gamma|beta|mean|var][C]
     float* d_b = nullptr;     // f32 bias; OP_BN: [batch mean | 1/sqrt(var+eps)][C] of the last training forward, then 4*C doubles of reduction scratch
+    float* d_wrem = nullptr;  // f32 mode: the left-over output channels' kernel as shifted copies (conv_xb_kernel REM), owned by the op,
+    size_t wrem_bytes = 0;    //   sized at upload_weights, rebuilt by the launcher whenever wrem_valid is false (weights changed)
+    bool wrem_valid = false;
     void* plan = nullptr;     // bf16 mode: MfmaPlan (pseg_mfma.hip), owned by the op
     bool fused_away = false;  // bf16 mode: op folded into a neighbour (pool -> conv epilogue, logits -> deconv tail)
     int fuse1 = -1;           // bf16 mode: OP_CONV that recomputes this first-layer op on its halo tile
@@ -226,7 +229,12 @@ struct ConvArgs {
     float* pool_dst;     // blocked MFMA kernel, 8-row tiles only: also store the 2x2 max-pool of the output ((Hout/2) x (Wout/2) x Cout)
     int relaxed;         // MFMA kernel only: the caller accepts a channel-blocked summation order (train step) for layers whose all-channel tile does not fit LDS
     const float* wrem = nullptr;   // blocked MFMA kernel, set by its launcher: the left-over output channels' kernel, shifted copies [KH][KW + DX - 1][Cin][16] (conv_xb_kernel REM)
+    float* wrem_buf = nullptr;     // caller-owned buffer for that kernel (wrem_bytes_for() bytes; null or too small: padded cout tiles instead)
+    size_t wrem_cap = 0;
+    bool* wrem_valid = nullptr;    // null: rebuild on every launch (scratch weights); else rebuilt when *wrem_valid is false, then set
 };
+// bytes of ConvArgs.wrem_buf a KH x KW, Cin -> Cout stride-1 layer needs for its left-over channel tile, 0 when it has none
+size_t wrem_bytes_for(int KH, int KW, int Cin, int Cout);
 int launch_conv_exact(const ConvArgs& a, hipStream_t st, bool* pooled = nullptr);   // *pooled: ConvArgs.pool_dst was written by the conv kernel
 // HBM-bound float32 layers on the vector ALU (pseg_exact_valu.hip): first layer; Conv2DTranspose k2 s2, optionally with the
 // logits layer + argmax behind it.  1 = launched, 0 = not a layer for these kernels, < 0 error.

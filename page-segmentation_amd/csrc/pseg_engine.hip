@@ -500,6 +500,15 @@ int upload_weights(Engine& e) {
         PSEG_HIP(hipMalloc((void**)&op.d_b, (size_t)round_up(Cout, COT) * sizeof(float)));
         PSEG_HIP(hipMemset(op.d_b, 0, (size_t)round_up(Cout, COT) * sizeof(float)));
         PSEG_HIP(hipMemcpy(op.d_b, bp.host.data(), (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
+        // float32 engine: room for the left-over output channels' shifted kernel copies (conv_xb_kernel REM), rebuilt by the
+        // launcher on the first launch after every weight change
+        op.wrem_valid = false;
+        const size_t wrb = (e.mode != PSEG_MODE_BF16 && op.type == OP_CONV && op.stride == 1) ? wrem_bytes_for(k, k, Cin, Cout) : 0;
+        if (wrb != op.wrem_bytes) {
+            free_dev((void*&)op.d_wrem);
+            op.wrem_bytes = 0;
+            if (wrb) { PSEG_HIP(hipMalloc((void**)&op.d_wrem, wrb)); op.wrem_bytes = wrb; }
+        }
         if (e.mode == PSEG_MODE_BF16) PSEG_TRY(mfma_pack_op(e, op, w, bp.host));
     }
     // copies from pageable memory may still be in their final DMA when hipMemcpy returns, and the null stream is
@@ -610,6 +619,7 @@ int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
             a.relu = op.relu;
             a.Cout = op.Cout;
             a.relaxed = e.relaxed_f32;
+            a.wrem_buf = op.d_wrem; a.wrem_cap = op.wrem_bytes; a.wrem_valid = &op.wrem_valid;
             if (op.type == OP_LOGITS) {
                 // crop (lib/model.py:29-42) folded into the output extent
                 a.Hout = e.H;
@@ -1070,6 +1080,7 @@ int pseg_destroy(pseg_engine* h) {
     for (auto& op : e.ops) {
         free_dev((void*&)op.d_w);
         free_dev((void*&)op.d_b);
+        free_dev((void*&)op.d_wrem);
         mfma_free_op(op);
     }
     free_dev((void*&)e.d_lut);

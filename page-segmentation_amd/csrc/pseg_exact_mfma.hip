@@ -795,6 +795,12 @@ __global__ void wrem_kernel(const float* w, int KH, int KW, int Cin, int Cout, i
     }
 }
 
+size_t wrem_bytes_for(int KH, int KW, int Cin, int Cout) {
+    const int rem = Cout % 16, ntm = Cout / 16;
+    if (!((rem == 4 || rem == 8) && (ntm == 1 || ntm == 2))) return 0;
+    return (size_t)KH * (KW + 16 / rem - 1) * Cin * 16 * 4;
+}
+
 template <int MT, int NT, bool FLAT>
 static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, int CB, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_set[64] = {false};
@@ -870,25 +876,16 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     {
         const int rem = a.Cout % 16, ntm = a.Cout / 16;
         if ((rem == 4 || rem == 8) && (ntm == 1 || ntm == 2) && MT == 4 && !a.deconv4 && a.stride == 1 && !a.out_sy && !a.out_sx && (tiles >= 512 || PSEG_KNOB("PSEG_EXACT_REM_ANY")) &&
-            !PSEG_KNOB("PSEG_EXACT_NO_REM") && !PSEG_KNOB("PSEG_EXACT_NT")) {
-            const int dxn = 16 / rem;
-            const size_t wbytes = (size_t)a.KH * (a.KW + dxn - 1) * Cin * 16 * 4;
-            float* wr = nullptr;
-            {   // stream-ordered scratch; the device's default pool keeps what it is given back (no OS round trip per layer)
-                static bool pool_set[64] = {false};
-                int dev = 0;
-                PSEG_HIP(hipGetDevice(&dev));
-                if (!pool_set[dev & 63]) {
-                    hipMemPool_t mp = nullptr;
-                    if (hipDeviceGetDefaultMemPool(&mp, dev) == hipSuccess && mp) {
-                        uint64_t keep = ~0ull;
-                        (void)hipMemPoolSetAttribute(mp, hipMemPoolAttrReleaseThreshold, &keep);
-                    }
-                    pool_set[dev & 63] = true;
-                }
+            !PSEG_KNOB("PSEG_EXACT_NO_REM") && !PSEG_KNOB("PSEG_EXACT_NT") && a.wrem_buf && a.wrem_cap >= wrem_bytes_for(a.KH, a.KW, Cin, a.Cout)) {
+            const size_t wbytes = wrem_bytes_for(a.KH, a.KW, Cin, a.Cout);
+            // the shifted copies live in a buffer of the caller's (the op's, beside its kernel; the train step's scratch for the
+            // flipped kernels of the data gradients) and are rebuilt only when the weights behind them changed -- no allocation,
+            // no pool, nothing but kernels on `st`
+            float* const wr = a.wrem_buf;
+            if (!a.wrem_valid || !*a.wrem_valid) {
+                wrem_kernel<<<(int)std::min<size_t>((wbytes / 4 + 255) / 256, 1024), 256, 0, st>>>(a.w, a.KH, a.KW, Cin, a.Cout, ntm * 16, rem, wr);
+                if (a.wrem_valid) *a.wrem_valid = true;
             }
-            PSEG_HIP(hipMallocAsync((void**)&wr, wbytes, st));
-            wrem_kernel<<<(int)std::min<size_t>((wbytes / 4 + 255) / 256, 1024), 256, 0, st>>>(a.w, a.KH, a.KW, Cin, a.Cout, ntm * 16, rem, wr);
             a.wrem = wr;
             a.pool_dst = nullptr;                               // (the caller pools: return code 1)
             const dim3 g1(tiles, 1);
@@ -904,7 +901,6 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
             }
             PSEG_XR(1, 4) PSEG_XR(2, 8) PSEG_XR(1, 8) PSEG_XR(2, 4)
 #undef PSEG_XR
-            PSEG_HIP(hipFreeAsync(wr, st));
             if (rc != PSEG_OK) return rc;
             return 1;
         }

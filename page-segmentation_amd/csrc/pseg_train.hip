@@ -44,6 +44,8 @@ struct TrainState {
     std::vector<size_t> tbytes;
     float* d_wd = nullptr;       // scratch: transformed weights for dgrad
     size_t wd_bytes = 0;
+    float* d_wdrem = nullptr;    // scratch: the left-over output channels of those weights as shifted copies (conv_xb_kernel REM), rebuilt per launch
+    size_t wdrem_bytes = 0;
     float* d_wpart = nullptr;    // scratch: per-strip partial weight / bias gradients of the layer being reduced (deterministic sums)
     size_t wpart_bytes = 0;
     float* d_mpart = nullptr;    // scratch: per-block partial loss / metric sums
@@ -74,7 +76,7 @@ void train_free(Engine& e) {
     (void)hipFree(t->d_grad); (void)hipFree(t->d_m); (void)hipFree(t->d_v); (void)hipFree(t->d_norm);
     (void)hipFree(t->d_part); (void)hipFree(t->d_slice_nblk); (void)hipFree(t->d_slice_pi);
     for (auto p : t->tgrad) (void)hipFree(p);
-    (void)hipFree(t->d_wd); (void)hipFree(t->d_logits); (void)hipFree(t->d_dlogits);
+    (void)hipFree(t->d_wd); (void)hipFree(t->d_wdrem); (void)hipFree(t->d_logits); (void)hipFree(t->d_dlogits);
     (void)hipFree(t->d_wpart); (void)hipFree(t->d_mpart); (void)hipFree(t->d_bpart);
     (void)hipFree(t->d_mask); (void)hipFree(t->d_img); (void)hipFree(t->d_tmp); (void)hipFree(t->d_tmp2);
     if (t->wstream) { (void)hipStreamSynchronize(t->wstream); (void)hipStreamDestroy(t->wstream); }
@@ -1336,6 +1338,10 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
                 ConvArgs a{};
                 a.src0 = dYd; a.C0 = op.Cout; a.Hin = st_ == 2 ? Hx : Hy; a.Win = st_ == 2 ? Wx : Wy;
                 a.w = t->d_wd; a.bias = nullptr; a.KH = a.KW = k; a.stride = 1;
+                if (const size_t wrb = wrem_bytes_for(k, k, op.Cout, nc)) {   // (the scratch kernel changes with every layer: no validity flag)
+                    PSEG_TRY(ensure_buf((void**)&t->d_wdrem, &t->wdrem_bytes, wrb));
+                    a.wrem_buf = t->d_wdrem; a.wrem_cap = t->wdrem_bytes;
+                }
                 a.pt = k - 1 - pt; a.pl = k - 1 - pl;
                 a.Hout = lg ? H : Hx; a.Wout = lg ? W : Wx; a.Cout = nc;
                 a.mask = maskd;
@@ -1544,6 +1550,7 @@ static int train_apply(Engine& e, float lr, float gscale) {
         }
         if (pass == 0) sumsq_final_kernel<<<t->nslices, 256, 0, st>>>(t->d_part, t->d_slice_nblk, t->d_slice_pi, t->d_norm);
     }
+    for (auto& op : e.ops) op.wrem_valid = false;   // the kernels changed: the float32 convs rebuild their left-over channel copies
     PSEG_HIP(hipGetLastError());
     return PSEG_OK;
 }

@@ -2691,6 +2691,540 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k5 stride-1 layers whose weight set does NOT fit LDS (fcn / fcn_skip: conv5, conv6, conv7, deconv1 (+ deconv2), deconv3):
+// STREAMED weights, PERSISTENT workgroups, dedicated LOADER waves -- conv_sp_kernel.
+// In conv_mfma_kernel every wave of a workgroup does everything in turn: issue the tile DMA, issue a weight group, wait,
+// s_barrier, a few k-steps, again -- s_memtime stamps of the 1/8-resolution layers (2048x1536, one 8 x 32 tile per CU): 54 k
+// cycles per workgroup for 16 k cycles of matrix work; 7 k of them ISSUING weight DMAs from the compute waves, 5 k in group
+// waits, a drained software pipeline at each of the 14 group barriers, the tile re-staged per channel block, a serial
+// prologue (8.5 k) and epilogue (6 k; 20 k where the k2 s2 transposed conv follows on the accumulators, its A fragments
+// fetched from L2 one group ahead).  The fill rate is NOT the limit: four waves with four requests in flight each stream
+// the shared 256 KB weight set at 55 B/clk/CU (tools/microtests/lds_dma_ring.hip; the chip's L2 gives 24 TB/s).
+// Here ONE 512-thread workgroup per CU owns all 160 KB of LDS and splits the roles:
+//   * waves 0-3 (one per SIMD) COMPUTE: one flat, continuously software-pipelined k-loop over all channel blocks of a tile
+//     (no barrier, no wait, no DMA instruction inside), then the epilogue, then the next tile of the workgroup;
+//   * waves 4-5 stream the packed weights through a ring of RK k-steps (NT KiB each), as far ahead as the ring allows;
+//   * waves 6-7 stage the halo tiles, one channel block per LDS slot (all blocks of a tile resident at once; the next
+//     tile's block b lands while the current tile is past its own block b).
+// There is no s_barrier after set-up.  Loaders and compute waves meet through monotone counters in LDS: `ready` / `tready`
+// (weight groups / tile blocks landed: written by a loader after its counted s_waitcnt vmcnt), `done` / `tdone` (groups /
+// blocks a compute wave has finished reading).  A compute wave reads the loaders' counters at the START of a k-step's
+// region and looks at the value at its END (the LDS latency hides under the MFMAs); only a late loader sends it into a
+// polling loop.  Every polling loop is bounded (SP_SPIN_LIMIT polls, then it gives up, records the fact in SConv::err and
+// goes on with whatever is in LDS): a protocol bug produces wrong numbers, not a hung GPU.
+// Same products in the same k order with the same start value (bias) as conv_mfma_kernel on the dense tile: the same bits.
+// The Conv2DTranspose k2 s2 behind deconv1 (FL_DQ) takes its 48 A fragments from the SAME ring (they follow the conv's
+// k-steps in the packed stream), so its epilogue never waits for L2.
+// A tile index carries the page: tile t -> page t / tiles_per_page -- a launch covers all pages of a batch (pseg_predict_batch).
+// ---------------------------------------------------------------------------------------------
+struct SConv {
+    const uint16_t* src0; const uint16_t* src1;
+    int nch0, nch1;                  // 16-byte chunks per pixel of the two (concatenated) sources
+    unsigned bytes0, bytes1;         // bytes of ONE page of each source
+    int Hin, Win, Hout, Wout, pt, pl, relu;
+    int nblk, nc_full, nc_last;      // channel blocks of the tile: nblk slots of TBLK bytes, nc chunks each
+    int K;                           // conv k-steps per tile (all blocks; even)
+    int S;                           // steps of the weight stream per tile: K (+ the transposed conv's pseudo-steps), a multiple of SP_GK
+    int blk_steps;                   // k-steps per full channel block
+    const int* tab;                  // [K * 4] byte offsets of the k-chunks inside the tile region (block slot included)
+    const uint16_t* wpk;             // [S][NT][64][8] bf16
+    const float* bias;               // [NT * 16]
+    int row_pitch, TBLK, RK;         // LDS: tile row pitch, bytes of a block slot, ring capacity in steps
+    int lds_ring_off, lds_patch_off, lds_tab_off, lds_flag_off;
+    uint16_t* dst; unsigned dst_bytes; int nch_out;          // dst_bytes: ONE page (0: the tensor is not stored)
+    uint16_t* pool_dst; unsigned pool_bytes;
+    const float* dq_bias; uint16_t* dq_dst; unsigned dq_bytes; int dq_nch, dq_relu;
+    int ntiles, tiles_per_page, xq, xr;
+    int* err;                        // != 0 after a polling loop gave up (device int, zeroed by the host at plan time)
+    unsigned long long* trace;       // PSEG_SP_TRACE=<layer>: 16 s_memtime stamps per workgroup, or null
+    int dbg;                         // diagnostic build only (PSEG_SP_DBG, wrong results, timing only): 1 no weight DMA, 2 no tile DMA, 4 loaders poll slowly
+};
+enum { SP_POOL = 1, SP_DQ = 2, SP_PATCH = 4 };
+constexpr int SP_GK = 2;             // k-steps per weight group (the unit of the ready / done counters)
+// weight loaders publish group q once group q + lag has been issued (counted vmcnt): lag = min(3, ring groups - 3) -- a compute
+// wave inside group c must already see group c + 1 (loader at q >= c + lag + 1) while the ring lets the loader reach q <= c + NS - 1
+constexpr int SP_SPIN_LIMIT = 1 << 14;   // polls (~100-200 cycles each) before a waiter gives up: > 1 ms, a real wait is microseconds
+constexpr int SP_DQ_PIECES = 48;     // A fragments of the fused transposed conv: [ab 4][cout tile 4][k-step 3]
+
+// tile row pitch of conv_sp_kernel for a pixel of SG 16-byte slots: 36 pixels + the pad the bank model picks (pair_chunks; the host
+// checks that it still does) -- a compile-time constant so that fragment addresses are one register + immediates
+__host__ __device__ constexpr int sp_row_pitch(int sg) { return sg == 4 ? 2304 : (sg == 5 ? 2928 : 0); }
+
+template <int N>
+__device__ __forceinline__ void sp_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NT, int SG, int FL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_sp_kernel(SConv a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = 4, TH = 8, KS = 5, THH = TH + KS - 1, TWH = TW + KS - 1, PS2 = SG * 16;
+    constexpr int ROWP = sp_row_pitch(SG);                    // tile row pitch: a constant, so that a wave's four pixel fragments are one address + immediates
+    constexpr int WSTEP = NT * 1024;
+    constexpr bool POOL = (FL & SP_POOL) != 0, DQ = (FL & SP_DQ) != 0, PATCH = (FL & SP_PATCH) != 0;
+    static_assert(!DQ || NT == 5, "the fused transposed conv is written for 80 channels");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const ring = smem + a.lds_ring_off;
+    // the counters: [0,1] ready  [2,3] tready  [4..7] done  [8..11] tdone.  Plain LDS accesses through address-space-3 pointers (a
+    // `volatile` access became a FLAT load with a full vmcnt(0) wait behind it -- in the loaders that drained their own DMA queue
+    // at every poll); re-reads are forced by the compiler barriers (asm memory clobbers) around every use instead.
+    typedef __attribute__((address_space(3))) int lds_int;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    lds_int* const flags = (lds_int*)(smem + a.lds_flag_off);
+    const __attribute__((address_space(3))) i32x4* const flagsv = (const __attribute__((address_space(3))) i32x4*)(smem + a.lds_flag_off);   // the loaders' four counters in one read
+    const int tiles_x = (a.Wout + TW - 1) / TW;
+    const int n_my = ((int)a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup (>= 1)
+    const bool one_blk = a.nblk == 1;               // single channel block: two slots, tiles alternate
+    const int nslot = one_blk ? 2 : a.nblk;
+    auto xcd_tile = [&](int t) {
+        if (a.xq < 0) return t;
+        const int x = t & 7, j = t >> 3;
+        return x * a.xq + min(x, a.xr) + j;
+    };
+    auto origin = [&](int i, int& oy, int& ox, int& pg) {
+        const int t = xcd_tile((int)blockIdx.x + i * (int)gridDim.x);
+        pg = t / a.tiles_per_page;
+        const int tl = t - pg * a.tiles_per_page;
+        const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+        oy = ty * TH; ox = tx * TW;
+    };
+    // PSEG_SP_TRACE (developer aid): s_memtime stamps of wave 0 / 4 / 6, 16 slots per workgroup (tools/sp_trace.py)
+    unsigned long long* const trc = a.trace ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
+#define SP_STAMP(i) if (trc && lane == 0) trc[i] = __builtin_amdgcn_s_memtime();
+    if (trc && lane == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); ((unsigned short*)&trc[14])[wave] = (unsigned short)hw; }   // where the wave runs: bits 5:4 = SIMD
+    // the FIRST wait that gave up leaves its code and what it was waiting for: err[0] code, [1] wave, [2] needed, [3] had, [4] second need, [5] second had
+    auto give_up = [&](int code, int need, int have, int need2 = 0, int have2 = 0) {
+        if (lane == 0 && atomicCAS(a.err, 0, code) == 0) { a.err[1] = wave; a.err[2] = need; a.err[3] = have; a.err[4] = need2; a.err[5] = have2; a.err[6] = (int)blockIdx.x; }
+    };
+    // every wave clears the counters it writes, then the only barrier of the kernel: nothing else is shared before it
+    if (lane == 0) {
+        if (wave < 4) { flags[4 + wave] = 0; flags[8 + wave] = 0; }
+        else flags[wave - 4] = 0;
+    }
+    if (wave == 0) { SP_STAMP(0) }
+    lds_barrier();
+
+    if (wave >= 6) {
+        // =============================== TILE LOADERS ===============================
+        const int tw = wave - 6;
+        constexpr unsigned OOB = 0xfffffff0u;
+        constexpr int ROW_SLOTS = TWH * SG, J = (ROW_SLOTS + 63) >> 6;
+        constexpr int PER_BLOCK = (THH / 2) * J;              // DMA instructions of one wave per channel block (a block has ONE source: host)
+        static_assert(THH % 2 == 0 && 3 * PER_BLOCK < 64, "counted vmcnt waits of the tile loaders");
+        const unsigned inv = 65536u / (unsigned)SG + 1u;
+        const int nblocks = n_my * a.nblk;
+        if (tw == 0) {
+            // the k-chunk table first (K * 16 bytes in 1 KiB pieces): whoever sees the first tile block landed also sees the table
+            const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)a.tab, 0, (unsigned)a.K * 16u, 0x00020000);
+            for (int pc = 0; pc * 1024 < a.K * 16; ++pc)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void*)(smem + a.lds_tab_off + pc * 1024), 16, (unsigned)(pc * 1024 + lane * 16), 0, 0, 0);
+        }
+        auto stage = [&](int jb) {
+            if (PSEG_DIAG && (a.dbg & 2)) return;
+            const int i = jb / a.nblk, b = jb - i * a.nblk;
+            int oy0, ox0, pg;
+            origin(i, oy0, ox0, pg);
+            const int iy0 = oy0 - a.pt, ix0 = ox0 - a.pl;
+            char* const in_t = smem + (one_blk ? (i & 1) : b) * a.TBLK;
+            const int c0 = b * a.nc_full, nc = b == a.nblk - 1 ? a.nc_last : a.nc_full;
+            const bool s1 = c0 >= a.nch0;                     // (wave-uniform) the block's chunks come from the second source
+            const int nchs = s1 ? a.nch1 : a.nch0, cs0 = s1 ? c0 - a.nch0 : c0;
+            const unsigned pbytes = s1 ? a.bytes1 : a.bytes0;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(s1 ? a.src1 : a.src0) + (size_t)pg * pbytes), 0, pbytes, 0x00020000);
+            unsigned col[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int sl = j * 64 + lane;
+                const int px = (int)(((unsigned)sl * inv) >> 16), cc = sl - px * SG;
+                const int ix = ix0 + px;
+                col[j] = (cc < nc && ix >= 0 && ix < a.Win && sl < ROW_SLOTS) ? (unsigned)(ix * nchs + cs0 + cc) * 16u : OOB;
+            }
+            const unsigned rowb = (unsigned)a.Win * (unsigned)(nchs * 16);
+            for (int py = tw; py < THH; py += 2) {
+                const int iy = iy0 + py;
+                const bool rowv = iy >= 0 && iy < a.Hin;
+                const unsigned rb = rowv ? (unsigned)iy * rowb : OOB;
+                char* drow = in_t + py * ROWP;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    // (slots past the row end belong to the next row's start: a zero lands there before that row's own load when
+                    // the rows go in order; this wave takes every other row, so those lanes are switched off instead)
+                    const unsigned o = (col[j] == OOB || !rowv) ? OOB : rb + col[j];
+                    if (j * 64 + lane < ROW_SLOTS)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(drow + j * 1024), 16, o, 0, 0, 0);
+                }
+            }
+        };
+        // Every workgroup of the launch starts at the same moment and the chip delivers ~11 B/clk/CU to such a burst: what the
+        // first k-steps need goes first and alone -- the table, block 0 (and, in the weight loaders, two groups) -- the other
+        // blocks of the first tile follow once it has landed (they are needed a channel block = ~25 k-steps later).
+        const int pre = min(nslot, nblocks);
+        stage(0);
+        sp_wait_vmcnt<0>();
+        if (lane == 0) flags[2 + tw] = 1;
+        for (int jb = 1; jb < pre; ++jb) stage(jb);           // the slots are empty: no counter to look at
+        // publish them as they land (in order; a block = PER_BLOCK instructions of this wave)
+        if (pre > 3) { sp_wait_vmcnt<2 * PER_BLOCK>(); if (lane == 0) flags[2 + tw] = pre - 2; }
+        if (pre > 2) { sp_wait_vmcnt<PER_BLOCK>(); if (lane == 0) flags[2 + tw] = pre - 1; }
+        sp_wait_vmcnt<0>();
+        if (lane == 0) flags[2 + tw] = pre;
+        for (int jb = pre; jb < nblocks; ++jb) {
+            // the slot is free once every compute wave is past block jb - nslot
+            const int need = jb - nslot + 1;
+            for (int it = 0;; ++it) {
+                asm volatile("" ::: "memory");
+                const int d0 = flags[8], d1 = flags[9], d2 = flags[10], d3 = flags[11];
+                if (__builtin_amdgcn_readfirstlane(min(min(d0, d1), min(d2, d3))) >= need) break;
+                if (it >= SP_SPIN_LIMIT) { give_up(1, need, min(min(d0, d1), min(d2, d3)), jb); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            asm volatile("" ::: "memory");
+            stage(jb);
+            sp_wait_vmcnt<0>();
+            if (lane == 0) flags[2 + tw] = jb + 1;
+        }
+        if (tw == 0) { SP_STAMP(13) }
+        return;
+    }
+    if (wave >= 4) {
+        // =============================== WEIGHT LOADERS ===============================
+        const int lw = wave - 4;
+        const int gpt = a.S / SP_GK;                          // groups per tile
+        const int total = n_my * gpt;
+        const int NS = a.RK / SP_GK;                          // ring slots (groups), >= 5 (host)
+        const int lag = min(3, NS - 4);
+        // group q: 2 NT pieces of 1 KiB; this wave takes pieces lw, lw + 2, ... (NT of them)
+        // (buffer form: the per-lane offset is ONE constant register, the piece's offset rides in the scalar operand -- no
+        // per-load address arithmetic, half the address registers of the global form)
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (unsigned)a.S * (unsigned)(NT * 1024), 0x00020000);
+        const unsigned vo = (unsigned)lane * 16u;
+        int qt = 0, slot = 0;                                 // group within the tile's stream, ring slot (both of the NEXT group to issue)
+        auto issue = [&]() {
+            const unsigned so = (unsigned)(qt * (SP_GK * NT) + lw) * 1024u;
+            char* dstb = ring + (slot * (SP_GK * NT) + lw) * 1024;
+            if (!(PSEG_DIAG && (a.dbg & 1))) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dstb + j * 2048), 16, vo, so + (unsigned)j * 2048u, 0, 0);
+            }
+            qt = qt + 1 == gpt ? 0 : qt + 1;
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        };
+        const int pre = min(NS, total);
+        const int pre0 = min(2, pre);
+        for (int q = 0; q < pre0; ++q) issue();               // the ring is empty: two groups at once ...
+        sp_wait_vmcnt<0>();
+        if (lane == 0) flags[lw] = pre0;
+        for (int it = 0; it < SP_SPIN_LIMIT; ++it) {          // ... the rest behind the first tile block (see the tile loaders)
+            asm volatile("" ::: "memory");
+            const int t0 = flags[2], t1 = flags[3];
+            if (__builtin_amdgcn_readfirstlane(min(t0, t1)) >= 1) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        for (int q = pre0; q < pre; ++q) issue();
+        // publish what is in flight as it lands: at most 6 more groups were issued (NS <= 8: host)
+#define SP_PUB(REM)                                                                              \
+        if (pre - pre0 > (REM)) { sp_wait_vmcnt<(REM) * NT>(); if (lane == 0) flags[lw] = pre - (REM); }
+        SP_PUB(5) SP_PUB(4) SP_PUB(3) SP_PUB(2) SP_PUB(1) SP_PUB(0)
+#undef SP_PUB
+        int pub = pre;                                        // groups published so far (everything issued above has landed)
+        long long wl_poll = 0;
+        for (int q = pre; q < total; ++q) {
+            const int need = q - NS + 1;                      // every compute wave has finished group q - NS
+            const long long tp0 = trc ? __builtin_amdgcn_s_memtime() : 0;
+            for (int it = 0;; ++it) {
+                asm volatile("" ::: "memory");
+                const int d0 = flags[4], d1 = flags[5], d2 = flags[6], d3 = flags[7];
+                if (__builtin_amdgcn_readfirstlane(min(min(d0, d1), min(d2, d3))) >= need) break;
+                if (it >= SP_SPIN_LIMIT) { give_up(2, need, min(min(d0, d1), min(d2, d3)), q); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            if (trc) wl_poll += __builtin_amdgcn_s_memtime() - tp0;
+            issue();
+            // groups <= q - lag have landed once at most `lag` groups of this wave's loads are outstanding
+            if (lag == 3) sp_wait_vmcnt<3 * NT>(); else if (lag == 2) sp_wait_vmcnt<2 * NT>(); else sp_wait_vmcnt<NT>();
+            if (q - lag + 1 > pub) { pub = q - lag + 1; if (lane == 0) flags[lw] = pub; }
+        }
+        sp_wait_vmcnt<0>();
+        if (lane == 0) flags[lw] = total;
+        if (lw == 0) { SP_STAMP(11) if (trc && lane == 0) trc[12] = (unsigned long long)wl_poll; }
+        return;
+    }
+    // =============================== COMPUTE ===============================
+    if (wave == 0) { SP_STAMP(1) }
+    long long sw_cyc = 0; int sw_cnt = 0;
+    const int p16 = lane & 15, g = lane >> 4;
+    float4 biasr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) biasr[t] = *(const float4*)(a.bias + t * 16 + 4 * g);
+    const int pixb0 = (wave * 2) * ROWP + p16 * PS2;          // fragment m: + (m >> 1) * ROWP + (m & 1) * 16 * PS2 (immediates)
+    const char* const wb0 = ring + lane * 16;
+    const char* const tb = smem + a.lds_tab_off + g * 4;
+    const int K = a.K, RK = a.RK;
+    const int CsO = a.nch_out * 8;
+    constexpr unsigned OOBS = 0xfffffff0u;
+
+    // slow path of the counters: poll until `needw` weight groups and `needt` tile blocks have landed
+    auto slow_wait = [&](int needw, int needt) {
+        const long long tq0 = trc ? __builtin_amdgcn_s_memtime() : 0;
+        for (int it = 0;; ++it) {
+            asm volatile("" ::: "memory");
+            const int r0 = flags[0], r1 = flags[1], t0 = flags[2], t1 = flags[3];
+            if (__builtin_amdgcn_readfirstlane(min(r0, r1)) >= needw && __builtin_amdgcn_readfirstlane(min(t0, t1)) >= needt) break;
+            if (it >= SP_SPIN_LIMIT) { give_up(3, needw, min(r0, r1), needt, min(t0, t1)); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        if (trc) { sw_cyc += __builtin_amdgcn_s_memtime() - tq0; ++sw_cnt; }
+    };
+    int kg = 0;                       // weight-stream steps consumed by the tiles before this one (even)
+    int pos0 = 0;                     // ring position of this tile's step 0
+    for (int i = 0; i < n_my; ++i) {
+        int oy0, ox0, pg;
+        origin(i, oy0, ox0, pg);
+        const int jb0 = i * a.nblk;                           // tile blocks before this tile
+        const char* const in_t = smem + pixb0 + (one_blk ? (i & 1) * a.TBLK : 0);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{biasr[n].x, biasr[n].y, biasr[n].z, biasr[n].w};
+        // ---- the flat k-loop: one trip = one weight group = two k-steps ----------------------------------------------
+        // Needs of step x of this tile: weight group (kg + x) / 2 landed (ready >= that + 1), tile block x / blk_steps landed
+        // (tready >= jb0 + that + 1).  Entering a trip the needs of its steps s, s + 1 and of step s + 2 (whose fragments the
+        // trip's second half requests) have been looked at; behind its MFMAs the trip looks at those of s + 3 and s + 4.
+        bf16x8 xa[MT], wa[NT], xb[MT], wbq[NT];
+#define SP_LOAD(XF, WF, POS, OFF)                                                                 \
+        {                                                                                        \
+            const char* wbp_ = wb0 + (POS) * WSTEP;                                              \
+            const char* xp_ = in_t + (OFF);                                                      \
+            WF[0] = *(const bf16x8*)(wbp_);                                                      \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                       \
+                XF[m] = *(const bf16x8*)(xp_ + ((m >> 1) * ROWP + (m & 1) * 16 * PS2));          \
+            _Pragma("unroll") for (int t = 1; t < NT; ++t)                                       \
+                WF[t] = *(const bf16x8*)(wbp_ + t * 1024);                                       \
+        }
+#define SP_MMA(XF, WF)                                                                           \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                           \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                       \
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[t], XF[m], acc[m][t], 0, 0, 0);
+#define SP_INTERLEAVE                                                                            \
+        _Pragma("unroll") for (int q_ = 0; q_ < MT * NT; ++q_) {                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        }
+#define SP_TAB(X) (*(const int*)(tb + ((X) < K ? (X) : K - 1) * 16))
+        static_assert(SP_GK == 2, "a weight group is the two k-steps of one trip of the k-loop");
+        // tile blocks: the block of the last step whose needs have been looked at, and the blocks the k-loop is past
+        int blk4 = 0, blk4_next = a.nblk > 1 ? a.blk_steps : 0x7fffffff;   // first step of block blk4 + 1
+        int rel_blk = 0, rel_next = a.nblk > 1 ? a.blk_steps : 0x7fffffff;  // first step of block rel_blk + 1
+        {
+            const int x2 = min(2, K - 1);                     // steps 0, 1, 2: requested before the first check
+            while (x2 >= blk4_next) { ++blk4; blk4_next = blk4 + 1 < a.nblk ? blk4_next + a.blk_steps : 0x7fffffff; }
+            slow_wait(((kg + x2) >> 1) + 1, jb0 + blk4 + 1);
+        }
+        if (wave == 0 && i < 2) { SP_STAMP(2 + 3 * i) }
+        int pos1 = pos0 + 1 == RK ? 0 : pos0 + 1, pos2 = pos1 + 1 == RK ? 0 : pos1 + 1;   // ring positions of steps s + 1, s + 2
+        int offa = SP_TAB(0), offb = SP_TAB(1);
+        SP_LOAD(xa, wa, pos0, offa)
+        for (int s = 0; s < K; s += 2) {                      // K is even
+            __builtin_amdgcn_sched_barrier(0);
+            const i32x4 fv = *flagsv;                         // looked at behind the trip's MFMAs
+            offa = SP_TAB(s + 2);
+            SP_LOAD(xb, wbq, pos1, offb)
+            SP_MMA(xa, wa)
+            SP_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+            offb = SP_TAB(s + 3);
+            SP_LOAD(xa, wa, pos2, offa)
+            SP_MMA(xb, wbq)
+            SP_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+            // the group is read (its fragments are in registers: the MFMAs were issued): hand it back, and the tile blocks behind
+            if (lane == 0) flags[4 + wave] = ((kg + s) >> 1) + 1;
+            if (s + 2 >= rel_next) {
+                ++rel_blk; rel_next = rel_blk + 1 < a.nblk ? rel_next + a.blk_steps : 0x7fffffff;
+                if (lane == 0) flags[8 + wave] = jb0 + rel_blk;
+            }
+            // needs of steps s + 3 and s + 4 (requested by the next trip)
+            const int x4 = min(s + 4, K - 1);
+            if (x4 >= blk4_next) { ++blk4; blk4_next = blk4 + 1 < a.nblk ? blk4_next + a.blk_steps : 0x7fffffff; }
+            const int needw = ((kg + x4) >> 1) + 1, needt = jb0 + blk4 + 1;
+            if (__builtin_amdgcn_readfirstlane(min(fv.x, fv.y)) < needw || __builtin_amdgcn_readfirstlane(min(fv.z, fv.w)) < needt)
+                slow_wait(needw, needt);
+            asm volatile("" ::: "memory");
+            pos1 = pos2 + 1 == RK ? 0 : pos2 + 1;
+            pos2 = pos1 + 1 == RK ? 0 : pos1 + 1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#undef SP_TAB
+#undef SP_INTERLEAVE
+#undef SP_MMA
+#undef SP_LOAD
+        if (lane == 0) flags[8 + wave] = jb0 + a.nblk;        // the tile's last block: read to the end
+        if (wave == 0 && i < 2) { SP_STAMP(3 + 3 * i) }
+        // ---- epilogue from registers ---------------------------------------------------------------------------------
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        if constexpr (DQ) {
+            // Conv2DTranspose k2 s2 (ReLU) on the accumulators (see conv_mfma_kernel FL_DQ): a 16 x 16 accumulator tile has the pixel
+            // on the lane and four channels in registers, so two tiles are one B operand of the next MFMA.  Its 48 A fragments are
+            // pieces K * NT ... of this tile's weight stream (ring steps pos0 + K ...; piece p at step p / NT, KiB p % NT), so
+            // nothing is fetched from L2 here.  Per sub-pixel ab and pixel tile m the 64 output channels of 16 pixels (12 MFMAs) go
+            // through a 2 KiB LDS patch of this wave and leave as whole 128-byte lines -- a direct store instruction of the
+            // accumulator layout touches 64 lines for 8 bytes each, and 64 of those per wave made this epilogue 17 k cycles.
+            uint4 bq[MT][3];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                uint32_t pk[NT][2];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    pk[t][0] = pk_bf16(acc[m][t][0], acc[m][t][1]);
+                    pk[t][1] = pk_bf16(acc[m][t][2], acc[m][t][3]);
+                    if (a.relu) { pk[t][0] = relu_pk_bf16(pk[t][0], 0u); pk[t][1] = relu_pk_bf16(pk[t][1], 0u); }
+                }
+                bq[m][0] = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+                bq[m][1] = make_uint4(pk[2][0], pk[2][1], pk[3][0], pk[3][1]);
+                bq[m][2] = make_uint4(pk[4 % NT][0], pk[4 % NT][1], 0u, 0u);
+            }
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.dq_dst + (size_t)pg * a.dq_bytes), 0, a.dq_bytes, 0x00020000);
+            const int W2 = 2 * a.Wout;
+            constexpr int QPP = 128 + 8;                      // patch bytes per pixel (64 channels + 8: conflict-free 8-byte writes)
+            char* const patch = smem + a.lds_patch_off + wave * (2 * 16 * QPP);   // two patches: tile m + 1 is written while tile m's lines leave
+            float4 b2[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b2[t] = *(const float4*)(a.dq_bias + t * 16 + 4 * g);
+            const int posq = (pos0 + K) % RK;
+            auto piece = [&](int p) -> const char* {
+                int ps = posq + p / NT;
+                ps = ps >= RK ? ps - RK : ps;
+                return wb0 + ps * WSTEP + (p % NT) * 1024;
+            };
+#pragma unroll 1
+            for (int ab = 0; ab < 4; ++ab) {
+                // the 12 fragments of this sub-pixel: pieces 12 ab ... 12 ab + 11 (the stream behind them may still be landing)
+                slow_wait(((kg + K + (12 * ab + 11) / NT) >> 1) + 1, 0);
+                bf16x8 wf[4][3];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int s3 = 0; s3 < 3; ++s3) wf[t][s3] = *(const bf16x8*)piece((ab * 4 + t) * 3 + s3);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x4 z[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z[t] = f32x4{b2[t].x, b2[t].y, b2[t].z, b2[t].w};
+#pragma unroll
+                    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            z[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s3], __builtin_bit_cast(bf16x8, bq[m][s3]), z[t], 0, 0, 0);
+                    char* const pt = patch + (m & 1) * (16 * QPP);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        uint2 pk = make_uint2(pk_bf16(z[t][0], z[t][1]), pk_bf16(z[t][2], z[t][3]));
+                        if (a.dq_relu) pk = make_uint2(relu_pk_bf16(pk.x, 0u), relu_pk_bf16(pk.y, 0u));
+                        *(uint2*)(pt + p16 * QPP + t * 32 + g * 8) = pk;
+                    }
+                    const int y = oy0 + wave * 2 + (m >> 1);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {             // 16 pixels x 8 pieces of 16 bytes: piece lane + 64 u
+                        const int ii = lane + 64 * u, px = ii >> 3, c = ii & 7;
+                        const char* sp = pt + px * QPP + c * 16;
+                        const uint2 lo = *(const uint2*)sp, hi = *(const uint2*)(sp + 8);
+                        const int x = ox0 + (m & 1) * 16 + px;
+                        const bool ok = y < a.Hout && x < a.Wout && c < a.dq_nch;
+                        const unsigned o = ok ? (unsigned)((2 * y + (ab >> 1)) * W2 + 2 * x + (ab & 1)) * (unsigned)(a.dq_nch * 16) + (unsigned)(c * 16) : OOBS;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_uint4(lo.x, lo.y, hi.x, hi.y)), rq, o, 0, 0);
+                    }
+                }
+                // this sub-pixel's fragments are in registers: hand back the ring groups that lie wholly in front of the next one's
+                asm volatile("" ::: "memory");
+                if (lane == 0) flags[4 + wave] = (kg + K + (12 * (ab + 1)) / NT) >> 1;
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.dst + (size_t)pg * a.dst_bytes), 0, a.dst_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(POOL ? (char*)a.pool_dst + (size_t)pg * a.pool_bytes : (char*)a.dst), 0, POOL ? a.pool_bytes : 0u, 0x00020000);
+            unsigned pixoff[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int y = oy0 + wave * 2 + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+                pixoff[m] = (y < a.Hout && x < a.Wout) ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) : OOBS;
+            }
+            // stores through this wave's own LDS patch (whole 128-byte lines per store instruction, see conv_mfma_kernel) where
+            // the layer's LDS budget has room for one (SP_PATCH), else 8-byte lane stores
+            constexpr int LST_PP = NT * 32 + 8;
+            char* const patch = smem + a.lds_patch_off + wave * (2 * TW * LST_PP);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = t * 16 + 4 * g;
+                const unsigned noff = n < CsO ? (unsigned)n * 2u : OOBS;
+                float v[MT][4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    v[m][0] = acc[m][t][0]; v[m][1] = acc[m][t][1]; v[m][2] = acc[m][t][2]; v[m][3] = acc[m][t][3];
+                    if (a.relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[m][r] = vmax(v[m][r], 0.0f);
+                    }
+                    const uint2 pk = make_uint2(pk_bf16(v[m][0], v[m][1]), pk_bf16(v[m][2], v[m][3]));
+                    if constexpr (PATCH) {
+                        *(uint2*)(patch + ((m >> 1) * TW + (m & 1) * 16 + p16) * LST_PP + t * 32 + g * 8) = pk;
+                    } else {
+                        const unsigned o = (pixoff[m] == OOBS || noff == OOBS) ? OOBS : pixoff[m] + noff;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
+                    }
+                }
+                if constexpr (POOL) {
+                    const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {             // pairs (m, m + 2): rows 2r and 2r + 1 of this wave
+                        float q[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) q[r] = vmax_xor1(vmax(v[m][r], v[m + 2][r]));
+                        const int y = (oy0 >> 1) + wave;
+                        const int x = (ox0 >> 1) + ((m * 16 + p16) >> 1);
+                        const bool ok = !(p16 & 1) && y < Ho2 && x < Wo2 && noff != OOBS;
+                        const unsigned o = ok ? (unsigned)(y * Wo2 + x) * (unsigned)(CsO * 2) + noff : OOBS;
+                        const uint2 pk = make_uint2(pk_bf16(q[0], q[1]), pk_bf16(q[2], q[3]));
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rp, o, 0, 0);
+                    }
+                }
+            }
+            if constexpr (PATCH) {
+                constexpr int PPX = NT * 2;                   // 16-byte pieces per pixel
+                constexpr int NP = 2 * TW * PPX;              // pieces of this wave's two rows
+                asm volatile("" ::: "memory");                // (the patch rows are this wave's own: a wave's LDS operations execute in order)
+#pragma unroll
+                for (int u = 0; u < NP / 64; ++u) {
+                    const int ii = lane + 64 * u;
+                    const int px = ii / PPX, c = ii - px * PPX, r = px / TW, xx = px - r * TW;
+                    const char* sp = patch + px * LST_PP + c * 16;
+                    const uint2 lo = *(const uint2*)sp, hi = *(const uint2*)(sp + 8);
+                    const int y = oy0 + wave * 2 + r, x = ox0 + xx;
+                    const bool ok = y < a.Hout && x < a.Wout && c * 16 < CsO * 2;
+                    const unsigned o = ok ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) + (unsigned)(c * 16) : OOBS;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_uint4(lo.x, lo.y, hi.x, hi.y)), rd, o, 0, 0);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        // hand the rest of this tile's stream back (padding steps, the transposed conv's fragments)
+        if (wave == 0 && i < 2) { SP_STAMP(4 + 3 * i) }
+        kg += a.S;
+        asm volatile("" ::: "memory");
+        if (lane == 0) flags[4 + wave] = kg >> 1;
+        pos0 = (pos0 + a.S) % RK;
+    }
+    if (wave == 0) { SP_STAMP(10) if (trc && lane == 0) { trc[8] = (unsigned long long)sw_cyc; trc[9] = (unsigned long long)sw_cnt; } }
+#undef SP_STAMP
+}
+
 // =============================================================================================
 // host side: plans, packing, launches
 // =============================================================================================
@@ -2738,6 +3272,13 @@ struct MfmaPlan {
     size_t skiplog_bytes = 0;
     int skip_CP = 0;
     UpSplit* upsplit = nullptr;   // PLAN_UPSPLIT: GEMM + gather-sum form of upsample -> k2 conv
+    // conv_sp_kernel (streamed weights, persistent workgroups, loader waves): a second packing of the same layer
+    bool sp = false;
+    int sp_NT = 0, sp_sigma = 0, sp_fl = 0, sp_K = 0, sp_S = 0, sp_blk_steps = 0, sp_nblk = 0, sp_nc_full = 0, sp_nc_last = 0;
+    int sp_row_pitch = 0, sp_TBLK = 0, sp_RK = 0, sp_ring_off = 0, sp_patch_off = 0, sp_tab_off = 0, sp_flag_off = 0, sp_lds = 0;
+    int* d_sp_tab = nullptr;
+    uint16_t* d_sp_wpk = nullptr;
+    int* d_sp_err = nullptr;
 };
 
 void mfma_free_op(Op& op) {
@@ -2751,6 +3292,7 @@ void mfma_free_op(Op& op) {
     (void)hipFree(p->d_skiplog);
     (void)hipFree(p->d_dq_w); (void)hipFree(p->d_dq_bias);
     (void)hipFree(p->d_q_w); (void)hipFree(p->d_q_bias); (void)hipFree(p->d_t2_wD); (void)hipFree(p->d_t2_wC);
+    (void)hipFree(p->d_sp_tab); (void)hipFree(p->d_sp_wpk); (void)hipFree(p->d_sp_err);
     delete p;
     op.plan = nullptr;
 }
@@ -3373,6 +3915,80 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         else { const int ab = n / P->CoP, co = n % P->CoP; if (ab < 4 && co < Cout) bb[n] = bias[co]; }
     }
     PSEG_TRY(upload(&P->d_bias, bb));
+    // ---- second packing for conv_sp_kernel: k5 stride-1 layers with one N block whose weights are streamed ----------
+    if (!deconv && KS == 5 && op.stride == 1 && !op.up0 && !op.up1 && !op.in_relu && op.add < 0 && op.fuse1 < 0 && op.tail_logits < 0 &&
+        op.skiplog < 0 && op.relu_dst < 0 && P->nblocks_n == 1 && NT >= 3 && NT <= 5 && (op.dq_fuse < 0 || NT == 5) && !P->pp &&
+        !PSEG_KNOB("PSEG_NO_SP") && !PSEG_KNOB("PSEG_GENERIC")) {
+        const int sg = P->nc_full;                 // dense tile: sigma = chunks per pixel of a block
+        int pad = 1, best_cyc = 1 << 30;
+        for (int pd = 0; pd < 16; ++pd) {
+            int cyc = 0;
+            (void)pair_chunks(KS, P->nc_full, sg, (TW + KS - 1) * sg + pd, &cyc);
+            if (cyc < best_cyc) { best_cyc = cyc; pad = pd; }
+        }
+        const int rowp = ((TW + KS - 1) * sg + pad) * 16, TBLK = round_up((8 + KS - 1) * rowp, 16);
+        const auto o_full = pair_chunks(KS, P->nc_full, sg, rowp / 16), o_last = pair_chunks(KS, P->nc_last, sg, rowp / 16);
+        const int ksf = (int)o_full.size() / 4, ksl = (int)o_last.size() / 4;
+        const int K0 = (P->nblk - 1) * ksf + ksl, K = round_up(K0, 2);
+        const bool dq = op.dq_fuse >= 0;
+        const int S = round_up(K + (dq ? cdiv(SP_DQ_PIECES, NT) : 0), SP_GK);
+        const int nslot = P->nblk == 1 ? 2 : P->nblk;
+        const int tiles_b = nslot * TBLK, tabb = K * 16, LDS_MAX = 160 * 1024;
+        const int patchb = dq ? 4 * 2 * 16 * (128 + 8) : 4 * 2 * TW * (NT * 32 + 8);   // the transposed conv's 16-pixel patches / the plain epilogue's two rows per wave
+        auto ring_for = [&](bool patch) {          // largest even ring (<= 16 steps: vmcnt counts, SP_PUB) that fits
+            int rk = (LDS_MAX - tiles_b - round_up(tabb, 1024) - 64 - (patch ? patchb : 0)) / (NT * 1024);
+            rk = std::min(rk, 16) & ~1;
+            return rk;
+        };
+        const int rk_min = dq ? 12 : 10;           // five ring slots of two k-steps; the transposed conv's 10 pseudo-steps sit in the ring at once
+        const bool patch = dq || ring_for(true) >= rk_min;
+        const int RK = ring_for(patch);
+        // the kernel instances (mfma_launch_conv), a row pitch the kernel is compiled for, channel blocks that have ONE source each,
+        // at most four of them (the tile loaders' counted waits), 64 output channels behind a fused transposed conv
+        const bool inst = (NT == 5 && sg == 4 && (dq || patch)) || (NT == 4 && (sg == 4 || sg == 5) && patch) || (NT == 3 && sg == 4);
+        const bool shape_ok = rowp == sp_row_pitch(sg) && P->nblk <= 4 && (!s1 || (Cs0 / 8) % P->nc_full == 0) &&
+                              (!dq || e.tensors[e.ops[op.dq_fuse].dst].Cs == 64);
+        if (RK >= rk_min && inst && shape_ok && ksf >= 2) {
+            P->sp = true;
+            P->sp_NT = NT; P->sp_sigma = sg; P->sp_K = K; P->sp_S = S; P->sp_blk_steps = ksf;
+            P->sp_nblk = P->nblk; P->sp_nc_full = P->nc_full; P->sp_nc_last = P->nc_last;
+            P->sp_row_pitch = rowp; P->sp_TBLK = TBLK; P->sp_RK = RK;
+            P->sp_fl = (dq ? SP_DQ : 0) | (patch && !dq ? SP_PATCH : 0) | (op.pool_dst >= 0 ? SP_POOL : 0);
+            P->sp_ring_off = tiles_b;
+            P->sp_patch_off = tiles_b + RK * NT * 1024;
+            P->sp_tab_off = P->sp_patch_off + (patch ? patchb : 0);
+            P->sp_flag_off = P->sp_tab_off + round_up(tabb, 1024);      // (the table arrives in 1 KiB DMA pieces)
+            P->sp_lds = P->sp_flag_off + 64;
+            std::vector<int> tab((size_t)K * 4, 0);
+            std::vector<uint16_t> spk((size_t)S * NT * 512, 0);
+            for (int b = 0; b < P->nblk; ++b) {
+                const bool last = b == P->nblk - 1;
+                const auto& ord = last ? o_last : o_full;
+                const int ksb = last ? ksl : ksf, st0 = b * ksf, slot_base = P->nblk == 1 ? 0 : b * TBLK;
+                for (int st = 0; st < ksb; ++st)
+                    for (int gi = 0; gi < 4; ++gi) {
+                        const Chunk c = ord[(size_t)st * 4 + gi];
+                        if (c.cc < 0) continue;                          // dummy: offset 0 (finite data), zero weights
+                        tab[(size_t)(st0 + st) * 4 + gi] = slot_base + (c.tap / KS) * rowp + (c.tap % KS) * sg * 16 + c.cc * 16;
+                        for (int t = 0; t < NT; ++t)
+                            for (int p16 = 0; p16 < 16; ++p16) {
+                                uint16_t* o = &spk[(((size_t)(st0 + st) * NT + t) * 64 + gi * 16 + p16) * 8];
+                                for (int j = 0; j < 8; ++j) {
+                                    const int ci = true_ci((b * P->nc_full + c.cc) * 8 + j);
+                                    if (ci >= 0) o[j] = f2bf(wval(c.tap, ci, t * 16 + p16));
+                                }
+                            }
+                    }
+            }
+            PSEG_TRY(upload(&P->d_sp_tab, tab));
+            PSEG_TRY(upload(&P->d_sp_wpk, spk));
+            std::vector<int> z(8, 0);
+            PSEG_TRY(upload(&P->d_sp_err, z));
+            if (PSEG_KNOB("PSEG_LOG_SP"))
+                fprintf(stderr, "[pseg] conv_sp plan %s: NT %d sigma %d fl %d nblk %d (nc %d / %d) K %d S %d blk_steps %d row_pitch %d TBLK %d RK %d lds %d\n", op.layer.c_str(),
+                        NT, sg, P->sp_fl, P->nblk, P->nc_full, P->nc_last, K, S, ksf, rowp, TBLK, RK, P->sp_lds);
+        }
+    }
     if (deconv && op.into_tail >= 0) {
         // this transposed conv runs inside the composed tail: A fragments [ab][cout tile 2][k-step 4][lane = (cout & 15, g)][8],
         // element j <-> storage channel (4s + g) * 8 + j of the concatenated quarter-resolution sources
@@ -3427,6 +4043,13 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
             for (int c = 0; c < Cout; ++c) bq[c] = bias[c];
             PSEG_TRY(upload(&P->d_dq_w, wq));
             PSEG_TRY(upload(&P->d_dq_bias, bq));
+            // conv_sp_kernel takes these 48 fragments from its weight ring: they follow the conv's k-steps in the producer's stream
+            for (auto& o : e.ops) {
+                auto* PC = (MfmaPlan*)o.plan;
+                if (o.dq_fuse != (int)(&op - e.ops.data()) || !PC || !PC->sp) continue;
+                if (!(PC->sp_fl & SP_DQ) || (size_t)(PC->sp_S - PC->sp_K) * PC->sp_NT * 512 < wq.size()) return fail(PSEG_EINVAL, "conv_sp_kernel: no room for the transposed conv's fragments");
+                PSEG_HIP(hipMemcpy(PC->d_sp_wpk + (size_t)PC->sp_K * PC->sp_NT * 512, wq.data(), wq.size() * 2, hipMemcpyHostToDevice));
+            }
         }
     }
     if (!deconv && op.skiplog >= 0) {
@@ -3878,6 +4501,79 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     // mostly hidden by the co-resident workgroup); needs the per-trip opaque lane ids to keep two waves per SIMD.
     // wave-specialised persistent kernel (conv12_ws_kernel): one 512-thread workgroup per CU, two input tiles + the resident
     // weights in LDS.  PSEG_NO_WS=1 falls back to the every-wave-does-everything fused instance below.
+    // streamed-weights persistent kernel with loader waves (conv_sp_kernel): conv5, conv6, conv7, deconv1 (+ deconv2), deconv3
+    if (P->sp && !a.trace && !PSEG_KNOB("PSEG_NO_SP") && !PSEG_KNOB("PSEG_GENERIC") && (op.dq_fuse >= 0) == ((P->sp_fl & SP_DQ) != 0) &&
+        (op.pool_dst >= 0) == ((P->sp_fl & SP_POOL) != 0)) {
+        static int cus_sp = 0;
+        int dev = 0;
+        PSEG_HIP(hipGetDevice(&dev));
+        if (!cus_sp) PSEG_HIP(hipDeviceGetAttribute(&cus_sp, hipDeviceAttributeMultiprocessorCount, dev));
+        // Where it pays (same box, us per layer, conv_sp_kernel vs conv_mfma_kernel): the 80-channel layers always (2048x1536: conv7 20.5 vs
+        // 27.0, deconv1 + deconv2 30.4 vs 39.3; 4096x3072: 48.7 vs 73.1, 75.3 vs 112.1 -- their five cout tiles leave conv_mfma_kernel two
+        // workgroups per CU at best); the 40- / 60-channel layers while a launch is one round of tiles (1024x768: 14.7 / 19.7 / 26.7 vs
+        // 19.4 / 25.5 / 37.0) -- with several tiles per CU three co-resident conv_mfma_kernel workgroups (three waves per SIMD, each
+        // hiding the others' fragment reads) still beat one compute wave per SIMD by 3-10 %.  PSEG_SP_ALL=1: every eligible layer.
+        const bool sp_pays = P->sp_NT == 5 || (int)grid.x <= cus_sp || PSEG_KNOB("PSEG_SP_ALL");
+        SConv c{};
+        c.src0 = a.src0; c.src1 = a.src1; c.nch0 = a.nch0; c.nch1 = a.nch1; c.bytes0 = a.bytes0; c.bytes1 = a.bytes1;
+        c.Hin = a.Hin; c.Win = a.Win; c.Hout = a.Hout; c.Wout = a.Wout; c.pt = a.pt; c.pl = a.pl; c.relu = a.relu;
+        c.nblk = P->sp_nblk; c.nc_full = P->sp_nc_full; c.nc_last = P->sp_nc_last; c.K = P->sp_K; c.S = P->sp_S; c.blk_steps = P->sp_blk_steps;
+        c.tab = P->d_sp_tab; c.wpk = P->d_sp_wpk; c.bias = P->d_bias;
+        c.row_pitch = P->sp_row_pitch; c.TBLK = P->sp_TBLK; c.RK = P->sp_RK;
+        c.lds_ring_off = P->sp_ring_off; c.lds_patch_off = P->sp_patch_off; c.lds_tab_off = P->sp_tab_off; c.lds_flag_off = P->sp_flag_off;
+        c.dst = a.dst; c.dst_bytes = a.dst_bytes; c.nch_out = a.nch_out; c.pool_dst = a.pool_dst; c.pool_bytes = a.pool_bytes;
+        c.dq_bias = a.dq_bias; c.dq_dst = a.dq_dst; c.dq_bytes = a.dq_bytes; c.dq_nch = a.dq_nch; c.dq_relu = a.dq_relu;
+        c.ntiles = (int)grid.x; c.tiles_per_page = (int)grid.x; c.xq = a.xq; c.xr = a.xr;
+        c.err = P->d_sp_err;
+        c.dbg = PSEG_DIAG_KNOB("PSEG_SP_DBG") ? atoi(PSEG_DIAG_KNOB("PSEG_SP_DBG")) : 0;
+        const dim3 gs((unsigned)std::min<int>((int)grid.x, cus_sp));
+        const char* trl = PSEG_KNOB("PSEG_SP_TRACE");
+        const bool tracing = sp_pays && trl && op.layer == trl;
+        if (tracing) {
+            PSEG_HIP(hipMalloc((void**)&c.trace, (size_t)gs.x * 16 * 8));
+            PSEG_HIP(hipMemset(c.trace, 0, (size_t)gs.x * 16 * 8));
+        }
+        bool launched = !sp_pays;
+#define PSEG_SP(NT_, SG_, FL_)                                                                                      \
+        if (!launched && P->sp_NT == NT_ && P->sp_sigma == SG_ && P->sp_fl == (FL_)) {                               \
+            static bool attr_set[64] = {false};                                                                   \
+            if (!attr_set[dev & 63]) {                                                                            \
+                PSEG_HIP(hipFuncSetAttribute((const void*)conv_sp_kernel<NT_, SG_, (FL_)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                attr_set[dev & 63] = true;                                                                        \
+            }                                                                                                     \
+            conv_sp_kernel<NT_, SG_, (FL_)><<<gs, 512, P->sp_lds, st>>>(c);                                        \
+            PSEG_HIP(hipGetLastError());                                                                          \
+            launched = true;                                                                                      \
+        }
+        PSEG_SP(5, 4, SP_PATCH)                 // conv7
+        PSEG_SP(5, 4, SP_DQ)                    // deconv1 + deconv2 (k2 s2) on its accumulators
+        PSEG_SP(4, 5, SP_PATCH)                 // conv5
+        PSEG_SP(4, 4, SP_PATCH | SP_POOL)       // conv6
+        PSEG_SP(4, 4, SP_PATCH)
+        PSEG_SP(4, 5, SP_PATCH | SP_POOL)
+        PSEG_SP(3, 4, 0)                        // deconv3 (fcn_skip: four channel blocks, no room for the store patch)
+        PSEG_SP(3, 4, SP_PATCH)                 // deconv3 (fcn)
+#undef PSEG_SP
+        if (!sp_pays) launched = false;
+        if (launched && tracing) {
+            PSEG_HIP(hipStreamSynchronize(st));
+            std::vector<unsigned long long> hbuf((size_t)gs.x * 16);
+            PSEG_HIP(hipMemcpy(hbuf.data(), c.trace, hbuf.size() * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(c.trace);
+            const std::string fn = std::string("gpurun_out/sp_trace_") + op.layer + ".bin";
+            if (FILE* f = fopen(fn.c_str(), "wb")) { fwrite(hbuf.data(), 8, hbuf.size(), f); fclose(f); }
+        }
+        if (launched) {
+            if (PSEG_KNOB("PSEG_SP_CHECK")) {   // tests: a polling loop of the kernel that gave up is an error, not a silent wrong result
+                int herr[8] = {0};
+                PSEG_HIP(hipStreamSynchronize(st));
+                PSEG_HIP(hipMemcpy(herr, P->d_sp_err, 32, hipMemcpyDeviceToHost));
+                if (herr[0]) return fail(PSEG_EHIP, "conv_sp_kernel (%s): a counter wait gave up (code %d: 1 tile loader, 2 weight loader, 3 compute; wave %d of workgroup %d needed %d had %d / needed %d had %d)",
+                                         op.layer.c_str(), herr[0], herr[1], herr[6], herr[2], herr[3], herr[4], herr[5]);
+            }
+            return PSEG_OK;
+        }
+    }
     // ping-pong persistent kernel (conv_pp_kernel) for the k5 mid layers whose weights fit LDS beside two tiles: conv3, conv4
     if (P->wg3 && P->KS == 5 && P->NT == 3 && P->MT == 4 && P->NW == 4 && P->nblk == 1 && P->nblocks_n == 1 && op.Cout <= 40 && !op.transposed &&
         op.src1 < 0 && !a.add && !a.in_relu && !a.up0 && op.fuse1 < 0 && op.tail_logits < 0 && op.skiplog < 0 && op.relu_dst < 0 &&

@@ -357,6 +357,44 @@ def test_bf16_ping_pong_mid_layer_kernel_is_bit_identical(gpu, monkeypatch, arch
     assert np.abs(res[0][2]).max() > 0
 
 
+@pytest.mark.parametrize("arch,C,shape", [("fcn_skip", 3, (96, 80)), ("fcn_skip", 6, (130, 67)), ("fcn", 3, (300, 420)), ("fcn_skip", 3, (1056, 1000)),
+                                          ("fcn_skip", 3, (33, 1)), ("fcn", 6, (1, 37))])
+def test_bf16_streamed_weights_kernel_is_bit_identical(gpu, monkeypatch, arch, C, shape):
+    """conv_sp_kernel (conv5, conv6, conv7, deconv1 + deconv2, deconv3: persistent workgroups, loader waves streaming the weights
+    through an LDS ring and staging the channel blocks of the halo tile, compute waves that never wait at a barrier) against the
+    conv_mfma_kernel instances it replaces (PSEG_NO_SP): same packing, same k order, same start value -- the same bits in the
+    logits, the labels and every tensor these layers write, on one-tile pages, ragged edges, several tiles per workgroup and six
+    classes.  PSEG_SP_ALL routes every eligible layer to it (the release picks per layer and page size); PSEG_SP_CHECK turns a
+    counter wait that gave up -- the kernel's polling loops are bounded -- into an error instead of a wrong result."""
+    from pseg_amd import synth
+    img = synth.synth_page(9, shape[0], shape[1], C)[0] if min(shape) >= 64 else np.random.default_rng(9).integers(0, 256, shape, dtype=np.uint8)
+    res = []
+    for env in ({"PSEG_SP_ALL": "1", "PSEG_SP_CHECK": "1"}, {"PSEG_SP_CHECK": "1"}, {"PSEG_NO_SP": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
+        e.set_weights(synth.glorot_weights(e.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+        z, _, l = e.predict(img, want_probs=False)
+        z2, _, l2 = e.predict(img, want_probs=False)      # (a second page through the same engine: plans, counters and rings start over)
+        assert np.array_equal(z, z2) and np.array_equal(l, l2)
+        acts = [z, l]
+        for name in ("conv2d_4", "conv2d_5", "conv2d_6", "conv2d_transpose_1", "conv2d_transpose_2"):
+            try:
+                acts.append(e.activation(name))
+            except Exception:
+                acts.append(None)                         # (fused away in this graph: the same in every run)
+        res.append(acts)
+        e.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert np.array_equal(a, b)
+    assert np.abs(res[0][0]).max() > 0
+
+
 @pytest.mark.parametrize("arch,shape", [("fcn_skip", (300, 420)), ("unet", (96, 160)), ("res_unet", (70, 50)), ("fcn", (1056, 1000))])
 def test_bf16_epilogue_store_patch_is_bit_identical(gpu, monkeypatch, arch, shape):
     """The conv epilogue's stores through LDS (packed tiles written into a patch laid out like the tensor, read back as

@@ -47,6 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--width", type=int, default=1536)
+    ap.add_argument("--page-by-page", action="store_true", help="with --pages > 1: one pseg_predict_device call per page instead of pseg_predict_pages_device (A/B)")
     ap.add_argument("--pages", type=int, default=None, help="pages per rank per step (default: 1 at --gpus 1 = configs[1]; 32 at --gpus N > 1 = configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.* legs (host path, unet, configs[4], label-exact)")
@@ -406,12 +407,15 @@ def run_rank(args):
     eng.set_weights(weights)
 
     # synthetic pages, resident in HBM before the timed region (page index = global page id)
-    pages, host_pages = [], []
+    host_pages = []
     for p in range(args.pages):
         img, _, _ = synth.synth_page(rank * args.pages + p, H, W, C)
         host_pages.append(img)
-        pages.append(torch.from_numpy(img).to(dev))
-    labels = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(args.pages)]
+    # one behind the other, as pseg_predict_pages_device takes them (lib/predictor.py:27-30's page loop as one call)
+    d_pages = torch.from_numpy(np.stack(host_pages)).to(dev)
+    d_labels = torch.empty((args.pages, H, W), dtype=torch.uint8, device=dev)
+    pages = [d_pages[p] for p in range(args.pages)]
+    labels = [d_labels[p] for p in range(args.pages)]
     # the hot path is launched on a stream of this process's own (torch's default stream has the raw handle 0, which
     # the library reads as "the engine's stream"): the per-step torch events below are recorded on the same stream
     tstream = torch.cuda.Stream(dev)
@@ -419,6 +423,9 @@ def run_rank(args):
     stream = tstream.cuda_stream
 
     def step():
+        if args.pages > 1 and not args.page_by_page:
+            eng.predict_pages_device(d_pages.data_ptr(), args.pages, H, W, d_labels_u8=d_labels.data_ptr(), stream=stream)
+            return
         for img_t, lab_t in zip(pages, labels):
             eng.predict_device(img_t.data_ptr(), H, W, d_labels_u8=lab_t.data_ptr(), stream=stream)
 
@@ -545,7 +552,8 @@ def run_rank(args):
             "data": "synthetic pages (numpy default_rng(1000+i)), glorot random-init weights (default_rng(42))",
             "config": {"workload": (("configs[1]: single %dx%d page, %d-class %s predict" % (H, W, C, args.arch)) if world == 1 and args.pages == 1 else
                                     ("configs[2] shape: %d independent %dx%d pages per rank per step, %d-class %s predict, page-parallel, "
-                                     "no data-path collective" % (args.pages, H, W, C, args.arch)))
+                                     "no data-path collective, %s" % (args.pages, H, W, C, args.arch,
+                                     "one pseg_predict_device call per page" if args.page_by_page else "one pseg_predict_pages_device call per step (page slots: the low-resolution layers take all pages of a unit in one launch)")))
                                    + ", inputs resident in HBM, uint8 label maps left in HBM (value = HBM-resident rate per the measurement "
                                      "contract; SURVEY 8d's pinned-host-in / host-out rate is value_host_path)",
                        "pages_per_rank_per_step": args.pages, "parallelism": "page-parallel x%d" % world},

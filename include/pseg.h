@@ -94,9 +94,19 @@ int pseg_predict(pseg_engine* e, const uint8_t* img, int H, int W, float* logits
 int pseg_predict_device(pseg_engine* e, const uint8_t* d_img, int H, int W, float* d_logits,
                         float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8, void* stream);
 
+/* Predictor.predict's page loop (lib/predictor.py:27-30) for n_pages pages of ONE shape that are resident on the device:
+ * d_imgs = the pages one behind the other (n_pages * H * W * in_channels bytes), d_labels / d_labels_u8 = the label maps
+ * one behind the other (either may be NULL).  bf16 fcn / fcn_skip engines keep a page slot per page in every activation
+ * tensor and give the low-resolution layers all slots in one launch (a page alone leaves them a partly filled chip); any
+ * other engine runs the pages one after the other.  Each map equals pseg_predict_device's for that page.  Asynchronous
+ * on `stream`. */
+int pseg_predict_pages_device(pseg_engine* e, const uint8_t* d_imgs, int n_pages, int H, int W, int64_t* d_labels,
+                              uint8_t* d_labels_u8, void* stream);
+
 /* Predictor.predict (lib/predictor.py:27-30): label maps of a list of pages of individual sizes.
  * The upload of page i+1 and the download of page i-1 overlap the compute of page i (two staging
- * slots, separate copy streams).  labels[i] (int64, H[i]*W[i]) and/or labels_u8[i]; either array may
+ * slots, separate copy streams); runs of consecutive pages of one shape travel and compute as a unit (up to 8 pages,
+ * pseg_predict_pages_device).  labels[i] (int64, H[i]*W[i]) and/or labels_u8[i]; either array may
  * be NULL, not both.  Host pointers; returns when every page is back. */
 int pseg_predict_batch(pseg_engine* e, int n_pages, const uint8_t* const* imgs, const int* H,
                        const int* W, int64_t* const* labels, uint8_t* const* labels_u8);

@@ -89,8 +89,10 @@ struct Tensor {
     int s = 0;          // log2 down-scale relative to the padded canvas
     int C = 0;          // true channel count
     int Cs = 0;         // storage channels: C (f32 mode) or round_up(C, 8) (bf16 mode)
-    void* d = nullptr;  // device buffer, NHWC, (Hp>>s) x (Wp>>s) x Cs
-    size_t bytes = 0;
+    void* d = nullptr;  // device buffer, NHWC, (Hp>>s) x (Wp>>s) x Cs -- of the page slot in use (Engine::pages slots; slot 0 = base)
+    void* base = nullptr;       // the allocation: `pages` slots of page_bytes each (bf16 page batches), d == base outside a per-page run
+    size_t page_bytes = 0;      // bytes of one page slot at the current canvas
+    size_t bytes = 0;           // bytes allocated
     bool fused = false; // bf16 mode: never written to HBM (lives only inside a fused kernel)
     bool relu_stored = false;   // bf16 mode: stored after the pre-activation ReLU of its readers (mfma_plan_graph)
 };
@@ -174,6 +176,9 @@ struct Engine {
     int input_tensor = 0;
     // canvas
     int H = 0, W = 0, Hp = 0, Wp = 0;
+    int pages = 1;                 // page slots every activation tensor has room for (bf16 page batches: pseg_predict_batch)
+    int page = 0;                  // page slot the per-page launches of a batch run are working on
+    int batch_pages = 0;           // > 1 while a launch covers that many page slots at once (a tile index carries the page)
     bool weights_dirty = true;
     bool exact_dirty = true;       // label-exact mode: the float32 companion's weights / the calibrated threshold are stale
     float* d_lut = nullptr;        // 256-entry u/255 table (f32)
@@ -278,7 +283,8 @@ int create_engine(int arch, int n_classes, int in_channels, int device, int mode
 void exact_free(Engine& e);
 void chain_free(Engine& e);
 void dist_free(Engine& e);                      // RCCL communicator (pseg_dist.hip)                     // Predictor chain buffers (pseg_chain.hip)                     // label-exact mode state (pseg_exactlabels.hip)
-int set_canvas(Engine& e, int H, int W, hipStream_t st);
+int set_canvas(Engine& e, int H, int W, hipStream_t st, int pages = 1);
+bool mfma_op_batchable(const Engine& e, const Op& op);      // the op's kernel takes several page slots in one launch
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs, int64_t* d_labels,
               uint8_t* d_labels_u8, hipStream_t st);
 // training state (pseg_train.hip)

@@ -518,12 +518,13 @@ int upload_weights(Engine& e) {
     return PSEG_OK;
 }
 
-int set_canvas(Engine& e, int H, int W, hipStream_t st) {
+int set_canvas(Engine& e, int H, int W, hipStream_t st, int pages) {
     if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
     const int Hp = round_up(H, 32), Wp = round_up(W, 32);
     e.H = H;
     e.W = W;
-    if (Hp == e.Hp && Wp == e.Wp) return PSEG_OK;
+    if (Hp == e.Hp && Wp == e.Wp && pages <= e.pages) return PSEG_OK;
+    pages = std::max(pages, Hp == e.Hp && Wp == e.Wp ? e.pages : 1);
     // A canvas change re-allocates and clears the activation tensors.  Work of earlier calls may still be in
     // flight on the engine's (non-blocking) stream or on a caller's stream: drain the device first, and clear on
     // the stream the coming kernels run on -- a hipMemset on the null stream is NOT ordered with non-blocking
@@ -533,6 +534,7 @@ int set_canvas(Engine& e, int H, int W, hipStream_t st) {
         // the throughput kernels address every tensor through 32-bit buffer descriptors / offsets (out-of-range reads give
         // zeros, out-of-range stores are dropped -- silently wrong labels, not a fault): refuse canvases whose largest
         // tensor, or the 16 B/px skip-logits / margin planes, reach 4 GiB (unet: 64 bf16 channels -> about 5790 x 5790)
+        // (per page slot: every launch, also one over several slots, builds its descriptors on the slot's own base)
         size_t worst = (size_t)Hp * Wp * 16 * 4;
         for (auto& t : e.tensors) worst = std::max(worst, (size_t)(Hp >> t.s) * (Wp >> t.s) * t.Cs * esz);
         if (worst >= ((size_t)1 << 32))
@@ -542,14 +544,17 @@ int set_canvas(Engine& e, int H, int W, hipStream_t st) {
     PSEG_HIP(hipDeviceSynchronize());
     e.Hp = Hp;
     e.Wp = Wp;
+    e.pages = pages;
     for (auto& t : e.tensors) {
-        const size_t bytes = (size_t)e.tH(t) * e.tW(t) * t.Cs * esz;
+        t.page_bytes = (size_t)e.tH(t) * e.tW(t) * t.Cs * esz;
+        const size_t bytes = t.page_bytes * pages;
         if (bytes > t.bytes) {
-            free_dev(t.d);
+            free_dev(t.base);
             t.bytes = 0;
-            PSEG_HIP(hipMalloc(&t.d, bytes));
+            PSEG_HIP(hipMalloc(&t.base, bytes));
             t.bytes = bytes;
         }
+        t.d = t.base;
         // float32 mode: fresh buffers start at zero; bf16 mode: the pad channels no kernel writes must read as
         // zero after every layout change
         if (t.d && bytes) PSEG_HIP(hipMemsetAsync(t.d, 0, bytes, st));
@@ -812,6 +817,89 @@ static int run_bf16(Engine& e, const uint8_t* d_img, float* d_logits, float* d_p
     return PSEG_OK;
 }
 
+// `n` pages of one shape (contiguous in d_imgs, label maps contiguous in d_labels / d_labels_u8) through the bf16 graph with every
+// activation tensor holding n page slots (lib/predictor.py:27-30 is a loop over pages; configs[2] = 32 per rank).  Layers whose
+// kernel walks tiles of several slots take the whole batch in one launch -- at 1/4 and 1/8 resolution a page has 768 / 192 tiles
+// for 256 CUs: a launch of one page ends in a partly filled round, starts with every workgroup fetching its first tile at once
+// and, at 1/8 resolution, leaves a quarter of the chip idle -- the others run page by page on the slot's pointers.  Runs of
+// per-page layers go page-major (a page's tensors stay in the caches between its layers), batched layers layer-major.
+static int run_bf16_pages(Engine& e, const uint8_t* d_imgs, int n, int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st) {
+    const size_t npx = (size_t)e.H * e.W;
+    e.cur_margin = nullptr;
+    e.margin_done = false;
+    e.cur_logits = nullptr;
+    e.cur_probs = nullptr;
+    auto slot = [&](int p) {
+        for (auto& t : e.tensors) t.d = t.base ? (char*)t.base + (size_t)p * t.page_bytes : nullptr;
+        e.page = p;
+        e.cur_labels = d_labels ? d_labels + (size_t)p * npx : nullptr;
+        e.cur_labels_u8 = d_labels_u8 ? d_labels_u8 + (size_t)p * npx : nullptr;
+    };
+    auto launch = [&](Op& op) -> int {
+        hipEvent_t ev0;
+        PSEG_TRY(time_begin(e, op, st, &ev0));
+        switch (op.type) {
+            case OP_CONV: PSEG_TRY(mfma_launch_conv(e, op, st)); break;
+            case OP_DECONV2: PSEG_TRY(mfma_launch_deconv2(e, op, st)); break;
+            case OP_POOL: PSEG_TRY(mfma_launch_pool(e, op, st)); break;
+            default: return fail(PSEG_EUNSUPPORTED, "page batches run the fcn / fcn_skip graphs (layer %s)", op.layer.c_str());
+        }
+        PSEG_HIP(hipGetLastError());
+        return time_end(e, op, st, ev0);
+    };
+    int rc = PSEG_OK;
+    std::vector<Op*> live;
+    for (auto& op : e.ops)
+        if (!op.fused_away) live.push_back(&op);
+    for (size_t i = 0; i < live.size() && rc == PSEG_OK;) {
+        if (mfma_op_batchable(e, *live[i])) {
+            slot(0);
+            e.batch_pages = n;
+            rc = launch(*live[i]);
+            e.batch_pages = 0;
+            ++i;
+            continue;
+        }
+        size_t j = i;
+        while (j < live.size() && !mfma_op_batchable(e, *live[j])) ++j;
+        for (int p = 0; p < n && rc == PSEG_OK; ++p) {
+            slot(p);
+            rc = mfma_preprocess(e, d_imgs + (size_t)p * npx * e.in_ch, st);     // (sets the page the fused first layer reads)
+            for (size_t k = i; k < j && rc == PSEG_OK; ++k) rc = launch(*live[k]);
+        }
+        i = j;
+    }
+    slot(0);
+    e.cur_labels = nullptr;
+    e.cur_labels_u8 = nullptr;
+    return rc;
+}
+
+// pseg_predict_batch's device leg for a group of same-shape pages
+int predict_device_pages(Engine& e, const uint8_t* d_imgs, int n, int H, int W, int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st) {
+    PSEG_HIP(hipSetDevice(e.device));
+    for (auto& p : e.params)
+        if (!p.set) return fail(PSEG_EINVAL, "weight '%s' was never set", p.name.c_str());
+    if (e.weights_dirty) PSEG_TRY(upload_weights(e));
+    PSEG_TRY(set_canvas(e, H, W, st, n));
+    return run_bf16_pages(e, d_imgs, n, d_labels, d_labels_u8, st);
+}
+
+// true when this engine's graph can run page batches (run_bf16_pages): bf16 mode, every live layer a conv / transposed conv of
+// the fcn family whose first layer is fused (no separate pre-process pass, no stand-alone logits layer)
+bool pages_capable(Engine& e) {
+    if (e.mode != PSEG_MODE_BF16 || e.in_ch != 1 || PSEG_KNOB("PSEG_NO_PAGE_BATCH")) return false;
+    if (e.weights_dirty) return false;        // (plans exist after the first upload: the caller's first page goes alone)
+    bool any = false;
+    for (auto& op : e.ops) {
+        if (op.fused_away) continue;
+        if (op.type != OP_CONV && op.type != OP_DECONV2) return false;
+        if (op.src0 == e.input_tensor && op.fuse1 < 0) return false;
+        any |= mfma_op_batchable(e, op);
+    }
+    return any;
+}
+
 int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* d_logits,
                    float* d_probs, int64_t* d_labels, uint8_t* d_labels_u8,
                    hipStream_t st, float* d_margin) {
@@ -881,6 +969,9 @@ static void batch_free(Engine& e) {
     e.batch = nullptr;
 }
 
+int predict_device_pages(Engine& e, const uint8_t* d_imgs, int n, int H, int W, int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st);
+bool pages_capable(Engine& e);
+
 static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int* H, const int* W,
                          int64_t* const* labels, uint8_t* const* labels_u8) {
     PSEG_HIP(hipSetDevice(e.device));
@@ -896,6 +987,9 @@ static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int
         }
     }
     auto* b = (BatchState*)e.batch;
+    for (auto& p : e.params)
+        if (!p.set) return fail(PSEG_EINVAL, "weight '%s' was never set", p.name.c_str());
+    if (e.weights_dirty) PSEG_TRY(upload_weights(e));      // (the plans decide whether pages travel as units)
     for (int i = 0; i < n; ++i) {
         if (H[i] <= 0 || W[i] <= 0 || !imgs[i] || (labels && !labels[i]) || (labels_u8 && !labels_u8[i]))
             return fail(PSEG_EINVAL, "page %d: empty shape or NULL buffer", i);
@@ -905,84 +999,107 @@ static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int
         in_pinned[i] = is_pinned(imgs[i]);
         out_pinned[i] = (!labels || is_pinned(labels[i])) && (!labels_u8 || is_pinned(labels_u8[i]));
     }
-    auto upload = [&](int i) -> int {        // page i -> slot i % 2 (its previous compute has been waited for)
-        const int s = i & 1;
-        const size_t npx = (size_t)H[i] * W[i];
-        PSEG_TRY(ensure((void**)&b->d_img[s], &b->img_bytes[s], npx * e.in_ch));
-        PSEG_TRY(ensure(&b->d_lab[s], &b->lab_bytes[s], npx * (labels ? 8 : 0) + npx * (labels_u8 ? 1 : 0) + 16));
+    // Units: runs of consecutive pages of one shape go through the graph together (run_bf16_pages: every tensor holds a page slot
+    // per page of the unit, the low-resolution layers take all slots in one launch); everything else is a unit of one page.
+    // PSEG_BATCH_PAGES caps a unit (default 8: 7 GB of activations at 2048x1536; 1 = page by page as before).
+    int cap = 8;
+    if (const char* ev = PSEG_KNOB("PSEG_BATCH_PAGES")) cap = std::max(1, std::min(64, atoi(ev)));
+    if (!pages_capable(e)) cap = 1;
+    std::vector<int> ub, ug;                 // first page, page count of every unit
+    for (int i = 0; i < n;) {
+        int g = 1;
+        while (g < cap && i + g < n && H[i + g] == H[i] && W[i + g] == W[i]) ++g;
+        ub.push_back(i); ug.push_back(g);
+        i += g;
+    }
+    const int nu = (int)ub.size();
+    auto upx = [&](int u) { return (size_t)H[ub[u]] * W[ub[u]]; };
+    auto lab_off8 = [&](int u, int k) { return (size_t)k * upx(u) * 8; };                                   // int64 map of page k of the unit
+    auto lab_off1 = [&](int u, int k) { return (labels ? (size_t)ug[u] * upx(u) * 8 : 0) + (size_t)k * upx(u); };   // its uint8 map
+    auto unit_out_bytes = [&](int u) { return (size_t)ug[u] * upx(u) * ((labels ? 8 : 0) + (labels_u8 ? 1 : 0)); };
+    auto unit_pinned = [&](int u, const std::vector<char>& v) { bool all = true; for (int k = 0; k < ug[u]; ++k) all = all && v[ub[u] + k]; return all; };
+    auto upload = [&](int u) -> int {        // unit u -> slot u % 2 (its previous compute has been waited for)
+        const int s = u & 1;
+        const size_t npx = upx(u), pb = npx * e.in_ch;
+        PSEG_TRY(ensure((void**)&b->d_img[s], &b->img_bytes[s], pb * ug[u]));
+        PSEG_TRY(ensure(&b->d_lab[s], &b->lab_bytes[s], unit_out_bytes(u) + 16));
         PSEG_HIP(hipStreamWaitEvent(b->s_in, b->done[s], 0));      // slot input consumed (no-op before first record)
-        const uint8_t* src = imgs[i];
-        if (!in_pinned[i]) {
-            // the ring slot was last read by the upload of page i-2, recorded in up[s]
+        const bool pinned = unit_pinned(u, in_pinned);
+        if (!pinned) {
+            // the ring slot was last read by the upload of unit u-2, recorded in up[s]
             PSEG_HIP(hipEventSynchronize(b->up[s]));
-            PSEG_TRY(ensure_pinned(&b->h_in[s], &b->h_in_bytes[s], npx * e.in_ch));
-            memcpy(b->h_in[s], imgs[i], npx * e.in_ch);
-            src = b->h_in[s];
+            PSEG_TRY(ensure_pinned(&b->h_in[s], &b->h_in_bytes[s], pb * ug[u]));
+            for (int k = 0; k < ug[u]; ++k) memcpy(b->h_in[s] + (size_t)k * pb, imgs[ub[u] + k], pb);
+            PSEG_HIP(hipMemcpyAsync(b->d_img[s], b->h_in[s], pb * ug[u], hipMemcpyHostToDevice, b->s_in));
+        } else {
+            for (int k = 0; k < ug[u]; ++k)
+                PSEG_HIP(hipMemcpyAsync(b->d_img[s] + (size_t)k * pb, imgs[ub[u] + k], pb, hipMemcpyHostToDevice, b->s_in));
         }
-        PSEG_HIP(hipMemcpyAsync(b->d_img[s], src, npx * e.in_ch, hipMemcpyHostToDevice, b->s_in));
         PSEG_HIP(hipEventRecord(b->up[s], b->s_in));
         return PSEG_OK;
     };
-    auto compute = [&](int i) -> int {
-        const int s = i & 1;
-        const size_t npx = (size_t)H[i] * W[i];
-        // a canvas change re-allocates / clears the activation tensors: the previous page must have left them
-        if (round_up(H[i], 32) != e.Hp || round_up(W[i], 32) != e.Wp) PSEG_HIP(hipStreamSynchronize(e.stream));
+    auto compute = [&](int u) -> int {
+        const int s = u & 1, i0 = ub[u];
+        // a canvas change re-allocates / clears the activation tensors: the previous unit must have left them
+        if (round_up(H[i0], 32) != e.Hp || round_up(W[i0], 32) != e.Wp || ug[u] > e.pages) PSEG_HIP(hipStreamSynchronize(e.stream));
         PSEG_HIP(hipStreamWaitEvent(e.stream, b->up[s], 0));
-        PSEG_HIP(hipStreamWaitEvent(e.stream, b->down[s], 0));      // slot output of page i-2 has left
+        PSEG_HIP(hipStreamWaitEvent(e.stream, b->down[s], 0));      // slot output of unit u-2 has left
         int64_t* dl = labels ? (int64_t*)b->d_lab[s] : nullptr;
-        uint8_t* du = labels_u8 ? (uint8_t*)b->d_lab[s] + (labels ? npx * 8 : 0) : nullptr;
-        PSEG_TRY(predict_device(e, b->d_img[s], H[i], W[i], nullptr, nullptr, dl, du, e.stream, nullptr));
+        uint8_t* du = labels_u8 ? (uint8_t*)b->d_lab[s] + lab_off1(u, 0) : nullptr;
+        if (ug[u] > 1) PSEG_TRY(predict_device_pages(e, b->d_img[s], ug[u], H[i0], W[i0], dl, du, e.stream));
+        else PSEG_TRY(predict_device(e, b->d_img[s], H[i0], W[i0], nullptr, nullptr, dl, du, e.stream, nullptr));
         PSEG_HIP(hipEventRecord(b->done[s], e.stream));
         return PSEG_OK;
     };
-    auto download = [&](int i) -> int {
-        const int s = i & 1;
-        const size_t npx = (size_t)H[i] * W[i];
+    auto download = [&](int u) -> int {
+        const int s = u & 1;
+        const size_t npx = upx(u);
         PSEG_HIP(hipStreamWaitEvent(b->s_out, b->done[s], 0));
-        if (out_pinned[i]) {
-            if (labels) PSEG_HIP(hipMemcpyAsync(labels[i], b->d_lab[s], npx * 8, hipMemcpyDeviceToHost, b->s_out));
-            if (labels_u8)
-                PSEG_HIP(hipMemcpyAsync(labels_u8[i], (uint8_t*)b->d_lab[s] + (labels ? npx * 8 : 0), npx, hipMemcpyDeviceToHost, b->s_out));
-        } else {   // both maps in one DMA into the ring slot (its previous content was copied out by finish(i - 2))
-            const size_t nb = npx * (labels ? 8 : 0) + npx * (labels_u8 ? 1 : 0);
-            PSEG_TRY(ensure_pinned(&b->h_out[s], &b->h_out_bytes[s], nb));
-            PSEG_HIP(hipMemcpyAsync(b->h_out[s], b->d_lab[s], nb, hipMemcpyDeviceToHost, b->s_out));
+        if (unit_pinned(u, out_pinned)) {
+            for (int k = 0; k < ug[u]; ++k) {
+                if (labels) PSEG_HIP(hipMemcpyAsync(labels[ub[u] + k], (uint8_t*)b->d_lab[s] + lab_off8(u, k), npx * 8, hipMemcpyDeviceToHost, b->s_out));
+                if (labels_u8) PSEG_HIP(hipMemcpyAsync(labels_u8[ub[u] + k], (uint8_t*)b->d_lab[s] + lab_off1(u, k), npx, hipMemcpyDeviceToHost, b->s_out));
+            }
+        } else {   // all maps of the unit in one DMA into the ring slot (its previous content was copied out by finish(u - 2))
+            PSEG_TRY(ensure_pinned(&b->h_out[s], &b->h_out_bytes[s], unit_out_bytes(u)));
+            PSEG_HIP(hipMemcpyAsync(b->h_out[s], b->d_lab[s], unit_out_bytes(u), hipMemcpyDeviceToHost, b->s_out));
         }
         PSEG_HIP(hipEventRecord(b->down[s], b->s_out));
         return PSEG_OK;
     };
-    auto finish = [&](int i) -> int {        // pageable destination: ring slot -> caller's arrays, on the calling thread
-        if (out_pinned[i]) return PSEG_OK;
-        const int s = i & 1;
-        const size_t npx = (size_t)H[i] * W[i];
+    auto finish = [&](int u) -> int {        // pageable destination: ring slot -> caller's arrays, on the calling thread
+        if (unit_pinned(u, out_pinned)) return PSEG_OK;
+        const int s = u & 1;
+        const size_t npx = upx(u);
         PSEG_HIP(hipEventSynchronize(b->down[s]));
-        if (labels) memcpy(labels[i], b->h_out[s], npx * 8);
-        if (labels_u8) memcpy(labels_u8[i], b->h_out[s] + (labels ? npx * 8 : 0), npx);
+        for (int k = 0; k < ug[u]; ++k) {
+            if (labels) memcpy(labels[ub[u] + k], b->h_out[s] + lab_off8(u, k), npx * 8);
+            if (labels_u8) memcpy(labels_u8[ub[u] + k], b->h_out[s] + lab_off1(u, k), npx);
+        }
         return PSEG_OK;
     };
-    // a reallocation of a slot must not race with work still using it: drain when sizes grow
-    size_t max_px = 0;
-    for (int i = 0; i < n; ++i) max_px = std::max(max_px, (size_t)H[i] * W[i]);
+    // a reallocation of a slot must not race with work still using it: size every slot for the largest unit up front
+    size_t max_in = 0, max_out = 0;
+    for (int u = 0; u < nu; ++u) { max_in = std::max(max_in, upx(u) * e.in_ch * ug[u]); max_out = std::max(max_out, unit_out_bytes(u)); }
     for (int s = 0; s < 2; ++s) {
-        PSEG_TRY(ensure((void**)&b->d_img[s], &b->img_bytes[s], max_px * e.in_ch));
-        PSEG_TRY(ensure(&b->d_lab[s], &b->lab_bytes[s], max_px * 9 + 16));
+        PSEG_TRY(ensure((void**)&b->d_img[s], &b->img_bytes[s], max_in));
+        PSEG_TRY(ensure(&b->d_lab[s], &b->lab_bytes[s], max_out + 16));
     }
     bool any_in = false, any_out = false;
     for (int i = 0; i < n; ++i) { any_in |= !in_pinned[i]; any_out |= !out_pinned[i]; }
     for (int s = 0; s < 2 && (any_in || any_out); ++s) {
         PSEG_HIP(hipEventSynchronize(b->up[s]));
         PSEG_HIP(hipEventSynchronize(b->down[s]));
-        if (any_in) PSEG_TRY(ensure_pinned(&b->h_in[s], &b->h_in_bytes[s], max_px * e.in_ch));
-        if (any_out) PSEG_TRY(ensure_pinned(&b->h_out[s], &b->h_out_bytes[s], max_px * ((labels ? 8 : 0) + (labels_u8 ? 1 : 0))));
+        if (any_in) PSEG_TRY(ensure_pinned(&b->h_in[s], &b->h_in_bytes[s], max_in));
+        if (any_out) PSEG_TRY(ensure_pinned(&b->h_out[s], &b->h_out_bytes[s], max_out));
     }
-    if (n > 0) { PSEG_TRY(upload(0)); PSEG_TRY(compute(0)); }
-    for (int i = 0; i < n; ++i) {
-        if (i + 1 < n) { PSEG_TRY(upload(i + 1)); PSEG_TRY(compute(i + 1)); }
-        PSEG_TRY(download(i));
-        if (i > 0) PSEG_TRY(finish(i - 1));
+    if (nu > 0) { PSEG_TRY(upload(0)); PSEG_TRY(compute(0)); }
+    for (int u = 0; u < nu; ++u) {
+        if (u + 1 < nu) { PSEG_TRY(upload(u + 1)); PSEG_TRY(compute(u + 1)); }
+        PSEG_TRY(download(u));
+        if (u > 0) PSEG_TRY(finish(u - 1));
     }
-    if (n > 0) PSEG_TRY(finish(n - 1));
+    if (nu > 0) PSEG_TRY(finish(nu - 1));
     PSEG_HIP(hipStreamSynchronize(b->s_out));
     PSEG_HIP(hipStreamSynchronize(e.stream));
     return PSEG_OK;
@@ -1076,7 +1193,7 @@ int pseg_destroy(pseg_engine* h) {
     exact_free(e);
     chain_free(e);
     batch_free(e);
-    for (auto& t : e.tensors) free_dev(t.d);
+    for (auto& t : e.tensors) { free_dev(t.base); t.d = nullptr; }
     for (auto& op : e.ops) {
         free_dev((void*&)op.d_w);
         free_dev((void*&)op.d_b);
@@ -1152,6 +1269,33 @@ int pseg_predict_device(pseg_engine* h, const uint8_t* d_img, int H, int W, floa
     KnobScope knob_scope(h->e);
     hipStream_t st = stream ? (hipStream_t)stream : h->e.stream;
     return predict_device(h->e, d_img, H, W, d_logits, d_probs, d_labels, d_labels_u8, st, nullptr);
+}
+
+int pseg_predict_pages_device(pseg_engine* h, const uint8_t* d_imgs, int n, int H, int W, int64_t* d_labels, uint8_t* d_labels_u8, void* stream) {
+    if (!h || !d_imgs || n < 1 || (!d_labels && !d_labels_u8)) return fail(PSEG_EINVAL, "NULL argument / no pages");
+    KnobScope knob_scope(h->e);
+    Engine& e = h->e;
+    hipStream_t st = stream ? (hipStream_t)stream : e.stream;
+    if (H <= 0 || W <= 0) return fail(PSEG_EINVAL, "empty page %dx%d", H, W);
+    PSEG_HIP(hipSetDevice(e.device));
+    for (auto& p : e.params)
+        if (!p.set) return fail(PSEG_EINVAL, "weight '%s' was never set", p.name.c_str());
+    if (e.weights_dirty) PSEG_TRY(upload_weights(e));
+    const size_t npx = (size_t)H * W;
+    if (n > 1 && pages_capable(e)) {
+        int cap = 16;                         // page slots per unit of a device-resident batch (14 GB of activations at 2048x1536; 8 and 16 measure alike)
+        if (const char* ev = PSEG_KNOB("PSEG_BATCH_PAGES")) cap = std::max(1, std::min(64, atoi(ev)));
+        for (int i = 0; i < n; i += cap) {
+            const int g = std::min(cap, n - i);
+            PSEG_TRY(predict_device_pages(e, d_imgs + (size_t)i * npx * e.in_ch, g, H, W, d_labels ? d_labels + (size_t)i * npx : nullptr,
+                                          d_labels_u8 ? d_labels_u8 + (size_t)i * npx : nullptr, st));
+        }
+        return PSEG_OK;
+    }
+    for (int i = 0; i < n; ++i)
+        PSEG_TRY(predict_device(e, d_imgs + (size_t)i * npx * e.in_ch, H, W, nullptr, nullptr, d_labels ? d_labels + (size_t)i * npx : nullptr,
+                                d_labels_u8 ? d_labels_u8 + (size_t)i * npx : nullptr, st, nullptr));
+    return PSEG_OK;
 }
 
 int pseg_predict(pseg_engine* h, const uint8_t* img, int H, int W, float* logits, float* probs,

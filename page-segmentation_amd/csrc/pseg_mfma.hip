@@ -231,6 +231,14 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = NW_, NTHR = NW_ * 64;
     constexpr int TH = NW * (MT / 2);  // NW waves x (MT/2) rows
+    if (gridDim.z > 1) {
+        // a launch over several page slots (pseg_predict_batch): blockIdx.z = the slot; only plain layers are launched this way
+        // (sources, output and fused pool -- mfma_op_batchable)
+        a.src0 = (const uint16_t*)((const char*)a.src0 + (size_t)blockIdx.z * a.bytes0);
+        if (a.src1) a.src1 = (const uint16_t*)((const char*)a.src1 + (size_t)blockIdx.z * a.bytes1);
+        a.dst = (uint16_t*)((char*)a.dst + (size_t)blockIdx.z * a.dst_bytes);
+        if (a.pool_dst) a.pool_dst = (uint16_t*)((char*)a.pool_dst + (size_t)blockIdx.z * a.pool_bytes);
+    }
     constexpr bool FIXED = KS_ > 0;
     const int c_stride = FIXED ? ST_ : a.stride;
     const int c_sigma = FIXED ? SG_ : a.sigma;
@@ -3369,7 +3377,9 @@ int mfma_plan_graph(Engine& e) {
                     Tensor c = e.tensors[*sp];
                     c.name += "/relu";
                     c.d = nullptr;
+                    c.base = nullptr;
                     c.bytes = 0;
+                    c.page_bytes = 0;
                     e.tensors.push_back(c);
                     p.relu_dst = (int)e.tensors.size() - 1;
                 }
@@ -4458,15 +4468,15 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         a.out_labels_u8 = e.cur_labels_u8;
     }
     if (op.skiplog >= 0) {
-        const size_t need = (size_t)a.Hout * a.Wout * P->skip_CP * 4;
-        if (need > P->skiplog_bytes) {
-            PSEG_HIP(hipStreamSynchronize(st));
+        const size_t need = (size_t)a.Hout * a.Wout * P->skip_CP * 4;     // one page slot
+        if (need * e.pages > P->skiplog_bytes) {
+            PSEG_HIP(hipDeviceSynchronize());
             (void)hipFree(P->d_skiplog);
             P->d_skiplog = nullptr; P->skiplog_bytes = 0;
-            PSEG_HIP(hipMalloc((void**)&P->d_skiplog, need));
-            P->skiplog_bytes = need;
+            PSEG_HIP(hipMalloc((void**)&P->d_skiplog, need * e.pages));
+            P->skiplog_bytes = need * e.pages;
         }
-        a.skip_logits = P->d_skiplog;
+        a.skip_logits = (float*)((char*)P->d_skiplog + (size_t)e.page * need);
         a.skip_CP = P->skip_CP;
         a.tail_wa = P->d_tail_wa;
     }
@@ -4513,7 +4523,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         // workgroups per CU at best); the 40- / 60-channel layers while a launch is one round of tiles (1024x768: 14.7 / 19.7 / 26.7 vs
         // 19.4 / 25.5 / 37.0) -- with several tiles per CU three co-resident conv_mfma_kernel workgroups (three waves per SIMD, each
         // hiding the others' fragment reads) still beat one compute wave per SIMD by 3-10 %.  PSEG_SP_ALL=1: every eligible layer.
-        const bool sp_pays = P->sp_NT == 5 || (int)grid.x <= cus_sp || PSEG_KNOB("PSEG_SP_ALL");
+        const bool sp_pays = P->sp_NT == 5 || (int)grid.x * (e.batch_pages > 1 ? e.batch_pages : 1) <= cus_sp || PSEG_KNOB("PSEG_SP_ALL");
         SConv c{};
         c.src0 = a.src0; c.src1 = a.src1; c.nch0 = a.nch0; c.nch1 = a.nch1; c.bytes0 = a.bytes0; c.bytes1 = a.bytes1;
         c.Hin = a.Hin; c.Win = a.Win; c.Hout = a.Hout; c.Wout = a.Wout; c.pt = a.pt; c.pl = a.pl; c.relu = a.relu;
@@ -4523,10 +4533,12 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         c.lds_ring_off = P->sp_ring_off; c.lds_patch_off = P->sp_patch_off; c.lds_tab_off = P->sp_tab_off; c.lds_flag_off = P->sp_flag_off;
         c.dst = a.dst; c.dst_bytes = a.dst_bytes; c.nch_out = a.nch_out; c.pool_dst = a.pool_dst; c.pool_bytes = a.pool_bytes;
         c.dq_bias = a.dq_bias; c.dq_dst = a.dq_dst; c.dq_bytes = a.dq_bytes; c.dq_nch = a.dq_nch; c.dq_relu = a.dq_relu;
-        c.ntiles = (int)grid.x; c.tiles_per_page = (int)grid.x; c.xq = a.xq; c.xr = a.xr;
+        const int npg = e.batch_pages > 1 ? e.batch_pages : 1;               // page slots of this launch: a tile index carries the page
+        c.ntiles = (int)grid.x * npg; c.tiles_per_page = (int)grid.x;
+        c.xq = a.xq < 0 ? -1 : c.ntiles / 8; c.xr = c.ntiles % 8;
         c.err = P->d_sp_err;
         c.dbg = PSEG_DIAG_KNOB("PSEG_SP_DBG") ? atoi(PSEG_DIAG_KNOB("PSEG_SP_DBG")) : 0;
-        const dim3 gs((unsigned)std::min<int>((int)grid.x, cus_sp));
+        const dim3 gs((unsigned)std::min<int>(c.ntiles, cus_sp));
         const char* trl = PSEG_KNOB("PSEG_SP_TRACE");
         const bool tracing = sp_pays && trl && op.layer == trl;
         if (tracing) {
@@ -4667,7 +4679,22 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         a.ntiles = (int)grid.x;
         grid.x = std::min<unsigned>(grid.x, 2u * (unsigned)cus);
     }
+    if (e.batch_pages > 1) grid.z = (unsigned)e.batch_pages;   // (mfma_op_batchable layers only: the page slot is blockIdx.z)
     return launch_generic_any(a, *P, grid, st, op.layer.c_str());
+}
+
+// Layers whose kernel takes all page slots of a batch in ONE launch (run_bf16_pages): conv_sp_kernel (a tile index carries
+// the page) and the plain conv_mfma_kernel instances (blockIdx.z = page slot; sources, output and fused pool only).  The
+// others -- the fused first layers, the ping-pong kernel, the tails -- are launched once per page slot.
+bool mfma_op_batchable(const Engine& e, const Op& op) {
+    auto* P = (MfmaPlan*)op.plan;
+    if (!P || P->kind != PLAN_GENERIC || op.type != OP_CONV || PSEG_KNOB("PSEG_NO_PAGE_LAUNCH")) return false;
+    if (op.add >= 0 || op.relu_dst >= 0 || op.fuse1 >= 0 || op.tail_logits >= 0 || op.skiplog >= 0 || op.in_relu || op.up0 || op.up1 ||
+        op.src0 == e.input_tensor || op.src1 == e.input_tensor)
+        return false;
+    if (P->pp) return false;
+    if (op.dq_fuse >= 0) return P->sp && (P->sp_fl & SP_DQ) != 0;
+    return true;
 }
 
 int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
@@ -4700,7 +4727,7 @@ int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st) {
                 if (sp >= 0 && e.ops[sp].skiplog >= 0) {
                     auto* PS = (MfmaPlan*)e.ops[sp].plan;
                     if (!PS || !PS->d_skiplog || PS->skip_CP != P->tc_CP) return fail(PSEG_EINVAL, "skip-logits buffer missing for the composed tail");
-                    t.S = PS->d_skiplog;
+                    t.S = (const float*)((const char*)PS->d_skiplog + (size_t)e.page * ((size_t)e.Hp * e.Wp * PS->skip_CP * 4));   // this page slot's plane
                     t.skip = nullptr;
                 }
             }

@@ -58,6 +58,51 @@ def test_config2_one_rank_share_32_full_size_pages(gpu):
     eng.close()
 
 
+@pytest.mark.parametrize("arch,C", [("fcn_skip", 3), ("fcn", 3), ("fcn_skip", 6), ("unet", 3)])
+def test_page_units_equal_page_by_page(gpu, monkeypatch, arch, C):
+    """Page slots (pseg_predict_pages_device; the units of pseg_predict_batch): every activation tensor holds one slot per page of a
+    unit, the low-resolution layers take all slots in one launch (conv_sp_kernel: the tile index carries the page; conv_mfma_kernel:
+    the slot is blockIdx.z), the others run per slot -- each label map must be the one pseg_predict_device gives for that page.
+    Ragged shapes (pad-to-32 canvases), one-tile pages, a list that mixes shapes (units break at a shape change), uint8 and
+    int64 maps, a unit size that does not divide the list, a graph without page support (unet: falls back to a page loop)."""
+    import torch
+    rng = np.random.default_rng(11)
+    monkeypatch.setenv("PSEG_SP_CHECK", "1")
+    monkeypatch.setenv("PSEG_BATCH_PAGES", "3")
+    eng = gpu.Engine(arch, C, mode=gpu.MODE_BF16)
+    from pseg_amd import synth
+    eng.set_weights(synth.glorot_weights(eng.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    def one(p):
+        d = torch.from_numpy(np.ascontiguousarray(p)).to(dev)
+        lab = torch.empty(p.shape, dtype=torch.uint8, device=dev)
+        eng.predict_device(d.data_ptr(), p.shape[0], p.shape[1], d_labels_u8=lab.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        return lab.cpu().numpy()
+    for (H, W), n in (((130, 67), 7), ((300, 420), 5), ((33, 1), 4), ((512, 384), 2)):
+        pages = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+        want = [one(pages[i]) for i in range(n)]
+        d = torch.from_numpy(pages).to(dev)
+        out8 = torch.zeros((n, H, W), dtype=torch.uint8, device=dev)
+        out64 = torch.zeros((n, H, W), dtype=torch.int64, device=dev)
+        eng.predict_pages_device(d.data_ptr(), n, H, W, d_labels=out64.data_ptr(), d_labels_u8=out8.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        assert all(np.array_equal(out8[i].cpu().numpy(), want[i]) for i in range(n))
+        assert all(np.array_equal(out64[i].cpu().numpy(), want[i]) for i in range(n))
+    # a list of mixed shapes through the host entry: units of <= 3 same-shape neighbours
+    shapes = [(96, 80)] * 4 + [(130, 67)] + [(96, 80)] * 2 + [(64, 64)] * 3
+    pages = [rng.integers(0, 256, s_, dtype=np.uint8) for s_ in shapes]
+    want = [one(p) for p in pages]
+    got = eng.predict_batch(pages, dtype=np.uint8)
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    got = eng.predict_batch(pages, dtype=np.int64)
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    # ... and a single page afterwards still goes through the one-slot path with the same result
+    assert np.array_equal(one(pages[0]), want[0])
+    eng.close()
+
+
 def test_config3_full_size_train_step_matches_torch_autograd(gpu):
     import oracle
     from oracle import train_ref

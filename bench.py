@@ -481,11 +481,15 @@ def run_rank(args):
     value = total_px / dt / 1e6
 
     if slots:
+        # a launch of the page entry covers several pages (page slots): every figure below is per PAGE -- a slot's time over the
+        # pages of the pass -- so that it compares with the slot's algorithmic FLOPs of one page
+        paged = args.pages > 1 and not args.page_by_page
+        per_page = (lambda s: s[1] / (nroof * args.pages)) if paged else (lambda s: s[1] / s[2])
         name, ms, n, flops = max(slots, key=lambda s: s[1])
-        avg_ms = ms / n
+        avg_ms = per_page((name, ms, n, flops))
         achieved = flops / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.mode]
-        total_ms = sum(s[1] / s[2] for s in slots)
+        total_ms = sum(per_page(s) for s in slots)
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
         # runs, gfx950 correction applied) recorded under profiles/ by tools/pmc_traffic.py -- replayed, not measured here
         traffic, traffic_src = None, None
@@ -507,11 +511,13 @@ def run_rank(args):
                 "whole_net_frac_what": "algorithmic FLOPs of the page / ms_per_step (the timed region); per_kernel_ms is a separate pass "
                                        "with event timing on, whose sum prices whole_net_frac_kernel_sum",
                 "whole_net_frac_kernel_sum": round(eng.flops_per_pixel() * H * W / (total_ms * 1e-3) / 1e12 / peak, 5),
-                "per_kernel_ms": {s[0]: round(s[1] / s[2], 5) for s in slots}}
+                "per_kernel_ms": {s[0]: round(per_page(s), 5) for s in slots}}
+        if paged:
+            roof["per_kernel_ms_what"] = "per page: the layer's time over the pages of the pass (launches of the low-resolution layers cover a unit of pages)"
         ksize = {n.split("/")[0]: sh[0] for n, sh in eng.weight_specs() if n.endswith("kernel")}
         k3 = [s for s in slots if ksize.get(s[0]) == 3 and s[3] > 1e10]
         if k3:
-            roof["conv3x3_stack_frac"] = round(sum(s[3] for s in k3) / (sum(s[1] / s[2] for s in k3) * 1e-3) / 1e12 / peak, 5)
+            roof["conv3x3_stack_frac"] = round(sum(s[3] for s in k3) / (sum(per_page(s) for s in k3) * 1e-3) / 1e12 / peak, 5)
 
     extra = dict(step_stats)
     cpu = None

@@ -246,6 +246,9 @@ int pseg_allreduce_unique_id(uint8_t id[128]);
 int pseg_allreduce_init(pseg_engine* e, int rank, int world, const uint8_t id[128]);
 int pseg_train_allreduce(pseg_engine* e);
 int pseg_allreduce_destroy(pseg_engine* e);
+/* 1 when the build pinned the dlopen'ed RCCL entry points (ncclUniqueId size, ncclFloat32 / ncclSum values, the five prototypes)
+ * against <rccl/rccl.h> with static_asserts, 0 when that header was absent at build time. */
+int pseg_rccl_abi_pinned(void);
 
 /* Clip + Adam update of every parameter with the (scaled) gradients; t += 1. */
 int pseg_train_apply(pseg_engine* e, float lr, float grad_scale);

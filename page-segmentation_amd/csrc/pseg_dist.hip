@@ -12,6 +12,27 @@
 
 #include "pseg_common.h"
 
+// The library is bound by dlopen, so the handful of ABI facts used below (the id's size, two enum values, five prototypes) are
+// restated here by hand -- and pinned against RCCL's own header wherever that header exists at build time (it does in the ROCm
+// image): a change of any of them stops the build instead of surfacing as a wrong reduction on the first N > 1 run.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#include <type_traits>
+static_assert(NCCL_UNIQUE_ID_BYTES == 128 && sizeof(ncclUniqueId) == 128, "pseg_allreduce_unique_id hands out 128 bytes");
+static_assert(ncclSuccess == 0, "a zero return is success");
+static_assert(ncclFloat32 == 7 && ncclSum == 0, "pseg_train_allreduce passes ncclFloat32 / ncclSum as 7 / 0");
+static_assert(sizeof(ncclDataType_t) == sizeof(int) && sizeof(ncclRedOp_t) == sizeof(int) && sizeof(ncclResult_t) == sizeof(int), "enums travel as int");
+static_assert(std::is_pointer<ncclComm_t>::value, "the communicator is kept as a void*");
+static_assert(std::is_same<decltype(&ncclGetUniqueId), ncclResult_t (*)(ncclUniqueId*)>::value, "ncclGetUniqueId");
+static_assert(std::is_same<decltype(&ncclCommInitRank), ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>::value, "ncclCommInitRank");
+static_assert(std::is_same<decltype(&ncclAllReduce), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)>::value, "ncclAllReduce");
+static_assert(std::is_same<decltype(&ncclCommDestroy), ncclResult_t (*)(ncclComm_t)>::value, "ncclCommDestroy");
+static_assert(std::is_same<decltype(&ncclGetErrorString), const char* (*)(ncclResult_t)>::value, "ncclGetErrorString");
+#define PSEG_RCCL_ABI_PINNED 1
+#else
+#define PSEG_RCCL_ABI_PINNED 0
+#endif
+
 namespace pseg {
 
 namespace {
@@ -116,6 +137,9 @@ int pseg_train_allreduce(pseg_engine* h) {
     if (rc != 0) return rccl_fail("ncclAllReduce", rc);
     return PSEG_OK;
 }
+
+/* 1 when this build checked its hand-written RCCL declarations against <rccl/rccl.h> (static_asserts above), else 0 */
+int pseg_rccl_abi_pinned(void) { return PSEG_RCCL_ABI_PINNED; }
 
 int pseg_allreduce_destroy(pseg_engine* h) {
     if (!h) return fail(PSEG_EINVAL, "NULL engine");

@@ -43,6 +43,7 @@ struct ExactState {
     int calib_Hp = 0, calib_Wp = 0;      // canvas the calibration crops were taken from
     int pages_since_calib = 0;
     int fallback_streak = 0, skip_left = 0;   // pages in a row that went through the float32 engine whole / pages left to send there directly
+    int skip_len = 0;                         // length of the last direct stretch: doubles while the probes behind it keep falling back
     float* d_margin = nullptr; size_t margin_bytes = 0;
     uint8_t* d_flags = nullptr; size_t flags_bytes = 0;
     float* d_blockmin = nullptr; size_t blockmin_bytes = 0;
@@ -158,7 +159,7 @@ static int sync_weights(Engine& e, ExactState& x) {
     }
     x.tau = 0.0f;   // recalibrate
     x.margin_err = 0.0f;
-    x.fallback_streak = x.skip_left = 0;
+    x.fallback_streak = x.skip_left = x.skip_len = 0;
     e.exact_dirty = false;
     return PSEG_OK;
 }
@@ -298,9 +299,12 @@ static int exact_labels(Engine& e, const uint8_t* d_img, int H, int W, uint8_t* 
     if (!d_margin) { PSEG_TRY(xensure((void**)&x.d_margin, &x.margin_bytes, npx * 4)); d_margin = x.d_margin; }
     uint8_t* lab = d_labels_u8;
     x.st_flag_px = x.st_blocks = x.st_area = x.st_escal = x.st_full = x.st_rects = x.st_changed = x.st_cost = x.st_direct = 0;
-    // A stream of pages that all end in the whole-page referee (text pages: a class boundary in every block) does not need
-    // the bf16 pass in front of it: after three such pages in a row the next eight go to the float32 engine directly
-    // (10 % of the page's cost), then one page probes again.  Not when the caller wants the margin map.
+    // A stream of pages that all end in the whole-page referee does not need the bf16 pass in front of it -- and a TEXT page always
+    // ends there, whatever the first pass's precision: near-ties sit on class boundaries, the margin passes through zero on every one
+    // of them, and a text page has one in three quarters of its 32-px blocks (profiles/r04_label_exact_study.json: 623 blocks hold a
+    // pixel whose float32 margin is under 0.005, a hundredth of the bf16 pass's logit error).  After three such pages in a row the
+    // next eight go to the float32 engine directly, then one page probes; every probe that falls back again doubles the stretch (up
+    // to 512 pages), a page that stays partial ends it.  Not when the caller wants the margin map.
     if (x.skip_left > 0 && !d_margin_out && !PSEG_KNOB("PSEG_EXACT_TAU")) {
         --x.skip_left;
         KnobScope ks(x.f32->e);
@@ -403,9 +407,11 @@ static int exact_labels(Engine& e, const uint8_t* d_img, int H, int W, uint8_t* 
         x.st_full = 1;
         x.st_area = 1.0;
         x.st_blocks = 1.0;
-        if (++x.fallback_streak >= 3) { x.skip_left = 8; x.fallback_streak = 0; }
+        if (x.skip_len > 0) { x.skip_len = std::min(2 * x.skip_len, 512); x.skip_left = x.skip_len; }     // a probe behind a direct stretch: back off
+        else if (++x.fallback_streak >= 3) { x.skip_len = x.skip_left = 8; x.fallback_streak = 0; }
     } else {
         x.fallback_streak = 0;
+        x.skip_len = 0;
     }
     if (d_labels) widen_u8_kernel<<<(int)std::min<size_t>((npx + 255) / 256, 8192), 256, 0, st>>>(lab, d_labels, npx);
     PSEG_HIP(hipGetLastError());

@@ -16,7 +16,7 @@ FLAG_BATCHNORM = 1
 EXPORTED_SYMBOLS = (
     "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_create_ex", "pseg_destroy",
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
-    "pseg_predict", "pseg_predict_device", "pseg_predict_pages_device", "pseg_predict_batch", "pseg_predict_chain", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
+    "pseg_predict", "pseg_predict_device", "pseg_predict_pages_device", "pseg_rccl_abi_pinned", "pseg_predict_batch", "pseg_predict_chain", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
     "pseg_host_alloc", "pseg_host_free", "pseg_host_register", "pseg_host_unregister",
     "pseg_predict_margin_device", "pseg_predict_exact_labels_device", "pseg_predict_exact_labels", "pseg_label_exact_stats", "pseg_label_exact_stats_ex",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",

@@ -26,6 +26,16 @@ def test_library_exports_every_declared_symbol():
     assert L.pseg_abi_version() == 1
 
 
+def test_rccl_entry_points_are_pinned_against_the_rccl_header():
+    """pseg_dist.hip binds RCCL by dlopen and restates its ABI by hand (128-byte id, ncclFloat32 = 7, ncclSum = 0, five prototypes);
+    where <rccl/rccl.h> exists at build time -- the ROCm image -- static_asserts compare every one of them with the header, and the
+    library says whether they ran.  No GPU and no second rank needed: a mismatch is a build failure."""
+    import pseg_amd
+    L = pseg_amd.lib()
+    pinned = L.pseg_rccl_abi_pinned()
+    assert pinned == (1 if os.path.exists("/opt/rocm/include/rccl/rccl.h") else 0)
+
+
 def test_oracle_library_is_separate_from_the_product():
     """Nothing of the oracle is linked into or imported by the product package."""
     import subprocess

@@ -75,6 +75,41 @@ def test_bf16_mode_vs_bf16_oracle(gpu, oracle_mod, monkeypatch, arch, C, shape):
     eng.close()
 
 
+def test_bf16_default_plan_full_size_page_vs_bf16_oracle(gpu, oracle_mod):
+    """configs[1]'s page -- 2048x1536, 3 classes, fcn_skip, bf16 -- on the DEFAULT engine against the bf16-emulating oracle, directly: at
+    this size the engine takes the plans the headline number is measured on (conv12_ws_kernel's persistent walk of 24 tiles per
+    CU, conv_pp_kernel for conv3 / conv4, conv_sp_kernel for conv7 and deconv1 + deconv2, three-workgroup instances for the
+    quarter-resolution layers, tail_fused2_kernel), which the small-page tests reach only through bit-identity chains.  Same bars
+    as test_bf16_mode_vs_bf16_oracle: logits and every stored activation within 2 % of the tensor's magnitude, labels equal to the
+    oracle's except where its top-2 margin is within twice the observed logit error, labels = argmax of the returned logits."""
+    from pseg_amd import synth
+    img = synth.synth_page(1000, 2048, 1536, 3)[0]
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=42, gain=1.5, bias_scale=0.05)
+    z_o, acts = oracle_mod.forward("fcn_skip", Wt, img, "bf16", return_acts=True)
+    eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
+    eng.set_weights(Wt)
+    logit, _, pred = eng.predict(img, want_probs=False)
+    assert np.abs(logit - z_o).max() <= TOL * max(1.0, np.abs(z_o).max())
+    bad, total = _check_labels(pred, logit, z_o)
+    assert np.array_equal(pred, np.argmax(logit, -1))
+    assert bad == 0, "%d label mismatches outside near-ties (%d total)" % (bad, total)
+    assert total < 0.02 * pred.size                                   # near-ties are rare even with random weights
+    checked = 0
+    for name, a in acts.items():
+        if name == "logits":
+            continue
+        try:
+            g = eng.activation(name)
+        except gpu.PsegError as ex:                                   # tensors the default plan never writes
+            assert "fused" in str(ex), ex
+            continue
+        checked += 1
+        err = np.abs(g - a).max()
+        assert err <= TOL * max(1.0, np.abs(a).max()), "%s: max err %g (max |a| %g)" % (name, err, np.abs(a).max())
+    assert checked >= 5                                               # conv3, conv5, conv6 and their pools, deconv2, deconv3
+    eng.close()
+
+
 def test_bf16_first_layer(gpu, oracle_mod, monkeypatch):
     """conv1 (MFMA, K = 25 taps): float32 sums of exact bf16 products; only the summation order
     differs from the oracle's sequential chain, so after bf16 rounding almost every value is

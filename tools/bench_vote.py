@@ -1,6 +1,6 @@
 """Vote timing on configs[4]'s page (4096x3072, 6 classes, uint8 labels): the synthetic page as BASELINE.md prescribes it
 (two speckled image rectangles: one percolating component each + thousands of specks) and the same page with the
-rectangles blanked (text only).  PSEG_VOTE_GLOBAL=1 selects the page-global union-find path."""
+rectangles blanked (text only).  PSEG_CCL_GLOBAL=1 selects the page-global union-find path."""
 import ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]

@@ -1,0 +1,136 @@
+"""Evidence for the label-exact mode on a TEXT page: run on the GPU box, writes profiles/<tag>_label_exact_study.json.
+  (i)   where the bf16 and the float32 label maps differ on the trained-weights text page: float32 margin at those pixels, and
+        how many pixels / 32-px blocks / referee crops a threshold tau flags (the library's own cover() through PSEG_EXACT_TAU);
+  (ii)  which layers the first pass's logit error comes from: bf16-engine activations against the float32 engine's, layer by
+        layer, and the plan variants of the tail (folded deconv5 o logits, skip logits taken in conv2's epilogue) against the
+        unfused kernels;
+  (iii) the first-pass accuracy a text page would need: pixels / blocks under a float32 margin x, i.e. what a first pass with
+        logit error x / 2 would have to flag.
+    python tools/label_exact_study.py [tag]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
+import numpy as np
+import torch
+torch.cuda.is_available()
+import pseg_amd
+from pseg_amd import synth
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+H, W, C, arch = 2048, 1536, 3, "fcn_skip"
+dev = torch.device("cuda:0")
+st = torch.cuda.current_stream(dev).cuda_stream
+out = {"page": "synthetic text page synth_page(99), %dx%d, %d classes, %s" % (H, W, C, arch)}
+
+# the bench leg's trained weights: 150 Adam steps (lr 2e-3) on six 128x160 synthetic pages
+e32 = pseg_amd.Engine(arch, C, mode=pseg_amd.MODE_F32_EXACT)
+e32.set_weights(synth.glorot_weights(e32.weight_specs(), seed=7))
+e32.train_init(clipnorm=1.0)
+tp = [synth.synth_page(s, 128, 160, C) for s in range(6)]
+for it in range(150):
+    img, _, mask = tp[it % len(tp)]
+    loss = e32.train_forward_backward(img, mask)[0]
+    e32.train_apply(2e-3)
+Wt = e32.get_weights()
+out["weights"] = "150 Adam steps (lr 2e-3) on six 128x160 synthetic pages, last loss %.4f" % loss
+page = synth.synth_page(99, H, W, C)[0]
+
+
+def run(mode, env=None):
+    env = env or {}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    e = pseg_amd.Engine(arch, C, mode=mode)
+    for k, v in old.items():
+        if v is None: os.environ.pop(k)
+        else: os.environ[k] = v
+    e.set_weights(Wt)
+    z, _, l = e.predict(page, want_probs=False)
+    return e, z, l
+
+
+ef, zf, lf = run(pseg_amd.MODE_F32_EXACT)
+eb, zb, lb = run(pseg_amd.MODE_BF16)
+srt = np.sort(zf, -1)
+mf = srt[..., -1] - srt[..., -2]                     # float32 margin
+srtb = np.sort(zb, -1)
+mb = srtb[..., -1] - srtb[..., -2]                   # bf16 margin
+diff = lf != lb
+err = np.abs(zb - zf)
+out["i_label_differences"] = {
+    "pixels": int(diff.sum()), "fraction": float(diff.mean()),
+    "logit_err_max": float(err.max()), "logit_err_p999": float(np.quantile(err, 0.999)), "logit_err_p99": float(np.quantile(err, 0.99)),
+    "logit_err_median": float(np.median(err)), "logit_abs_max": float(np.abs(zf).max()),
+    "f32_margin_at_differing_px": {"max": float(mf[diff].max()) if diff.any() else 0.0, "p99": float(np.quantile(mf[diff], 0.99)) if diff.any() else 0.0,
+                                   "median": float(np.median(mf[diff])) if diff.any() else 0.0},
+    "bf16_margin_at_differing_px": {"max": float(mb[diff].max()) if diff.any() else 0.0, "p99": float(np.quantile(mb[diff], 0.99)) if diff.any() else 0.0},
+    "margin_change_max_same_label": float(np.abs(mb - mf)[~diff].max()),
+}
+# class-boundary geometry of the page (float32 labels)
+bnd = np.zeros_like(lf, bool)
+bnd[:, 1:] |= lf[:, 1:] != lf[:, :-1]
+bnd[1:, :] |= lf[1:, :] != lf[:-1, :]
+out["page_geometry"] = {"boundary_px": int(bnd.sum()), "boundary_px_fraction": float(bnd.mean()),
+                        "blocks32_with_a_boundary_px": int(bnd.reshape(H // 32, 32, W // 32, 32).any((1, 3)).sum()), "blocks32_total": (H // 32) * (W // 32)}
+
+# (iii) what a first pass with worst-case logit error E must flag: pixels whose float32 margin is under 2 E
+curve = []
+for x in (0.005, 0.01, 0.02, 0.04, 0.08, 0.16, 0.32, 0.64, 1.28, 2.56):
+    fl = mf < x
+    curve.append({"f32_margin_below": x, "pixels": int(fl.sum()), "px_fraction": float(fl.mean()),
+                  "blocks32": int(fl.reshape(H // 32, 32, W // 32, 32).any((1, 3)).sum())})
+out["iii_pixels_and_blocks_under_a_float32_margin"] = curve
+
+# (i, continued) the library's own flagging and crop cover as a function of tau (bf16 margin < tau)
+d_img = torch.from_numpy(page).to(dev)
+lab = torch.empty((H, W), dtype=torch.uint8, device=dev)
+taus = []
+for tau in (0.02, 0.05, 0.1, 0.2, 0.4, 0.8, 1.6):
+    os.environ["PSEG_EXACT_TAU"] = repr(tau)
+    e = pseg_amd.Engine(arch, C, mode=pseg_amd.MODE_BF16)
+    os.environ.pop("PSEG_EXACT_TAU")
+    e.set_weights(Wt)
+    e.predict_exact_labels_device(d_img.data_ptr(), H, W, lab.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    s = e.label_exact_stats()
+    fl = mb < tau
+    taus.append({"tau": tau, "flagged_px": int(fl.sum()), "flagged_blocks32": int(fl.reshape(H // 32, 32, W // 32, 32).any((1, 3)).sum()),
+                 "referee_rects": s.get("referee_rects"), "referee_cost_vs_full_page": s.get("referee_cost_vs_full_page"),
+                 "whole_page_fallback": s.get("whole_page_fallback"), "referee_area_frac": s.get("referee_area_frac"),
+                 "labels_equal_float32": bool(np.array_equal(lab.cpu().numpy(), lf)),
+                 "wrong_px_left_if_only_flagged_were_refereed": int((diff & ~fl).sum())})
+    e.close()
+out["i_flagging_vs_tau"] = taus
+
+# (ii) per-layer error of the bf16 engine against the float32 engine (same weights, same page)
+layers = []
+names = list(dict.fromkeys(n.split("/")[0] for n, _ in eb.weight_specs())) + ["max_pooling2d", "max_pooling2d_1", "max_pooling2d_2"]
+env_keep = {"PSEG_NO_POOL_ONLY": "1", "PSEG_NO_SKIPLOG": "1", "PSEG_NO_TAIL2": "1", "PSEG_NO_DQ": "1", "PSEG_NO_TAIL_COMPOSE": "1"}
+ek, zk, lk = run(pseg_amd.MODE_BF16, env_keep)       # an engine that stores every tensor (unfused tail, stored skip tensor)
+for nm in names:
+    try:
+        a32 = ef.activation(nm)
+        a16 = ek.activation(nm)
+    except Exception:
+        continue
+    d = np.abs(a16 - a32)
+    layers.append({"layer": nm, "abs_max": float(np.abs(a32).max()), "err_max": float(d.max()), "err_rms": float(np.sqrt((d.astype(np.float64) ** 2).mean())),
+                   "err_max_rel_to_abs_max": float(d.max() / max(np.abs(a32).max(), 1e-9)), "rms_rel_to_rms": float(np.sqrt((d.astype(np.float64) ** 2).mean()) / max(np.sqrt((a32.astype(np.float64) ** 2).mean()), 1e-12))})
+out["ii_per_layer_error_bf16_vs_float32"] = layers
+variants = []
+for what, env in (("default plan (folded tail, skip logits in conv2's epilogue, deconv4 inside the tail)", {}),
+                  ("unfused tail, stored skip tensor (PSEG_NO_TAIL_COMPOSE, PSEG_NO_SKIPLOG, PSEG_NO_TAIL2)", {"PSEG_NO_TAIL_COMPOSE": "1", "PSEG_NO_SKIPLOG": "1", "PSEG_NO_TAIL2": "1"}),
+                  ("composed tail, stored skip tensor (PSEG_NO_SKIPLOG)", {"PSEG_NO_SKIPLOG": "1", "PSEG_NO_TAIL2": "1"}),
+                  ("composed tail, skip logits fused, deconv4 stored (PSEG_NO_TAIL2)", {"PSEG_NO_TAIL2": "1"})):
+    e, z, l = run(pseg_amd.MODE_BF16, env)
+    dd = np.abs(z - zf)
+    variants.append({"plan": what, "logit_err_max": float(dd.max()), "logit_err_p999": float(np.quantile(dd, 0.999)), "logit_err_rms": float(np.sqrt((dd.astype(np.float64) ** 2).mean())),
+                     "labels_differ_from_float32": int((l != lf).sum())})
+    e.close()
+out["ii_tail_plan_variants"] = variants
+# float32 first layers + bf16 rest is not a mode of the engine; the nearest experiment the engines allow: feed the bf16 engine's
+# first-layer error forward is what the per-layer table shows (error after conv2 vs after the decoder)
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+fn = os.path.join(ROOT, "gpurun_out", "%s_label_exact_study.json" % tag)
+json.dump(out, open(fn, "w"), indent=1)
+print(json.dumps(out, indent=1))

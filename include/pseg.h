@@ -68,6 +68,14 @@ int pseg_create(int arch, int n_classes, int in_channels, int device, int mode,
 enum { PSEG_FLAG_BATCHNORM = 1 };
 int pseg_create_ex(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
                    pseg_engine** out);
+/* ... with PLAN SWITCHES: alternative kernel / fusion choices of the bf16 and float32 engines ("PSEG_NO_DQ=1;PSEG_WS_FORM=2";
+ * NULL or "" = pseg_create_ex).  Test and measurement entry: every switch leaves the results within the documented bars (most
+ * are bit-identical) and is pinned by a test; the process environment cannot set them -- the release library reads only the
+ * names pseg_env_knobs() lists from the environment (README.md documents them), once per engine at creation. */
+int pseg_create_plan(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags, const char* switches,
+                     pseg_engine** out);
+/* the environment variables the release library reads, one per line (static storage) */
+const char* pseg_env_knobs(void);
 int pseg_destroy(pseg_engine* e);
 
 /* Weight table in Keras creation order; names are Keras' default layer names plus

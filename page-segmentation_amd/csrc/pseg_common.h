@@ -34,22 +34,33 @@ int fail(int code, const char* fmt, ...);
         if (_rc != PSEG_OK) return _rc;                                                        \
     } while (0)
 
-// Developer knobs (PSEG_* environment variables: alternative kernel choices that must not change results beyond the
-// documented bars; every one is exercised by a bit-identity or tolerance test).  pseg_create snapshots the PSEG_* part of
-// the environment ONCE for the new engine; the engine keeps that snapshot for its whole life (std::shared_ptr, freed
-// with the last engine that holds it) and every entry point that takes an engine answers knob queries from the
-// engine's OWN snapshot (KnobScope, thread-local) -- plan-time and launch-time reads of one engine always agree, and
-// neither a later change of the environment nor the creation of another engine (e.g. the float32 companion of the
-// label-exact mode, which inherits its parent's snapshot) can alter a running engine.  Engine-less entries (post-
-// process, resize) read the newest snapshot.  Each call site caches its answer per snapshot id.
-// Knobs that produce WRONG results (timing ablations: PSEG_DBG, PSEG_XM_DBG, PSEG_PP_NODMA, PSEG_PP_NOEPI, the
-// in-kernel trace stamps) exist only in the diagnostic build (libpseg_diag.so, -DPSEG_DIAG=1): PSEG_DIAG_KNOB is a
-// constant nullptr in the release library (tests/test_abi.py checks that the release .so does not even hold the names).
+// Knobs.  Two kinds, one lookup (PSEG_KNOB):
+//   * ENVIRONMENT knobs -- the PSEG_ENV_KNOBS list below, fourteen names, documented in README.md: operational choices a deployment
+//     may make (page-unit size, the persistent kernel families off, checks, logging).  Nothing else in the process environment
+//     reaches the release library.
+//   * PLAN SWITCHES -- alternative kernel / fusion choices that must not change results beyond the documented bars; every one is
+//     exercised by a bit-identity or tolerance test.  They exist for those tests and for A/B measurements and enter ONLY through
+//     pseg_create_plan's `switches` string ("PSEG_NO_DQ=1;PSEG_WS_FORM=2"); the Python test harness builds that string from
+//     os.environ when pseg_amd.engine.PLAN_FROM_ENV is set (tests/conftest.py, tools/), a product caller never does.
+// pseg_create* takes ONE snapshot (the listed environment knobs + the plan switches) for the new engine; the engine keeps it for
+// its whole life (std::shared_ptr) and every entry point that takes an engine answers queries from the engine's OWN snapshot
+// (KnobScope, thread-local) -- plan-time and launch-time reads of one engine always agree, and neither a later change of the
+// environment nor the creation of another engine (the float32 companion of the label-exact mode inherits its parent's snapshot)
+// can alter a running engine.  Engine-less entries (post-process, resize) read the newest environment snapshot.  Each call site
+// caches its answer per snapshot id.
+// Knobs that produce WRONG results (timing ablations: PSEG_DBG, PSEG_XM_DBG, PSEG_SP_DBG, PSEG_PP_NODMA, PSEG_PP_NOEPI, the
+// in-kernel trace stamps) exist only in the diagnostic build (libpseg_diag.so, -DPSEG_DIAG=1, which reads everything from the
+// environment): PSEG_DIAG_KNOB is a constant nullptr in the release library (tests/test_abi.py checks that the release .so does
+// not even hold the names).
+#define PSEG_ENV_KNOBS                                                                                                          \
+    "PSEG_BATCH_PAGES", "PSEG_NO_PAGE_BATCH", "PSEG_GENERIC", "PSEG_NO_SP", "PSEG_NO_PP", "PSEG_NO_WS", "PSEG_SP_CHECK",        \
+    "PSEG_EXACT_TAU", "PSEG_EXACT_FULL", "PSEG_TRAIN_ONE_STREAM", "PSEG_TRAIN_STRICT", "PSEG_LOG_GENERIC", "PSEG_LOG_SP",       \
+    "PSEG_CCL_GLOBAL"
 #ifndef PSEG_DIAG
 #define PSEG_DIAG 0
 #endif
 struct KnobSnap;                                  // id + the PSEG_* variables at the time of the snapshot
-std::shared_ptr<const KnobSnap> knobs_snapshot(); // snapshot the environment now; it also becomes the "newest" one
+std::shared_ptr<const KnobSnap> knobs_snapshot(const char* plan = nullptr); // the listed environment knobs now (+ plan switches "A=1;B=2"); without a plan it also becomes the "newest" one
 unsigned knob_generation();                       // id of the snapshot in scope (the engine's, else the newest), >= 1
 const char* knob_lookup(const char* name);        // value in that snapshot, or nullptr
 struct Engine;
@@ -279,7 +290,7 @@ int predict_device(Engine& e, const uint8_t* d_img, int H, int W, float* d_logit
 void launch_margin_from_logits(const float* d_logits, size_t n, int C, float* d_margin, hipStream_t st);
 bool mfma_tail_emits_margin(const Engine& e);   // the bf16 graph's tail kernel writes the margin map itself
 int create_engine(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
-                  std::shared_ptr<const KnobSnap> inherit, struct ::pseg_engine** out);   // pseg_create_ex; `inherit` = a parent engine's knob snapshot
+                  std::shared_ptr<const KnobSnap> inherit, struct ::pseg_engine** out, const char* plan = nullptr);   // pseg_create_ex; `inherit` = a parent engine's knob snapshot
 void exact_free(Engine& e);
 void chain_free(Engine& e);
 void dist_free(Engine& e);                      // RCCL communicator (pseg_dist.hip)                     // Predictor chain buffers (pseg_chain.hip)                     // label-exact mode state (pseg_exactlabels.hip)

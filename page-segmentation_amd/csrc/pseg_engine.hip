@@ -34,20 +34,37 @@ unsigned g_knob_next_id = 0;
 thread_local const KnobSnap* tls_knobs = nullptr;  // the snapshot of the engine whose entry point is running on this thread
 extern "C" char** environ;
 }  // namespace
-std::shared_ptr<const KnobSnap> knobs_snapshot() {
+static const char* const k_env_knobs[] = {PSEG_ENV_KNOBS};
+std::shared_ptr<const KnobSnap> knobs_snapshot(const char* plan) {
     auto m = std::make_shared<KnobSnap>();
-    for (char** ep = environ; ep && *ep; ++ep) {
+#if PSEG_DIAG
+    for (char** ep = environ; ep && *ep; ++ep) {          // (the diagnostic build answers from the live environment anyway)
         if (strncmp(*ep, "PSEG_", 5) != 0) continue;
         const char* eq = strchr(*ep, '=');
         if (eq) m->kv[std::string(*ep, eq - *ep)] = std::string(eq + 1);
     }
+#else
+    for (const char* name : k_env_knobs)
+        if (const char* v = getenv(name)) m->kv[name] = v;
+#endif
+    // plan switches: "NAME=VALUE;NAME=VALUE" (pseg_create_plan); a name without '=' means "=1"
+    for (const char* p = plan; p && *p;) {
+        const char* e = strchr(p, ';');
+        const std::string item = e ? std::string(p, e - p) : std::string(p);
+        p = e ? e + 1 : p + item.size();
+        if (item.compare(0, 5, "PSEG_") != 0) continue;
+        const size_t eq = item.find('=');
+        m->kv[item.substr(0, eq)] = eq == std::string::npos ? "1" : item.substr(eq + 1);
+    }
     std::lock_guard<std::mutex> lk(g_knob_mu);
     // an unchanged environment (the normal case: one snapshot per process) shares the newest snapshot; a changed one
     // retires it -- retired "newest" snapshots stay alive (an engine-less call site on another thread may still hold a
-    // pointer into it), one per CHANGE of the PSEG_* environment, not one per engine
+    // pointer into it), one per CHANGE of the listed variables, not one per engine.  A snapshot with plan switches belongs to
+    // its engine alone: it never becomes the newest one.
     if (g_knob_latest && g_knob_latest->kv == m->kv) return g_knob_latest;
-    if (g_knob_latest) g_knob_retired.push_back(g_knob_latest);
     m->id = ++g_knob_next_id;
+    if (plan && *plan) return m;
+    if (g_knob_latest) g_knob_retired.push_back(g_knob_latest);
     g_knob_latest = m;
     return m;
 }
@@ -418,8 +435,7 @@ int launch_conv_exact(const ConvArgs& a, hipStream_t st, bool* pooled) {
         return rc < 0 ? rc : PSEG_OK;
     }
     const int Cin = a.C0 + a.C1;
-    if (a.KH == 1 && a.KW == 1 && a.stride == 1 && !a.pt && !a.pl && !a.up0 && !a.up1 && !a.in_relu && !a.mask && Cin <= 127 &&
-        !PSEG_KNOB("PSEG_EXACT_NO_1X1")) {
+    if (a.KH == 1 && a.KW == 1 && a.stride == 1 && !a.pt && !a.pl && !a.up0 && !a.up1 && !a.in_relu && !a.mask && Cin <= 127) {
         static bool attr_set[64] = {false};
         int dev = 0;
         PSEG_HIP(hipGetDevice(&dev));
@@ -1135,12 +1151,22 @@ int pseg_create_ex(int arch, int n_classes, int in_channels, int device, int mod
     return pseg::create_engine(arch, n_classes, in_channels, device, mode, flags, nullptr, out);
 }
 
+int pseg_create_plan(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags, const char* switches,
+                     pseg_engine** out) {
+    return pseg::create_engine(arch, n_classes, in_channels, device, mode, flags, nullptr, out, switches);
+}
+
+const char* pseg_env_knobs(void) {
+    static const std::string joined = [] { std::string j; for (const char* n : k_env_knobs) { if (!j.empty()) j += "\n"; j += n; } return j; }();
+    return joined.c_str();
+}
+
 }  // extern "C"
 
 // `inherit`: the snapshot of a parent engine (the float32 companion of the label-exact mode is created in the middle of
 // its parent's predict call and must not see another environment than its parent); nullptr = snapshot the environment now
 int pseg::create_engine(int arch, int n_classes, int in_channels, int device, int mode, unsigned flags,
-                        std::shared_ptr<const KnobSnap> inherit, pseg_engine** out) {
+                        std::shared_ptr<const KnobSnap> inherit, pseg_engine** out, const char* plan) {
     if (!out) return fail(PSEG_EINVAL, "out is NULL");
     if (flags & ~(unsigned)PSEG_FLAG_BATCHNORM) return fail(PSEG_EINVAL, "unknown flag bits 0x%x", flags);
     *out = nullptr;
@@ -1154,7 +1180,7 @@ int pseg::create_engine(int arch, int n_classes, int in_channels, int device, in
     PSEG_HIP(hipSetDevice(device));
     auto* h = new pseg_engine();
     Engine& e = h->e;
-    e.knobs = inherit ? inherit : knobs_snapshot();   // the PSEG_* developer knobs are read here, once per engine, never per launch
+    e.knobs = inherit ? inherit : knobs_snapshot(plan);   // the knobs are read here, once per engine, never per launch
     KnobScope ks(e);
     e.arch = arch;
     e.n_classes = n_classes;

@@ -818,7 +818,6 @@ static int launch_xm(const ConvArgs& a, int Cp, int THH, int TWH, int CB, dim3 g
 // Returns 1 when the layer was launched on a matrix-core kernel (2: with ConvArgs.pool_dst written too), 0 when it is not
 // one for them (caller falls back to the 1x1 / scalar kernels: a handful of output channels), < 0 on error.
 int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
-    if (PSEG_KNOB("PSEG_EXACT_SCALAR")) return 0;
     ConvArgs a = a_in;
     if (const char* dv = PSEG_DIAG_KNOB("PSEG_XM_DBG")) a.dbg = atoi(dv);   // wrong-result timing switches: diagnostic build only
     const int Cin = a.C0 + a.C1;
@@ -850,7 +849,7 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     // blocked chain: 8-row tiles unless the 16-channel slab of a strided layer's halo tile would leave fewer than three
     // workgroups per CU (then 4-row tiles)
     auto lds_of = [&](int mt) { return (size_t)((4 * (mt / 2) - 1) * a.stride + a.KH) * TWH * XCP * 4; };
-    int MT = (lds_of(4) <= 52 * 1024 && !PSEG_KNOB("PSEG_EXACT_MT2")) ? 4 : 2;
+    int MT = (lds_of(4) <= 52 * 1024) ? 4 : 2;
     const bool pooled = a.pool_dst != nullptr && MT == 4 && a.stride == 1 && !a.deconv4 && !a.add && !(a.Hout & 1) && !(a.Wout & 1);
     if (!pooled) a.pool_dst = nullptr;
     if (lds_of(MT) > 150 * 1024) return 0;
@@ -866,8 +865,7 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     // quarter-resolution layers of a 2048x1536 page (768 tiles): the chip holds 768 three- or four-tile workgroups at once (three
     // waves per SIMD), so one cout block beats two -- 3 tiles cannot split evenly (2 + 1 with a dead tile: deconv3 612 -> 461 us),
     // 4 tiles as 2 + 2 stage every slab twice (conv5 / conv6 226 -> 218, 326 -> 308 us).  PSEG_EXACT_SPLIT=1: the split forms.
-    if ((ntall == 3 || ntall == 4) && nblk == 2 && tiles >= 512 && !PSEG_KNOB("PSEG_EXACT_SPLIT")) { NT = ntall; nblk = 1; }
-    if (const char* fv = PSEG_KNOB("PSEG_EXACT_NT")) { NT = std::max(1, std::min(4, atoi(fv))); nblk = cdiv(ntall, NT); }
+    if ((ntall == 3 || ntall == 4) && nblk == 2 && tiles >= 512) { NT = ntall; nblk = 1; }
     const size_t lds = lds_of(MT);
     dim3 grid(tiles, nblk);
     const int tail_ch = Cin % XCB;                              // channels of the last slab (0: a full one)
@@ -876,7 +874,7 @@ int launch_conv_exact_mfma(const ConvArgs& a_in, hipStream_t st) {
     {
         const int rem = a.Cout % 16, ntm = a.Cout / 16;
         if ((rem == 4 || rem == 8) && (ntm == 1 || ntm == 2) && MT == 4 && !a.deconv4 && a.stride == 1 && !a.out_sy && !a.out_sx && (tiles >= 512 || PSEG_KNOB("PSEG_EXACT_REM_ANY")) &&
-            !PSEG_KNOB("PSEG_EXACT_NO_REM") && !PSEG_KNOB("PSEG_EXACT_NT") && a.wrem_buf && a.wrem_cap >= wrem_bytes_for(a.KH, a.KW, Cin, a.Cout)) {
+            !PSEG_KNOB("PSEG_EXACT_NO_REM") && a.wrem_buf && a.wrem_cap >= wrem_bytes_for(a.KH, a.KW, Cin, a.Cout)) {
             const size_t wbytes = wrem_bytes_for(a.KH, a.KW, Cin, a.Cout);
             // the shifted copies live in a buffer of the caller's (the op's, beside its kernel; the train step's scratch for the
             // flipped kernels of the data gradients) and are rebuilt only when the weights behind them changed -- no allocation,

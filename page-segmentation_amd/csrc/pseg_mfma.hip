@@ -2177,57 +2177,6 @@ __global__ __launch_bounds__(256) void logits_mfma_kernel(const uint16_t* src0, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// first layer, Cin = 1: VALU direct conv straight from the uint8 page (fuses x/255 and the
-// pad-to-32).  0.9 % of the FLOPs; K = 25 is too short for MFMA.  Sequential fmaf chain in tap
-// order over bf16-rounded operands == the bf16-mode oracle bit for bit.
-// ---------------------------------------------------------------------------------------------
-template <int KS, int COUT>
-__global__ __launch_bounds__(256) void conv1_bf16_kernel(const uint8_t* img, int H, int W, int Hp,
-                                                         int Wp, const float* lut, const float* w,
-                                                         const float* bias, uint16_t* dst, int relu) {
-    constexpr int CS = (COUT + 7) / 8 * 8;
-    constexpr int BW = 32, BH = 8, P = KS / 2;
-    __shared__ float tile[(BH + KS - 1) * (BW + KS - 1)];
-    const int ox0 = blockIdx.x * BW, oy0 = blockIdx.y * BH;
-    for (int i = threadIdx.x; i < (BH + KS - 1) * (BW + KS - 1); i += 256) {
-        const int py = i / (BW + KS - 1), px = i - py * (BW + KS - 1);
-        const int y = oy0 + py - P, x = ox0 + px - P;
-        tile[i] = (y >= 0 && y < H && x >= 0 && x < W) ? lut[img[(size_t)y * W + x]] : 0.0f;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x = ox0 + lx, y = oy0 + ly;
-    float acc[COUT];
-#pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.0f;
-#pragma unroll
-    for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            const float xv = tile[(ly + ky) * (BW + KS - 1) + lx + kx];
-            const float* wr = w + (ky * KS + kx) * COUT;
-#pragma unroll
-            for (int c = 0; c < COUT; ++c) acc[c] = __builtin_fmaf(xv, wr[c], acc[c]);
-        }
-    if (x >= Wp || y >= Hp) return;
-    uint16_t o[CS];
-#pragma unroll
-    for (int c = 0; c < CS; ++c) {
-        float v = 0.0f;
-        if (c < COUT) {
-            v = acc[c] + bias[c];
-            if (relu) v = v > 0.f ? v : 0.f;
-        }
-        o[c] = d_f2bf(v);
-    }
-    uint4* d = (uint4*)(dst + ((size_t)y * Wp + x) * CS);
-#pragma unroll
-    for (int q = 0; q < CS / 8; ++q)
-        d[q] = make_uint4(o[8 * q] | ((uint32_t)o[8 * q + 1] << 16), o[8 * q + 2] | ((uint32_t)o[8 * q + 3] << 16),
-                          o[8 * q + 4] | ((uint32_t)o[8 * q + 5] << 16), o[8 * q + 6] | ((uint32_t)o[8 * q + 7] << 16));
-}
-
-// ---------------------------------------------------------------------------------------------
 // first layer on MFMA (Cin = 1).  K = KS rows x 8 columns (columns >= KS carry zero weights):
 // k-step s, lane group g <-> kernel row ky = 4s + g, element j <-> kernel column kx = j.  The B
 // fragment of pixel (y, x) for row ky is therefore 8 consecutive input pixels
@@ -3363,7 +3312,7 @@ int mfma_plan_graph(Engine& e) {
             // producers that leave through conv_mfma_kernel's direct-store epilogue
             const Tensor& tt = e.tensors[t];
             return p.type == OP_CONV && !p.transposed && p.k == 3 && p.stride == 1 && !p.up0 && !p.up1 && p.Cin >= 8 &&
-                   ((tt.C >> (2 * tt.s)) <= 8 || PSEG_KNOB("PSEG_RELU_COPY_ALL"));
+                   ((tt.C >> (2 * tt.s)) <= 8);
         };
         const size_t nops = e.ops.size();
         for (size_t ri = 0; ri < nops; ++ri) {
@@ -3714,7 +3663,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     // 128->64 the two extra passes over the full-resolution tensor cost more than the direct kernel (PSEG_UPSPLIT_MIN_CIN).
     if (op.type == OP_CONV && k == 2 && op.up0 && !s1 && op.stride == 1 && !op.in_relu && op.add < 0 && op.pool_dst < 0 &&
         op.tail_logits < 0 && op.fuse1 < 0 && !op.transposed && !PSEG_KNOB("PSEG_NO_UPSPLIT") && !PSEG_KNOB("PSEG_GENERIC")) {
-        const int min_cin = PSEG_KNOB("PSEG_UPSPLIT_MIN_CIN") ? atoi(PSEG_KNOB("PSEG_UPSPLIT_MIN_CIN")) : 256;
+        const int min_cin = 256;
         if (Cin >= min_cin) {
             P->kind = PLAN_UPSPLIT;
             return upsplit_create(&P->upsplit, w, bias, Cin, Cs0, Cout, e.tensors[op.dst].Cs);
@@ -3741,7 +3690,6 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     if (deint && NT == 4 && KS == 3 && !PSEG_KNOB("PSEG_NO_S2_MT2") && !PSEG_KNOB("PSEG_GENERIC")) P->MT = 2;
     // (the fused conv1+conv2 kernel was also tried with 8-row tiles -- 136 registers, 42 KB, three workgroups per
     // CU: 182 vs 164 us; the halo recompute of conv1 grows from 1.41x to 1.69x and the weights stream twice as often)
-    if (PSEG_KNOB("PSEG_MT")) P->MT = atoi(PSEG_KNOB("PSEG_MT")) == 8 && NT <= 2 ? 8 : 4;
     // (the 1/8-resolution k5 layers -- conv7, deconv1: 192 eight-row tiles for 256 CUs on a 2048x1536 page -- were tried
     // with four-row tiles (384 workgroups: 28.0 -> 26.3 and 33.3 -> 31.0 us) and with two N blocks of 3 + 2 cout tiles
     // (no change): two workgroups sharing a CU gain little over one here, not worth the extra instances)
@@ -3749,7 +3697,7 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     P->stride = deconv ? 1 : op.stride;
     // 8-wave workgroups (16-row tiles, the whole CU's LDS) exist for the k5 stride-1 mid-layer shapes
     P->nw8_ok = !deconv && (KS == 5 || (KS == 3 && NT == 4)) && op.stride == 1 && P->MT == 4 && (NT == 3 || NT == 4) && !op.up0 && !op.up1 &&
-                !op.in_relu && op.add < 0 && op.fuse1 < 0 && (P->nblocks_n == 1 || KS == 3) && !PSEG_KNOB("PSEG_GENERIC") && !PSEG_KNOB("PSEG_NO_NW8");
+                !op.in_relu && op.add < 0 && op.fuse1 < 0 && (P->nblocks_n == 1 || KS == 3) && !PSEG_KNOB("PSEG_GENERIC");
     P->NW = (P->nw8_ok && op.nw_hint == 8) ? 8 : 4;
     const int TH = P->NW * (P->MT / 2);
     const int totc = (Cs0 + Cs1) / 8;
@@ -3783,18 +3731,18 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
         // by the bank model) plus a two-slot ring fit 53 KB.  A workgroup's life is prologue -> k-loop ->
         // epilogue with the MFMA pipe used only in the middle; a third resident workgroup fills more of the
         // gaps: conv3 78 -> 67 us, deconv3 79 -> 66 us, better than the 16-row resident variant (70 us).
-        P->wg3 = P->NW == 4 && !deconv && ((KS == 5 && (NT == 3 || NT == 4) && P->nblocks_n == 1) || (KS == 3 && NT == 4 && !PSEG_KNOB("PSEG_NO_WG3_K3")) ||
-                                                 (KS == 2 && NT == 4 && op.up0 && !s1 && !PSEG_KNOB("PSEG_NO_WG3_K3"))) &&
+        P->wg3 = P->NW == 4 && !deconv && ((KS == 5 && (NT == 3 || NT == 4) && P->nblocks_n == 1) || (KS == 3 && NT == 4) ||
+                                                 (KS == 2 && NT == 4 && op.up0 && !s1)) &&
                  (P->nc_full == 4 || P->nc_full == 5) && op.stride == 1 &&
-                 (!op.up0 || KS == 2 || KS == 3) && !op.up1 && ((!op.in_relu && op.add < 0) || (KS == 3 && !PSEG_KNOB("PSEG_NO_WG3_RES"))) && op.fuse1 < 0 &&
-                 !PSEG_KNOB("PSEG_GENERIC") && !PSEG_KNOB("PSEG_NO_WG3");
+                 (!op.up0 || KS == 2 || KS == 3) && !op.up1 && ((!op.in_relu && op.add < 0) || (KS == 3)) && op.fuse1 < 0 &&
+                 !PSEG_KNOB("PSEG_GENERIC");
         // (stride 2: always the dense tile -- its columns are de-interleaved by parity at staging time, which makes the fragment
         // reads those of a stride-1 layer, and the 4.3 input pixels per output pixel are the layer's LDS and DMA bill)
         // conv_pp_kernel (conv3 / conv4: resident weights, two tile buffers).  (A 64-byte pixel pitch -- conv3's four chunks -- cannot be
         // read without 2-way bank conflicts: the eight lanes of a 16-lane read group that share a chunk cover four distinct 16-byte
         // windows.  An 80-byte pitch removes them and was measured in this kernel: 52.1 vs 52.0 us, so the dense tile stays.)
         P->pp = P->wg3 && KS == 5 && NT == 3 && P->nblocks_n == 1 && op.Cout <= 40 && !op.transposed && op.src1 < 0 && !PSEG_KNOB("PSEG_NO_PP");
-        if (P->wg3 || (deint && P->nc_full >= 2) || (!PSEG_KNOB("PSEG_NO_DENSE") && P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16))) {
+        if (P->wg3 || (deint && P->nc_full >= 2) || (P->nblk == 1 && !fits(sigma, 1) && P->nc_full < sigma && fits(P->nc_full, 16))) {
             sigma = P->nc_full;
             int best_cyc = 1 << 30;
             for (int pad = 0; pad < 16; ++pad) {
@@ -3837,7 +3785,6 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     const int ks_max = std::max(P->ks_full, P->ks_last);
     const int tab_bytes = ks_max * 16;
     int budget = P->NW == 8 ? 156 * 1024 : 80 * 1024;
-    if (const char* ev = PSEG_KNOB("PSEG_LDS_KB")) budget = atoi(ev) * 1024;
     if (P->wg3) budget = 53 * 1024;
     auto total = [&](int gk, int nbuf) { return round_up(in_bytes, 16) + nbuf * gk * NT * 1024 + tab_bytes + 16; };
     const int gstep = P->NW != 4 ? 1 : ((NT % 4 == 0) ? 1 : (NT % 2 == 0 ? 2 : 4));
@@ -3855,12 +3802,10 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     // all weights of a single-block layer resident in one slot: no ring, no group barriers
     const bool can_reside = P->nblk == 1 && total(round_up(ks_max, gstep), 1) <= budget && round_up(ks_max, gstep) <= 32;
     P->nw8_resident = P->NW == 8 && can_reside;
-    if (can_reside && !PSEG_KNOB("PSEG_NO_RESIDENT")) {
+    if (can_reside) {
         NB = 1;
         GK = round_up(ks_max, gstep);
     }
-    if (const char* ev = PSEG_KNOB("PSEG_NB")) { NB = std::max(2, std::min(4, atoi(ev))); GK = std::max(best_gk(NB), gstep); }
-    if (const char* ev = PSEG_KNOB("PSEG_GK")) GK = std::max(gstep, atoi(ev) / gstep * gstep);
     if (total(GK, NB) > 160 * 1024) return fail(PSEG_EUNSUPPORTED, "layer %s needs %d B of LDS", op.layer.c_str(), total(GK, NB));
     P->GK = GK;
     P->NB = NB;
@@ -4375,7 +4320,6 @@ static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv&
     a.nb_loop = 1;
     a.nb_total = P.nblocks_n;
     a.dbg = PSEG_DIAG_KNOB("PSEG_DBG") ? atoi(PSEG_DIAG_KNOB("PSEG_DBG")) : 0;   // wrong-result ablations: diagnostic build only
-    if (PSEG_KNOB("PSEG_INRELU_VGPR")) a.dbg |= 16;
     if (PSEG_KNOB("PSEG_NO_LDS_STORE")) a.dbg |= 32;   // direct 8-byte stores instead of the LDS patch (same bytes)
 }
 
@@ -4387,31 +4331,19 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         return fail(PSEG_EUNSUPPORTED, "layer %s: the ReLU'd second output exists only in the direct-store epilogue", op.layer.c_str());
     if (P->kind == PLAN_CONV1) {
         const uint8_t* img = e.cur_img;  // raw uint8 page (x/255 and pad-to-32 are fused)
-        if ((P->KS == 3 && (op.Cout == 64 || op.Cout == 32)) && !PSEG_KNOB("PSEG_CONV1_MFMA") && !PSEG_KNOB("PSEG_CONV1_VALU")) {
+        if ((P->KS == 3 && (op.Cout == 64 || op.Cout == 32))) {
             constexpr int RB = 16;
             dim3 g(cdiv(e.Wp, 64), cdiv(e.Hp, 4 * RB));
             if (op.Cout == 64) conv1_rows_kernel<3, 64, RB><<<g, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
             else conv1_rows_kernel<3, 32, RB><<<g, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
             return PSEG_OK;
         }
-        if (!PSEG_KNOB("PSEG_CONV1_VALU")) {
-            dim3 g1(e.Wp / 32, cdiv(e.Hp, 16));
-            uint16_t* o = (uint16_t*)d.d;
-            if (P->KS == 5 && op.Cout == 20) conv1_mfma_kernel<5, 20><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
-            else if (P->KS == 3 && op.Cout == 64) conv1_mfma_kernel<3, 64><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
-            else if (P->KS == 3 && op.Cout == 32) conv1_mfma_kernel<3, 32><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
-            else conv1_mfma_kernel<1, 32><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
-            return PSEG_OK;
-        }
-        dim3 grid(cdiv(e.Wp, 32), cdiv(e.Hp, 8));
-        if (P->KS == 5 && op.Cout == 20)
-            conv1_bf16_kernel<5, 20><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
-        else if (P->KS == 3 && op.Cout == 64)
-            conv1_bf16_kernel<3, 64><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
-        else if (P->KS == 3 && op.Cout == 32)
-            conv1_bf16_kernel<3, 32><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
-        else
-            conv1_bf16_kernel<1, 32><<<grid, 256, 0, st>>>(img, e.H, e.W, e.Hp, e.Wp, P->d_lut, P->d_wf, P->d_bias, (uint16_t*)d.d, op.relu);
+        dim3 g1(e.Wp / 32, cdiv(e.Hp, 16));
+        uint16_t* o = (uint16_t*)d.d;
+        if (P->KS == 5 && op.Cout == 20) conv1_mfma_kernel<5, 20><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
+        else if (P->KS == 3 && op.Cout == 64) conv1_mfma_kernel<3, 64><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
+        else if (P->KS == 3 && op.Cout == 32) conv1_mfma_kernel<3, 32><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
+        else conv1_mfma_kernel<1, 32><<<g1, 256, 0, st>>>(img, e.H, e.W, e.Wp, P->d_wpk, P->d_bias, o, op.relu);
         return PSEG_OK;
     }
     if (P->kind == PLAN_UPSPLIT) {
@@ -4422,10 +4354,9 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         // 16-row tiles when they still fill the chip (one workgroup per CU); re-pack on a change
         // Measured (MI355X, 2048x1536): 16-row tiles pay off where the layer's whole weight set then
         // stays resident in LDS (conv3: 80 -> 68 us); with a streamed ring they only tie (the halved
-        // weight traffic is offset by losing the second workgroup's overlap).  PSEG_NW=4|8 forces.
-        int want = (cdiv(e.tW(d), TW) * cdiv(e.tH(d), 16) >= 224 && sigma_for(P->nc_full) == 6 && !P->wg3) ? 8 : 4;
-        const char* ev = PSEG_KNOB("PSEG_NW");
-        if (ev) want = atoi(ev) == 8 ? 8 : 4;
+        // weight traffic is offset by losing the second workgroup's overlap).
+        const int want = (cdiv(e.tW(d), TW) * cdiv(e.tH(d), 16) >= 224 && sigma_for(P->nc_full) == 6 && !P->wg3) ? 8 : 4;
+        const char* const ev = nullptr;
         if (want != P->NW && want != P->nw_tried) {
             const std::vector<float> w = P->w_keep, b = P->b_keep;
             op.nw_hint = want;
@@ -4600,7 +4531,6 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
             MConv w = a;
             w.lds_w_off = TB;
             w.ntiles = (int)grid.x;
-            if (PSEG_KNOB("PSEG_PP_PRIO")) w.dbg |= 0x400;
             if (PSEG_DIAG_KNOB("PSEG_PP_NODMA")) w.dbg |= 0x800;     // wrong results, timing only: diagnostic build only
             if (PSEG_DIAG_KNOB("PSEG_PP_NOEPI")) w.dbg |= 0x1000;
             const dim3 gp((unsigned)cus_pp);
@@ -4631,7 +4561,6 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         w.lds_w_off = TB;                                   // the kernel's tile stride
         w.ntiles = (int)grid.x;
         const int lds = WS_TILE0 + 2 * TB + P->ks_full * P->NT * 1024 + round_up(P->ks_full * 16, 16) + 4 * (2 * 9 * 96 + 16);
-        if (const char* pr = PSEG_KNOB("PSEG_WS_PRIO")) w.dbg |= (atoi(pr) & 3) << 8;
         const int form = PSEG_KNOB("PSEG_WS_FORM") ? atoi(PSEG_KNOB("PSEG_WS_FORM")) : 0;
         if (lds <= 160 * 1024 && P->GK >= P->ks_full && P->row_pitch == WS_ROWP && P->ks_full == (P->pairc2 ? WS_KSTEPS_PAIR : WS_KSTEPS)) {
             const unsigned gx = std::min<unsigned>(grid.x, (unsigned)cus_ws);
@@ -4813,7 +4742,7 @@ int mfma_launch_logits(Engine& e, Op& op, float* d_logits, float* d_probs, int64
     const uint16_t* p0 = (const uint16_t*)s0.d;
     const uint16_t* p1 = s1 ? (const uint16_t*)s1->d : nullptr;
     const int n0 = s0.Cs / 8, n1 = s1 ? s1->Cs / 8 : 0;
-    if (!PSEG_KNOB("PSEG_LOGITS_VALU") && P->cmax <= 16) {
+    if (P->cmax <= 16) {
         const int waves = e.H * cdiv(e.W, 16);
         logits_mfma_kernel<<<cdiv(waves, 4), 256, 0, st>>>(p0, n0, p1, n1, e.Wp, e.H, e.W, op.Cout, P->d_wpk, P->d_bias,
                                                           d_logits, d_probs, d_labels, d_labels_u8);

@@ -829,9 +829,9 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
     const int taps = (int)grid.y;
     // ---- which instance, with which strips
     enum { V_PAIR, V_FLAT, V_C1, V_KX5, V_TAP, V_WIDE, V_SCALAR } variant;
-    const bool scalar = PSEG_KNOB("PSEG_WGRAD_SCALAR") != nullptr;
+    const bool scalar = false;
     WgradFlatPlan flat;
-    const bool lds = a.mode == 0 && a.stride == 1 && !a.xup && !PSEG_KNOB("PSEG_WGRAD_NO_LDS");
+    const bool lds = a.mode == 0 && a.stride == 1 && !a.xup;
     const int ti = (a.XC + 15) / 16, tj = (a.Cout + 15) / 16;
     if (a.XC0 > 0) {                                          // both concat sources + the bias gradient in one pass (pseg_wgrad_flat.hip)
         if (!wgrad_pair_plan(a, taps, &flat)) return fail(PSEG_EINVAL, "no two-source weight-gradient instance for this layer");
@@ -840,12 +840,12 @@ static int launch_wgrad(const WgradArgs& a_in, dim3 grid, hipStream_t st, float*
     } else if (!scalar && wgrad_flat_plan(a, taps, &flat)) {
         variant = V_FLAT;                                      // the k5 layers of fcn / fcn_skip (pseg_wgrad_flat.hip)
         a.strip_rows = flat.strip_rows;
-    } else if (a.XC == 1 && a.mode == 0 && a.stride == 1 && !a.xup && !a.in_relu && a.KW * a.KW <= 32 && a.Cout <= 64 && !PSEG_KNOB("PSEG_WGRAD_NO_C1") && !scalar) {
+    } else if (a.XC == 1 && a.mode == 0 && a.stride == 1 && !a.xup && !a.in_relu && a.KW * a.KW <= 32 && a.Cout <= 64 && !scalar) {
         variant = V_C1;
         a.strip_rows = std::max(1, cdiv(a.Hy, 1024));
     } else if (a.XC <= 16 * WGM_MAXT && a.Cout <= 16 * WGM_MAXT && !scalar) {
         // a whole kernel row per workgroup for the small k5 layers (mode 0: taps of a row share dY)
-        if (a.mode == 0 && a.KW == 5 && taps % 5 == 0 && !PSEG_KNOB("PSEG_WGRAD_KX1") && ((ti <= 2 && tj <= 2) || (ti <= 2 && tj <= 3) || (ti <= 1 && tj <= 2))) {
+        if (a.mode == 0 && a.KW == 5 && taps % 5 == 0 && ((ti <= 2 && tj <= 2) || (ti <= 2 && tj <= 3) || (ti <= 1 && tj <= 2))) {
             variant = V_KX5;                                   // five times fewer "taps": five times more strips
             a.strip_rows = std::max(1, a.strip_rows / 5);
         } else {
@@ -1229,7 +1229,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
         return ensure_buf((void**)&t->d_wd, &t->wd_bytes, (floats + COT) * 4);
     };
     const int strips_target = 1536;
-    const bool scalar_wgrad = PSEG_KNOB("PSEG_WGRAD_SCALAR") != nullptr;
+    const bool scalar_wgrad = false;
     // Second stream for the weight gradients.  A layer's weight gradient and its data gradient both only READ the layer's output
     // gradient, and nothing downstream of a weight gradient runs before the optimizer: the weight-gradient kernels (and their
     // ordered reductions) go to `ws`, gated by an event recorded on the main stream once dY is final; the main stream carries on

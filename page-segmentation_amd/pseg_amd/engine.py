@@ -14,7 +14,7 @@ FLAG_BATCHNORM = 1
 
 # every symbol include/pseg.h declares (tests check that the library exports each one)
 EXPORTED_SYMBOLS = (
-    "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_create_ex", "pseg_destroy",
+    "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_create_ex", "pseg_create_plan", "pseg_env_knobs", "pseg_destroy",
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
     "pseg_predict", "pseg_predict_device", "pseg_predict_pages_device", "pseg_rccl_abi_pinned", "pseg_predict_batch", "pseg_predict_chain", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
     "pseg_host_alloc", "pseg_host_free", "pseg_host_register", "pseg_host_unregister",
@@ -30,6 +30,9 @@ EXPORTED_SYMBOLS = (
     "pseg_prepare_images", "pseg_affine_warp",
     "pseg_eval_confusion", "pseg_cc_label", "pseg_cc_tables",
 )
+
+
+PLAN_FROM_ENV = bool(os.environ.get("PSEG_PLAN_FROM_ENV"))   # test harness / tools: PSEG_* of os.environ -> plan switches of new engines (see Engine)
 
 
 class PsegError(Exception):
@@ -58,6 +61,8 @@ def lib():
     L.pseg_last_error.restype = c.c_char_p
     L.pseg_create.argtypes = [i, i, i, i, i, c.POINTER(vp)]
     L.pseg_create_ex.argtypes = [i, i, i, i, i, c.c_uint, c.POINTER(vp)]
+    L.pseg_create_plan.argtypes = [i, i, i, i, i, c.c_uint, c.c_char_p, c.POINTER(vp)]
+    L.pseg_env_knobs.restype = c.c_char_p
     L.pseg_destroy.argtypes = [vp]
     L.pseg_num_weights.argtypes = [vp]
     L.pseg_weight_info.argtypes = [vp, i, c.c_char_p, c.c_size_t, c.POINTER(i64), c.POINTER(i)]
@@ -232,14 +237,23 @@ def pinned_copy(a):
 class Engine:
     """Opaque pseg_engine handle: one FCN graph + its weights resident on one GPU."""
 
-    def __init__(self, arch="fcn_skip", n_classes=3, in_channels=1, device=0, mode=MODE_BF16, batch_norm=False):
-        """batch_norm: BatchNormalization at res_unet's bn_act sites (lib/model.py:265-271; PSEG_FLAG_BATCHNORM)."""
+    def __init__(self, arch="fcn_skip", n_classes=3, in_channels=1, device=0, mode=MODE_BF16, batch_norm=False, plan=None):
+        """batch_norm: BatchNormalization at res_unet's bn_act sites (lib/model.py:265-271; PSEG_FLAG_BATCHNORM).
+        plan: plan switches for pseg_create_plan, "PSEG_NO_DQ=1;PSEG_WS_FORM=2" or a dict (tests and A/B measurements: every
+        switch keeps the results within the documented bars).  With PLAN_FROM_ENV set (tests/conftest.py, tools/) and no plan given,
+        the PSEG_* variables of os.environ that the library does not read itself become the plan -- the test suite keeps steering
+        kernels with monkeypatch.setenv while the release library ignores the environment beyond pseg_env_knobs()."""
         self._h = None
         L = lib()
         arch_id = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
         h = ctypes.c_void_p()
-        _check(L.pseg_create_ex(arch_id, int(n_classes), int(in_channels), int(device), int(mode),
-                                FLAG_BATCHNORM if batch_norm else 0, ctypes.byref(h)))
+        if plan is None and PLAN_FROM_ENV:
+            listed = set(L.pseg_env_knobs().decode().split("\n"))
+            plan = {k: v for k, v in os.environ.items() if k.startswith("PSEG_") and k not in listed and k not in ("PSEG_LIB",)}
+        if isinstance(plan, dict):
+            plan = ";".join("%s=%s" % kv for kv in sorted(plan.items()))
+        _check(L.pseg_create_plan(arch_id, int(n_classes), int(in_channels), int(device), int(mode),
+                                  FLAG_BATCHNORM if batch_norm else 0, (plan or "").encode(), ctypes.byref(h)))
         self._h = h
         self.batch_norm = bool(batch_norm)
         self.arch = arch

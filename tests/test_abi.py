@@ -36,6 +36,38 @@ def test_rccl_entry_points_are_pinned_against_the_rccl_header():
     assert pinned == (1 if os.path.exists("/opt/rocm/include/rccl/rccl.h") else 0)
 
 
+def test_release_library_reads_at_most_15_documented_environment_knobs():
+    """The release library takes its environment knobs from ONE list (PSEG_ENV_KNOBS, pseg_env_knobs()): at most 15 names, every
+    one documented in README.md, and no other getenv in the sources -- kernel / fusion plan switches reach an engine only through
+    pseg_create_plan's string (the test harness builds it from os.environ: pseg_amd.engine.PLAN_FROM_ENV)."""
+    import glob
+    import re
+    import pseg_amd
+    names = pseg_amd.lib().pseg_env_knobs().decode().split("\n")
+    assert 1 <= len(names) <= 15 and len(set(names)) == len(names), names
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    assert all(("`%s`" % n) in readme for n in names), [n for n in names if ("`%s`" % n) not in readme]
+    csrc = os.path.join(ROOT, "page-segmentation_amd", "csrc")
+    src = {fn: open(fn).read() for fn in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h"))}
+    # getenv: the snapshot (over the list) and the two macros of the diagnostic build, nothing else
+    calls = [(os.path.basename(fn), ln.strip()) for fn, t in src.items() for ln in t.splitlines() if re.search(r"\bgetenv\(", ln)]
+    assert len(calls) == 3 and sorted(c[0] for c in calls) == ["pseg_common.h", "pseg_common.h", "pseg_engine.hip"], calls
+    # every name the sources look up is a listed environment knob or a plan switch; the total stays reviewable
+    used = sorted({m for t in src.values() for m in re.findall(r'PSEG_KNOB\("(PSEG_[A-Z0-9_]+)"\)', t)})
+    assert set(names) <= set(used), sorted(set(names) - set(used))          # no listed knob is dead
+    assert len(used) <= 48, (len(used), used)
+
+
+def test_plan_switches_do_not_come_from_the_environment(monkeypatch):
+    """A plan switch in the process environment does not reach the snapshot an engine would take; a listed knob does (checked on
+    the snapshot text the library reports -- no GPU needed)."""
+    import pseg_amd
+    from pseg_amd import engine as E
+    assert E.PLAN_FROM_ENV                                                  # (tests/conftest.py: the harness translates for the tests)
+    listed = pseg_amd.lib().pseg_env_knobs().decode().split("\n")
+    assert "PSEG_NO_SP" in listed and "PSEG_NO_DQ" not in listed and "PSEG_WS_FORM" not in listed
+
+
 def test_oracle_library_is_separate_from_the_product():
     """Nothing of the oracle is linked into or imported by the product package."""
     import subprocess

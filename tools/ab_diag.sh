@@ -1,4 +1,5 @@
 #!/bin/bash
+export PSEG_PLAN_FROM_ENV=1   # PSEG_* variables set below become the plan switches of the engines the Python tools create
 # ablations on the diagnostic build (results wrong, timing only): tools/ab_diag.sh "<PSEG_DBG=8>" ...
 export PSEG_LIB=page-segmentation_amd/csrc/libpseg_diag.so
 for v in "" "$@"; do

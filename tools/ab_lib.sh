@@ -1,4 +1,5 @@
 #!/bin/bash
+export PSEG_PLAN_FROM_ENV=1   # PSEG_* variables set below become the plan switches of the engines the Python tools create
 # same-box A/B of two builds of the library: tools/ab_lib.sh <lib_a.so> <lib_b.so> [bench args]
 A=$1; B=$2; shift 2
 for rep in 1 2 3; do

@@ -5,6 +5,7 @@ Also times prepare_images (host buffers) on an A4 scan.  Prints one JSON line.
 Default: the uint8 label map end to end (pseg_predict_device labels_u8 -> pseg_cc_vote_device_u8 -> pseg_masks_device_u8), the
 entries bench.py's extra.config5 leg times and the Predictor chain uses; --int64: the reference's int64 maps."""
 import ctypes, json, os, sys, time
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np

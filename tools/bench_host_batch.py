@@ -1,5 +1,6 @@
 """pseg_predict_batch from pinned host memory to pinned host memory (SURVEY 8d's boundary metric), 8 pages of 2048x1536."""
 import os, sys
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np, torch

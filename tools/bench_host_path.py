@@ -1,6 +1,7 @@
 """PCIe-inclusive rate of the host-buffer entry pseg_predict (never the bench `value`): uint8 page in
 host memory -> labels (and optionally logits / probabilities) back in host memory."""
 import os, sys, time
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np

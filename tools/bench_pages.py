@@ -1,6 +1,7 @@
 """Page batches (pseg_predict_pages_device / pseg_predict_batch units) against page-by-page launches: labels equal, ms per page.
     python tools/bench_pages.py [pages] [H W]"""
 import os, sys, time
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np

@@ -2,6 +2,7 @@
 clipnorm 1).  One rank per GPU; with WORLD_SIZE > 1 the flat gradient is all-reduced over RCCL.
 Prints one JSON line on rank 0.  Not the headline metric (bench.py is)."""
 import argparse, json, os, sys, time
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np

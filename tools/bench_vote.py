@@ -2,6 +2,7 @@
 (two speckled image rectangles: one percolating component each + thousands of specks) and the same page with the
 rectangles blanked (text only).  PSEG_CCL_GLOBAL=1 selects the page-global union-find path."""
 import ctypes, json, os, sys, time
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np

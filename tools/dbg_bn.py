@@ -1,5 +1,6 @@
 """First layer at which the float32 engine's res_unet + BatchNormalization activations leave the oracle's."""
 import sys, os
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]

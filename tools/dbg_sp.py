@@ -1,6 +1,7 @@
 """conv_sp_kernel against the conv_mfma_kernel instances it replaces (PSEG_NO_SP=1): stored activations layer by layer, labels,
 per-kernel times.  GPU box:  python tools/dbg_sp.py [H W]..."""
 import os, sys
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np

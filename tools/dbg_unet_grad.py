@@ -1,5 +1,6 @@
 """Debug aid: per-tensor gradient error of the unet train step against torch autograd (float32 and float64 referees)."""
 import os, sys
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.environ.get("DBG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np

@@ -1,4 +1,5 @@
 import os, sys, subprocess
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 sys.path[:0] = ['.', 'page-segmentation_amd']
 import numpy as np
 if len(sys.argv) > 1:

@@ -1,5 +1,6 @@
 """Per-kernel durations of one float32 predict under rocprofv3 (run as: rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/f32_seq.py run), then print: python3 tools/f32_seq.py show DIR"""
 import sys, os, glob, csv
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if sys.argv[1] == "run":
     sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]

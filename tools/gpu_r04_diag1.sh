@@ -1,4 +1,5 @@
 #!/bin/bash
+export PSEG_PLAN_FROM_ENV=1   # PSEG_* variables set below become the plan switches of the engines the Python tools create
 # round-4 diagnostics pass 1: LDS-DMA ring fill rate vs issuing waves; phase stamps of the 1/8-resolution k5 layers
 set -o pipefail
 OUT=$PWD/gpurun_out

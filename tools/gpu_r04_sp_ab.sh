@@ -1,4 +1,5 @@
 #!/bin/bash
+export PSEG_PLAN_FROM_ENV=1   # PSEG_* variables set below become the plan switches of the engines the Python tools create
 # conv_sp_kernel: phase stamps, default and with the loaders' DMAs switched off (diagnostic build, wrong results)
 OUT=$PWD/gpurun_out
 timeout -k 10 200 python3 tools/sp_trace.py > $OUT/r04_sp_trace_rel.txt 2>&1

@@ -8,6 +8,7 @@
         logit error x / 2 would have to flag.
     python tools/label_exact_study.py [tag]"""
 import json, os, sys
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np

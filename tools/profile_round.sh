@@ -1,4 +1,5 @@
 #!/bin/bash
+export PSEG_PLAN_FROM_ENV=1   # PSEG_* variables set below become the plan switches of the engines the Python tools create
 # rocprofv3 evidence for one round (run on the GPU box from the repo root):  tools/profile_round.sh r03
 #   1. --kernel-trace --stats of the default bench (per-kernel average durations of the bf16 page)
 #   2. --kernel-trace --stats of every other leg the bench line quotes: float32 engine, train step, unet, res_unet, configs[4]

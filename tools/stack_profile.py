@@ -6,6 +6,7 @@ inflate the numbers).  Two steps inside one gpurun command:
 flops) to gpurun_out/stack_ops_<arch>.json; `merge` pairs it with the trace and reports every layer plus the
 k3-conv-stack aggregate (north star: >= 40 % of the dense bf16 MFMA peak on the 3x3 stack of unet)."""
 import csv, glob, json, os, sys
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 PAGES, PEAK = 12, 2.5e15
 mode, arch = sys.argv[1], sys.argv[2]
 if mode == "run":

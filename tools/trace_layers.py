@@ -2,6 +2,7 @@
 Needs the diagnostic build:  make -C page-segmentation_amd/csrc libpseg_diag.so
     PSEG_LIB=page-segmentation_amd/csrc/libpseg_diag.so python tools/trace_layers.py [arch] [layers...]"""
 import os, sys, subprocess
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]
 import numpy as np

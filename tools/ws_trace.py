@@ -1,6 +1,7 @@
 """Phase cycles of conv12_ws_kernel (PSEG_WS_TRACE=1): per-wave s_memtime sums written by the kernel to
 gpurun_out/ws_trace.bin -- consumers: k-loop / epilogue / barrier wait, producers: fill / barrier wait."""
 import os, sys
+os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 os.environ["PSEG_WS_TRACE"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "page-segmentation_amd")]

@@ -86,6 +86,9 @@ extern "C" int pseg_predict_chain(pseg_engine* h, const uint8_t* img, int H, int
     if (need_bin) PSEG_TRY(censure(c, CB_BIN, nl));
     if (want_masks) { PSEG_TRY(censure(c, CB_MASKS, 4 * nla * 3)); PSEG_TRY(censure(c, CB_LUT, (size_t)n_lut * 3)); }
     if (labels) PSEG_TRY(censure(c, CB_I64, nl * 8));
+    // every way out -- also an error return in the middle -- ends with both streams drained: copies from / to the caller's host
+    // arrays must not be in flight when the caller gets its buffers back
+    struct Drain { hipStream_t a, b; ~Drain() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); } } drain{st, c.s_aux};
     // uploads: the page on the engine's stream (the network waits for it anyway), binarisation and colour table beside it
     PSEG_HIP(hipMemcpyAsync(c.d_buf[CB_IMG], img, npx * e.in_ch, hipMemcpyHostToDevice, st));
     if (need_bin) PSEG_HIP(hipMemcpyAsync(c.d_buf[CB_BIN], binary, nl, hipMemcpyHostToDevice, c.s_aux));

@@ -4290,6 +4290,17 @@ static int launch_generic_any(const MConv& a0, const MfmaPlan& P, dim3 grid, hip
     return launch_generic_any2(a0, P, grid, st);
 }
 
+// compute units of the current device (cached per device: persistent kernels launch one workgroup per CU)
+static int device_cus(int* dev_out = nullptr) {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev_out) *dev_out = dev;
+    int& n = cache[dev & 63];
+    if (n == 0 && (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)) n = 256;
+    return n;
+}
+
 static void fill_common(const Engine& e, const Op& op, const MfmaPlan& P, MConv& a) {
     const Tensor& s0 = e.tensors[op.src0];
     const Tensor* s1 = op.src1 >= 0 ? &e.tensors[op.src1] : nullptr;
@@ -4445,10 +4456,8 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     // streamed-weights persistent kernel with loader waves (conv_sp_kernel): conv5, conv6, conv7, deconv1 (+ deconv2), deconv3
     if (P->sp && !a.trace && !PSEG_KNOB("PSEG_NO_SP") && !PSEG_KNOB("PSEG_GENERIC") && (op.dq_fuse >= 0) == ((P->sp_fl & SP_DQ) != 0) &&
         (op.pool_dst >= 0) == ((P->sp_fl & SP_POOL) != 0)) {
-        static int cus_sp = 0;
         int dev = 0;
-        PSEG_HIP(hipGetDevice(&dev));
-        if (!cus_sp) PSEG_HIP(hipDeviceGetAttribute(&cus_sp, hipDeviceAttributeMultiprocessorCount, dev));
+        const int cus_sp = device_cus(&dev);
         // Where it pays (same box, us per layer, conv_sp_kernel vs conv_mfma_kernel): the 80-channel layers always (2048x1536: conv7 20.5 vs
         // 27.0, deconv1 + deconv2 30.4 vs 39.3; 4096x3072: 48.7 vs 73.1, 75.3 vs 112.1 -- their five cout tiles leave conv_mfma_kernel two
         // workgroups per CU at best); the 40- / 60-channel layers while a launch is one round of tiles (1024x768: 14.7 / 19.7 / 26.7 vs
@@ -4521,10 +4530,8 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     if (P->wg3 && P->KS == 5 && P->NT == 3 && P->MT == 4 && P->NW == 4 && P->nblk == 1 && P->nblocks_n == 1 && op.Cout <= 40 && !op.transposed &&
         op.src1 < 0 && !a.add && !a.in_relu && !a.up0 && op.fuse1 < 0 && op.tail_logits < 0 && op.skiplog < 0 && op.relu_dst < 0 &&
         P->pp && (a.sigma == 4 || a.sigma == 5) && !a.trace && !PSEG_KNOB("PSEG_NO_PP") && !PSEG_KNOB("PSEG_GENERIC")) {
-        static int cus_pp = 0;
         int dev = 0;
-        PSEG_HIP(hipGetDevice(&dev));
-        if (!cus_pp) PSEG_HIP(hipDeviceGetAttribute(&cus_pp, hipDeviceAttributeMultiprocessorCount, dev));
+        const int cus_pp = device_cus(&dev);
         const int TB = round_up(P->THH * P->row_pitch, 16);
         const int lds = 2 * TB + P->ks_full * 2560 + 16 + round_up(P->ks_full * 16, 16);
         if (lds <= 160 * 1024 && (int)grid.x >= 2 * cus_pp) {
@@ -4552,10 +4559,8 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && P->MT == 8 && P->NT == 2 && P->KS == 5 && a.sigma == 3 &&
         a.pool_dst && !a.add && !a.in_relu && !a.relu && !PSEG_KNOB("PSEG_NO_WS") && !PSEG_KNOB("PSEG_NO_PERSIST") && !PSEG_KNOB("PSEG_GENERIC") && !a.trace) {
         const bool ws_trace = PSEG_DIAG_KNOB("PSEG_WS_TRACE") != nullptr;   // developer aid: per-wave phase cycles -> gpurun_out/ws_trace.bin
-        static int cus_ws = 0;
         int dev = 0;
-        PSEG_HIP(hipGetDevice(&dev));
-        if (!cus_ws) PSEG_HIP(hipDeviceGetAttribute(&cus_ws, hipDeviceAttributeMultiprocessorCount, dev));
+        const int cus_ws = device_cus(&dev);
         MConv w = a;
         const int TB = round_up(P->THH * P->row_pitch, 16);
         w.lds_w_off = TB;                                   // the kernel's tile stride
@@ -4599,12 +4604,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
     }
     if (P->pairc2) return fail(PSEG_EUNSUPPORTED, "layer %s is packed for conv12_ws_kernel (paired half chunks), which cannot take this launch", op.layer.c_str());
     if (op.fuse1 >= 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && !PSEG_KNOB("PSEG_NO_PERSIST") && !PSEG_KNOB("PSEG_GENERIC")) {
-        static int cus = 0;   // one device model per process
-        if (!cus) {
-            int dev = 0;
-            PSEG_HIP(hipGetDevice(&dev));
-            PSEG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        }
+        const int cus = device_cus();
         a.ntiles = (int)grid.x;
         grid.x = std::min<unsigned>(grid.x, 2u * (unsigned)cus);
     }

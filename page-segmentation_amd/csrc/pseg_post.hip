@@ -766,8 +766,19 @@ int pseg_bbox_fill_device_u8(int device, const uint8_t* d_pred, uint8_t* d_out, 
     PSEG_TRY(set_dev(device));
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)H * W;
-    int64_t* d_tmp = nullptr;
-    PSEG_HIP(hipMalloc((void**)&d_tmp, n * 16));
+    // the two int64 planes live in the device's bounding-box scratch (kept between calls: 200 MB at 4096x3072 were allocated and
+    // freed per call); the call ends synchronised and holds the scratch's lock to its end, so one call at a time uses it
+    static std::mutex mu[64];
+    static int64_t* scratch[64] = {nullptr};
+    static size_t scratch_bytes[64] = {0};
+    std::lock_guard<std::mutex> lk(mu[device & 63]);
+    if (scratch_bytes[device & 63] < n * 16) {
+        if (scratch[device & 63]) (void)hipFree(scratch[device & 63]);
+        scratch[device & 63] = nullptr; scratch_bytes[device & 63] = 0;
+        PSEG_HIP(hipMalloc((void**)&scratch[device & 63], n * 16));
+        scratch_bytes[device & 63] = n * 16;
+    }
+    int64_t* const d_tmp = scratch[device & 63];
     const int g = (int)std::min<size_t>((n + 255) / 256, 8192);
     widen_u8_i64_kernel<<<g, 256, 0, st>>>(d_pred, d_tmp, n);
     int rc = bbox_fill_device(d_tmp, d_tmp + n, H, W, st);
@@ -776,7 +787,6 @@ int pseg_bbox_fill_device_u8(int device, const uint8_t* d_pred, uint8_t* d_out, 
         if (hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "bbox narrow launch failed");
     }
     (void)hipStreamSynchronize(st);
-    (void)hipFree(d_tmp);
     return rc;
 }
 

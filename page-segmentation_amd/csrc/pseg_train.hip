@@ -1243,6 +1243,13 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
         }
         ws = t->wstream;
     }
+    // every way out of this function -- also an early error return -- leaves the main stream waiting for what was enqueued on `ws`:
+    // the next step's zeroing of the gradient buffer and its forward must not overtake weight-gradient kernels still in flight
+    struct Join {
+        hipStream_t ws, st; hipEvent_t ev; bool done = false;
+        void now() { if (!done && ws != st && ev) { (void)hipEventRecord(ev, ws); (void)hipStreamWaitEvent(st, ev, 0); } done = true; }
+        ~Join() { now(); }
+    } join{ws, st, t->ev_wdone};
     auto dy_ready = [&]() -> int {      // everything enqueued on the main stream so far is visible to the next kernel on ws
         if (ws != st) { PSEG_HIP(hipEventRecord(t->ev_dy, st)); PSEG_HIP(hipStreamWaitEvent(ws, t->ev_dy, 0)); }
         return PSEG_OK;
@@ -1442,7 +1449,7 @@ static int train_fwd_bwd(Engine& e, const uint8_t* img, const uint8_t* mask, int
         }
     }
     (void)producer_of;
-    if (ws != st) { PSEG_HIP(hipEventRecord(t->ev_wdone, ws)); PSEG_HIP(hipStreamWaitEvent(st, t->ev_wdone, 0)); }   // the optimizer / all-reduce / readers see every gradient
+    join.now();   // the optimizer / all-reduce / readers see every gradient
     return PSEG_OK;
 }
 

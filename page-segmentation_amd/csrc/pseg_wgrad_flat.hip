@@ -252,18 +252,23 @@ bool wgrad_flat_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan) {
         // chip holds at this instance's occupancy (asked of the runtime once), never a few more -- 528 workgroups on 512
         // slots ran three rounds for the work of two (conv4: 740 us against 500).  One column piece per workgroup where the
         // map is tall enough to keep the ring primed for many rows; shorter maps give a workgroup several pieces.
-        static int wg_per_cu[sizeof(g_flat) / sizeof(g_flat[0])];
-        if (wg_per_cu[k] == 0) {
+        // (per device: the strip partition -- and with it the summation order of the gradient -- follows the CURRENT device's CU count
+        // and occupancy; gradients are bit-reproducible per device configuration, not across different ones)
+        static int wg_per_cu[64][sizeof(g_flat) / sizeof(g_flat[0])];
+        static int ncu_dev[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 63;
+        if (wg_per_cu[dev][k] == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)f.kernel, f.NW * 64, 0) != hipSuccess || n < 1) n = f.wg_per_cu;
-            wg_per_cu[k] = n;
+            wg_per_cu[dev][k] = n;
         }
-        static int ncu = 0;
-        if (ncu == 0) {
-            int dev = 0, n = 0;
-            ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        if (ncu_dev[dev] == 0) {
+            int n = 0;
+            ncu_dev[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
         }
-        const int target = ncu * wg_per_cu[k];
+        const int target = ncu_dev[dev] * wg_per_cu[dev][k];
         const int min_rows = f.KYN > 1 ? 8 : 2;               // a strip shorter than this mostly primes its ring
         int cgroups = cpr, rows = 1;
         for (;;) {
@@ -508,19 +513,22 @@ bool wgrad_pair_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan) {
         if (f.mode == 1 ? (f.CO != a.Cout || taps != 4 || a.KW != 2) : (a.Cout > 16 || taps != 1 || a.KW != 1 || a.maskY != nullptr)) continue;
         if (a.Cin != a.XC || a.ci0 != 0) continue;
         const int itH = a.mode == 1 ? a.Hx : a.Hy, itW = a.mode == 1 ? a.Wx : a.Wy;
-        static int wg_per_cu[sizeof(g_pair) / sizeof(g_pair[0])];
-        if (wg_per_cu[k] == 0) {
+        static int wg_per_cu[64][sizeof(g_pair) / sizeof(g_pair[0])];       // (per device, as in wgrad_flat_plan)
+        static int ncu_dev[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 63;
+        if (wg_per_cu[dev][k] == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)f.kernel, f.NW * 64, 0) != hipSuccess || n < 1) n = f.wg_per_cu;
-            wg_per_cu[k] = n;
+            wg_per_cu[dev][k] = n;
         }
-        static int ncu = 0;
-        if (ncu == 0) {
-            int dev = 0, n = 0;
-            ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        if (ncu_dev[dev] == 0) {
+            int n = 0;
+            ncu_dev[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
         }
         // these layers are bound by the bytes they read: a workgroup per slot of ONE resident round, whole rows per workgroup
-        const int target = ncu * wg_per_cu[k];
+        const int target = ncu_dev[dev] * wg_per_cu[dev][k];
         const int cpr = cdiv(itW, f.PW);
         // (row strips x column groups) with at most `target` workgroups and the fewest steps for the busiest one
         int best_cg = 1, best_rows = itH, best_steps = 1 << 30;

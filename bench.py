@@ -125,10 +125,12 @@ def _sync_time(torch, fn, n, warm=2):
     return (time.perf_counter() - t0) / n
 
 
-def leg_host_path(np, pseg_amd, eng, synth, H, W, C, n_pages=8, reps=3):
+def leg_host_path(np, pseg_amd, eng, synth, H, W, C, n_pages=32, reps=3):
     """SURVEY.md 8d boundary: uint8 pages in PINNED host memory -> label maps in pinned host memory through
-    pseg_predict_batch (upload of page i+1 / download of page i-1 overlap the compute of page i)."""
-    pages = [pseg_amd.pinned_copy(synth.synth_page(100 + i, H, W, C)[0]) for i in range(n_pages)]
+    pseg_predict_batch (copies of the neighbouring page units overlap the compute of the current one); configs[2]'s 32 pages
+    per rank: eight synthetic pages, each in the list four times (own input and output buffers)."""
+    base = [synth.synth_page(100 + i, H, W, C)[0] for i in range(min(8, n_pages))]
+    pages = [pseg_amd.pinned_copy(base[i % len(base)]) for i in range(n_pages)]
     out = {}
     for name, dt in (("uint8", np.uint8), ("int64", np.int64)):
         outs = [pseg_amd.pinned_empty((H, W), dt) for _ in range(n_pages)]
@@ -148,8 +150,8 @@ def leg_host_path(np, pseg_amd, eng, synth, H, W, C, n_pages=8, reps=3):
     eng.predict_batch(pg, dtype=np.uint8, out=outs)
     tp = (time.perf_counter() - t0) / n_pages
     out["uint8_pageable_via_ring"] = {"ms_per_page": round(tp * 1e3, 4), "Mpixels_s": round(H * W / tp / 1e6, 1)}
-    out["what"] = ("pseg_predict_batch, %d pages of %dx%d, pages and label maps in pinned host memory (pseg_host_alloc), "
-                   "median of %d passes; PCIe-inclusive, never the headline value" % (n_pages, H, W, reps))
+    out["what"] = ("pseg_predict_batch, %d pages of %dx%d (configs[2]'s share of one rank), pages and label maps in pinned host memory "
+                   "(pseg_host_alloc), units of up to 8 same-shape pages, median of %d passes; PCIe-inclusive, never the headline value" % (n_pages, H, W, reps))
     return out
 
 
@@ -493,7 +495,7 @@ def run_rank(args):
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
         # runs, gfx950 correction applied) recorded under profiles/ by tools/pmc_traffic.py -- replayed, not measured here
         traffic, traffic_src = None, None
-        for fn in ("r03_traffic.json", "r02_traffic.json", "r01e_traffic.json"):
+        for fn in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01e_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     tr = json.load(f).get(name)

@@ -6,7 +6,7 @@ export PSEG_PLAN_FROM_ENV=1   # PSEG_* variables set below become the plan switc
 #   3. separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ busy + MFMA busy cycles), no tracing beside them
 # Raw output lands in gpurun_out/<tag>_*; the summaries to keep are copied to profiles/ by tools/pmc_traffic.py and by hand.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 stats() {   # stats <name> <program args...>
@@ -23,7 +23,11 @@ stats train python3 tools/bench_train.py --height 2048 --width 1536 --steps 6 --
 unset PSEG_TRAIN_ONE_STREAM
 stats unet python3 bench.py --arch unet --steps 5 --warmup 2 --no-cpu-baseline --no-extra || exit 4
 stats res_unet python3 bench.py --arch res_unet --steps 5 --warmup 2 --no-cpu-baseline --no-extra || exit 5
-stats config5 python3 tools/bench_config5.py || exit 6
+stats config5 python3 tools/bench_config5.py || exit 6          # the uint8 entries bench.py's extra.config5 leg times (--int64: the reference's maps)
+stats pages32 python3 bench.py --pages 32 --steps 3 --warmup 1 --no-cpu-baseline --no-extra || exit 6
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_c5_fetch -- python3 tools/bench_config5.py > $OUT/${TAG}_c5_fetch.log 2>&1 || exit 7
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_c5_write -- python3 tools/bench_config5.py > $OUT/${TAG}_c5_write.log 2>&1 || exit 8
+python3 tools/pmc_traffic.py $OUT/${TAG}_c5_fetch $OUT/${TAG}_c5_write $OUT/${TAG}_config5_traffic.json
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_fetch.log 2>&1 || exit 7
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_write.log 2>&1 || exit 8
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/${TAG}_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_sq.log 2>&1 || echo "SQ pass failed (counter set not available?)"

@@ -15,14 +15,23 @@ def shard_pages(n_pages: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_pages, world))
 
 
-def predict_pages_sharded(predict_fn: Callable[[np.ndarray], np.ndarray], pages: Sequence[np.ndarray],
-                          rank: int = 0, world: int = 1, gather: bool = True) -> Optional[List[np.ndarray]]:
-    """Every rank predicts its own pages with `predict_fn(page) -> label map`; with gather=True
+def predict_pages_sharded(predict_fn: Optional[Callable[[np.ndarray], np.ndarray]], pages: Sequence[np.ndarray],
+                          rank: int = 0, world: int = 1, gather: bool = True,
+                          batch_fn: Optional[Callable[[List[np.ndarray]], List[np.ndarray]]] = None) -> Optional[List[np.ndarray]]:
+    """Every rank predicts its own pages with `predict_fn(page) -> label map` -- or, given `batch_fn(list of pages) -> list of
+    label maps` (e.g. `lambda ps: engine.predict_batch(ps, dtype=np.uint8)`), its whole share in ONE call, so that the share
+    travels through pseg_predict_batch's page units (same-shape neighbours computed together); with gather=True
     rank 0 returns all label maps in page order (other ranks return None).  Pages may differ
     in size (ragged) and a rank may own no page at all.  Label maps travel as plain tensors, one point-to-point
     message per page (shapes and dtypes are exchanged first in one small integer table; nothing is pickled)."""
     mine = shard_pages(len(pages), rank, world)
-    local = [(i, np.ascontiguousarray(predict_fn(pages[i]))) for i in mine]
+    if batch_fn is not None:
+        maps = batch_fn([pages[i] for i in mine]) if mine else []
+        if len(maps) != len(mine):
+            raise ValueError("batch_fn returned %d label maps for %d pages" % (len(maps), len(mine)))
+        local = [(i, np.ascontiguousarray(m)) for i, m in zip(mine, maps)]
+    else:
+        local = [(i, np.ascontiguousarray(predict_fn(pages[i]))) for i in mine]
     if world == 1:
         return [lab for _, lab in local]
     if not gather:

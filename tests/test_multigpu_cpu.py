@@ -48,7 +48,7 @@ def _worker(rank, world, port, q, fn_name="_predict"):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pages = _pages()
-    fn = globals()[fn_name]
+    fn = globals().get(fn_name)
     if fn_name == "_predict_bad_dtype":
         # every rank must raise (nobody is left blocked in a send): the barrier below is reached by both
         try:
@@ -60,7 +60,11 @@ def _worker(rank, world, port, q, fn_name="_predict"):
         q.put((rank, raised))
         dist.destroy_process_group()
         return
-    out = predict_pages_sharded(fn, pages, rank, world)
+    if fn_name == "_predict_share_in_one_call":
+        # a rank's whole share through ONE call (the route to pseg_predict_batch's page units)
+        out = predict_pages_sharded(None, pages, rank, world, batch_fn=lambda ps: [_predict(p_) for p_ in ps])
+    else:
+        out = predict_pages_sharded(fn, pages, rank, world)
     dist.barrier()
     if rank == 0:
         q.put([o.tolist() for o in out])
@@ -85,6 +89,16 @@ def _run_two_ranks(fn_name, n_results=1):
 
 def test_two_rank_page_sharding_matches_single_process(oracle_mod):
     got = _run_two_ranks("_predict")[0]
+    want = [_predict(p) for p in _pages()]
+    assert len(got) == len(want)
+    for g, w_ in zip(got, want):
+        assert np.array_equal(np.array(g), w_)
+
+
+def test_two_rank_page_sharding_with_one_call_per_share(oracle_mod):
+    """batch_fn: every rank hands its whole share to one call (on the GPU: Engine.predict_batch, whose same-shape neighbours run as
+    page units); the gathered maps are the single-process ones, in page order."""
+    got = _run_two_ranks("_predict_share_in_one_call")[0]
     want = [_predict(p) for p in _pages()]
     assert len(got) == len(want)
     for g, w_ in zip(got, want):

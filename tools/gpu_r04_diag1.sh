@@ -6,6 +6,5 @@ OUT=$PWD/gpurun_out
 timeout -k 10 120 tools/microtests/lds_dma_ring.bin > $OUT/r04_dma_ring.txt 2>&1; echo "ring rc=$?"
 export PSEG_LIB=page-segmentation_amd/csrc/libpseg_diag.so
 timeout -k 10 200 python3 tools/trace_layers.py fcn_skip conv2d_6 conv2d_transpose conv2d_4 conv2d_5 conv2d_transpose_2 > $OUT/r04_trace_default.txt 2>&1; echo "trace rc=$?"
-PSEG_LDS_KB=156 timeout -k 10 200 python3 tools/trace_layers.py fcn_skip conv2d_6 conv2d_transpose > $OUT/r04_trace_lds156.txt 2>&1; echo "trace156 rc=$?"
 PSEG_DBG=8 timeout -k 10 200 python3 tools/trace_layers.py fcn_skip conv2d_6 conv2d_transpose > $OUT/r04_trace_nowdma.txt 2>&1; echo "trace nowdma rc=$?"
 cat $OUT/r04_dma_ring.txt $OUT/r04_trace_*.txt

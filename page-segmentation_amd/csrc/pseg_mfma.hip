@@ -2704,9 +2704,10 @@ constexpr int SP_GK = 2;             // k-steps per weight group (the unit of th
 constexpr int SP_SPIN_LIMIT = 1 << 14;   // polls (~100-200 cycles each) before a waiter gives up: > 1 ms, a real wait is microseconds
 constexpr int SP_DQ_PIECES = 48;     // A fragments of the fused transposed conv: [ab 4][cout tile 4][k-step 3]
 
-// tile row pitch of conv_sp_kernel for a pixel of SG 16-byte slots: 36 pixels + the pad the bank model picks (pair_chunks; the host
-// checks that it still does) -- a compile-time constant so that fragment addresses are one register + immediates
-__host__ __device__ constexpr int sp_row_pitch(int sg) { return sg == 4 ? 2304 : (sg == 5 ? 2928 : 0); }
+// tile row pitch of conv_sp_kernel for a pixel of SG 16-byte slots and a tile of `tw` output pixels per row: tw + 4 pixels + the
+// pad the bank model picks for the 32-wide tile (pair_chunks; the host checks that it still does) -- a compile-time constant so
+// that fragment addresses are one register + immediates
+__host__ __device__ constexpr int sp_row_pitch(int sg, int tw = 32) { return sg == 4 ? (tw + 4) * 64 : (sg == 5 ? (tw + 4) * 80 + 48 : 0); }
 
 template <int N>
 __device__ __forceinline__ void sp_wait_vmcnt() {
@@ -2714,14 +2715,21 @@ __device__ __forceinline__ void sp_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NT, int SG, int FL>
+// TWK = output pixels per tile row: 32 (a wave's two rows are four 16-pixel tiles) or 24 (three: two full ones and one whose lanes
+// 0-7 / 8-15 are columns 16-23 of the first / second row).  The narrow tile exists for launches of ONE round: a 2048x1536 page has
+// 256 x 192 pixels at 1/8 resolution = 192 tiles of 8 x 32 for 256 CUs, but exactly 256 of 8 x 24 -- every CU gets three quarters of
+// the work instead of a quarter of the chip idling (host: sp_pick_tw).
+template <int NT, int SG, int FL, int TWK = 32>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_sp_kernel(SConv a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = 4, TH = 8, KS = 5, THH = TH + KS - 1, TWH = TW + KS - 1, PS2 = SG * 16;
-    constexpr int ROWP = sp_row_pitch(SG);                    // tile row pitch: a constant, so that a wave's four pixel fragments are one address + immediates
+    static_assert(TWK == 32 || TWK == 24, "tile rows of two or one and a half 16-pixel MFMA tiles");
+    constexpr int TW = TWK;                                   // (shadows the engine-wide 32)
+    constexpr int MT = TWK == 32 ? 4 : 3, TH = 8, KS = 5, THH = TH + KS - 1, TWH = TW + KS - 1, PS2 = SG * 16;
+    constexpr int ROWP = sp_row_pitch(SG, TWK);               // tile row pitch: a constant, so that a wave's pixel fragments are one address + immediates
     constexpr int WSTEP = NT * 1024;
     constexpr bool POOL = (FL & SP_POOL) != 0, DQ = (FL & SP_DQ) != 0, PATCH = (FL & SP_PATCH) != 0;
     static_assert(!DQ || NT == 5, "the fused transposed conv is written for 80 channels");
+    static_assert(!(POOL && TWK != 32), "the fused pool pairs the rows of full 16-pixel tiles");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* const ring = smem + a.lds_ring_off;
@@ -2919,7 +2927,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float4 biasr[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) biasr[t] = *(const float4*)(a.bias + t * 16 + 4 * g);
-    const int pixb0 = (wave * 2) * ROWP + p16 * PS2;          // fragment m: + (m >> 1) * ROWP + (m & 1) * 16 * PS2 (immediates)
+    // pixel tile m of this wave: row wave * 2 + PR(m, p), column PC(m, p) for lane pixel p (TWK 32: uniform per tile -- immediates)
+    auto PR = [](int m, int p) { return TWK == 32 ? (m >> 1) : (m < 2 ? m : (p >> 3)); };
+    auto PC = [](int m, int p) { return TWK == 32 ? (m & 1) * 16 + p : (m < 2 ? p : 16 + (p & 7)); };
+    const int pixb0 = (wave * 2) * ROWP + p16 * PS2;          // TWK 32, fragment m: + (m >> 1) * ROWP + (m & 1) * 16 * PS2 (immediates)
+    int pixm[MT];                                             // TWK 24: the lane's own offset per tile (the third tile straddles the two rows)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pixm[m] = (wave * 2 + PR(m, p16)) * ROWP + PC(m, p16) * PS2;
     const char* const wb0 = ring + lane * 16;
     const char* const tb = smem + a.lds_tab_off + g * 4;
     const int K = a.K, RK = a.RK;
@@ -2945,7 +2959,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int oy0, ox0, pg;
         origin(i, oy0, ox0, pg);
         const int jb0 = i * a.nblk;                           // tile blocks before this tile
-        const char* const in_t = smem + pixb0 + (one_blk ? (i & 1) * a.TBLK : 0);
+        const char* const in_t = smem + (TWK == 32 ? pixb0 : 0) + (one_blk ? (i & 1) * a.TBLK : 0);
         f32x4 acc[MT][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -2962,7 +2976,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const char* xp_ = in_t + (OFF);                                                      \
             WF[0] = *(const bf16x8*)(wbp_);                                                      \
             _Pragma("unroll") for (int m = 0; m < MT; ++m)                                       \
-                XF[m] = *(const bf16x8*)(xp_ + ((m >> 1) * ROWP + (m & 1) * 16 * PS2));          \
+                XF[m] = *(const bf16x8*)(xp_ + (TWK == 32 ? (m >> 1) * ROWP + (m & 1) * 16 * PS2 : pixm[m])); \
             _Pragma("unroll") for (int t = 1; t < NT; ++t)                                       \
                 WF[t] = *(const bf16x8*)(wbp_ + t * 1024);                                       \
         }
@@ -3088,13 +3102,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         if (a.dq_relu) pk = make_uint2(relu_pk_bf16(pk.x, 0u), relu_pk_bf16(pk.y, 0u));
                         *(uint2*)(pt + p16 * QPP + t * 32 + g * 8) = pk;
                     }
-                    const int y = oy0 + wave * 2 + (m >> 1);
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {             // 16 pixels x 8 pieces of 16 bytes: piece lane + 64 u
                         const int ii = lane + 64 * u, px = ii >> 3, c = ii & 7;
                         const char* sp = pt + px * QPP + c * 16;
                         const uint2 lo = *(const uint2*)sp, hi = *(const uint2*)(sp + 8);
-                        const int x = ox0 + (m & 1) * 16 + px;
+                        const int y = oy0 + wave * 2 + PR(m, px), x = ox0 + PC(m, px);
                         const bool ok = y < a.Hout && x < a.Wout && c < a.dq_nch;
                         const unsigned o = ok ? (unsigned)((2 * y + (ab >> 1)) * W2 + 2 * x + (ab & 1)) * (unsigned)(a.dq_nch * 16) + (unsigned)(c * 16) : OOBS;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_uint4(lo.x, lo.y, hi.x, hi.y)), rq, o, 0, 0);
@@ -3110,7 +3123,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             unsigned pixoff[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int y = oy0 + wave * 2 + (m >> 1), x = ox0 + (m & 1) * 16 + p16;
+                const int y = oy0 + wave * 2 + PR(m, p16), x = ox0 + PC(m, p16);
                 pixoff[m] = (y < a.Hout && x < a.Wout) ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) : OOBS;
             }
             // stores through this wave's own LDS patch (whole 128-byte lines per store instruction, see conv_mfma_kernel) where
@@ -3131,7 +3144,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     const uint2 pk = make_uint2(pk_bf16(v[m][0], v[m][1]), pk_bf16(v[m][2], v[m][3]));
                     if constexpr (PATCH) {
-                        *(uint2*)(patch + ((m >> 1) * TW + (m & 1) * 16 + p16) * LST_PP + t * 32 + g * 8) = pk;
+                        *(uint2*)(patch + (PR(m, p16) * TW + PC(m, p16)) * LST_PP + t * 32 + g * 8) = pk;
                     } else {
                         const unsigned o = (pixoff[m] == OOBS || noff == OOBS) ? OOBS : pixoff[m] + noff;
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rd, o, 0, 0);
@@ -3158,13 +3171,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 constexpr int NP = 2 * TW * PPX;              // pieces of this wave's two rows
                 asm volatile("" ::: "memory");                // (the patch rows are this wave's own: a wave's LDS operations execute in order)
 #pragma unroll
-                for (int u = 0; u < NP / 64; ++u) {
-                    const int ii = lane + 64 * u;
+                for (int u = 0; u < (NP + 63) / 64; ++u) {
+                    const int ii = min(lane + 64 * u, NP - 1);        // (a last, partly filled trip repeats the last piece: masked below)
                     const int px = ii / PPX, c = ii - px * PPX, r = px / TW, xx = px - r * TW;
                     const char* sp = patch + px * LST_PP + c * 16;
                     const uint2 lo = *(const uint2*)sp, hi = *(const uint2*)(sp + 8);
                     const int y = oy0 + wave * 2 + r, x = ox0 + xx;
-                    const bool ok = y < a.Hout && x < a.Wout && c * 16 < CsO * 2;
+                    const bool ok = lane + 64 * u < NP && y < a.Hout && x < a.Wout && c * 16 < CsO * 2;
                     const unsigned o = ok ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) + (unsigned)(c * 16) : OOBS;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_uint4(lo.x, lo.y, hi.x, hi.y)), rd, o, 0, 0);
                 }
@@ -3233,6 +3246,8 @@ struct MfmaPlan {
     bool sp = false;
     int sp_NT = 0, sp_sigma = 0, sp_fl = 0, sp_K = 0, sp_S = 0, sp_blk_steps = 0, sp_nblk = 0, sp_nc_full = 0, sp_nc_last = 0;
     int sp_row_pitch = 0, sp_TBLK = 0, sp_RK = 0, sp_ring_off = 0, sp_patch_off = 0, sp_tab_off = 0, sp_flag_off = 0, sp_lds = 0;
+    // the same layer on tiles of 8 x 24 pixels (conv_sp_kernel<..., 24>): its own LDS layout and k-chunk table, the same weight stream
+    struct SpNarrow { bool ok = false; int row_pitch = 0, TBLK = 0, RK = 0, ring_off = 0, patch_off = 0, tab_off = 0, flag_off = 0, lds = 0; int* d_tab = nullptr; } sp24;
     int* d_sp_tab = nullptr;
     uint16_t* d_sp_wpk = nullptr;
     int* d_sp_err = nullptr;
@@ -3249,7 +3264,7 @@ void mfma_free_op(Op& op) {
     (void)hipFree(p->d_skiplog);
     (void)hipFree(p->d_dq_w); (void)hipFree(p->d_dq_bias);
     (void)hipFree(p->d_q_w); (void)hipFree(p->d_q_bias); (void)hipFree(p->d_t2_wD); (void)hipFree(p->d_t2_wC);
-    (void)hipFree(p->d_sp_tab); (void)hipFree(p->d_sp_wpk); (void)hipFree(p->d_sp_err);
+    (void)hipFree(p->d_sp_tab); (void)hipFree(p->sp24.d_tab); (void)hipFree(p->d_sp_wpk); (void)hipFree(p->d_sp_err);
     delete p;
     op.plan = nullptr;
 }
@@ -3937,6 +3952,31 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
             }
             PSEG_TRY(upload(&P->d_sp_tab, tab));
             PSEG_TRY(upload(&P->d_sp_wpk, spk));
+            // the narrow tile (8 x 24, instances for the 80-channel layers): same chunk ORDER (same products in the same order: same
+            // bits), offsets for its own row pitch, a ring as deep as its smaller tile allows
+            if (NT == 5 && sg == 4 && op.pool_dst < 0 && !PSEG_KNOB("PSEG_NO_SP24")) {
+                auto& N = P->sp24;
+                const int TWN = 24, rowpn = sp_row_pitch(sg, TWN), TBLKn = round_up((8 + KS - 1) * rowpn, 16), tiles_n = nslot * TBLKn;
+                const int patchn = dq ? patchb : 4 * 2 * TWN * (NT * 32 + 8);
+                const int rkn = std::min((LDS_MAX - tiles_n - round_up(tabb, 1024) - 64 - patchn) / (NT * 1024), 16) & ~1;
+                if (rkn >= rk_min) {
+                    N.ok = true; N.row_pitch = rowpn; N.TBLK = TBLKn; N.RK = rkn;
+                    N.ring_off = tiles_n; N.patch_off = tiles_n + rkn * NT * 1024; N.tab_off = N.patch_off + patchn;
+                    N.flag_off = N.tab_off + round_up(tabb, 1024); N.lds = N.flag_off + 64;
+                    std::vector<int> tabn((size_t)K * 4, 0);
+                    for (int b = 0; b < P->nblk; ++b) {
+                        const bool last = b == P->nblk - 1;
+                        const auto& ord = last ? o_last : o_full;
+                        const int ksb = last ? ksl : ksf, st0 = b * ksf, slot_base = P->nblk == 1 ? 0 : b * TBLKn;
+                        for (int st = 0; st < ksb; ++st)
+                            for (int gi = 0; gi < 4; ++gi) {
+                                const Chunk c = ord[(size_t)st * 4 + gi];
+                                if (c.cc >= 0) tabn[(size_t)(st0 + st) * 4 + gi] = slot_base + (c.tap / KS) * rowpn + (c.tap % KS) * sg * 16 + c.cc * 16;
+                            }
+                    }
+                    PSEG_TRY(upload(&N.d_tab, tabn));
+                }
+            }
             std::vector<int> z(8, 0);
             PSEG_TRY(upload(&P->d_sp_err, z));
             if (PSEG_KNOB("PSEG_LOG_SP"))
@@ -4471,10 +4511,22 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         c.tab = P->d_sp_tab; c.wpk = P->d_sp_wpk; c.bias = P->d_bias;
         c.row_pitch = P->sp_row_pitch; c.TBLK = P->sp_TBLK; c.RK = P->sp_RK;
         c.lds_ring_off = P->sp_ring_off; c.lds_patch_off = P->sp_patch_off; c.lds_tab_off = P->sp_tab_off; c.lds_flag_off = P->sp_flag_off;
+        // tiles of 8 x 24 where they need fewer pixel columns per CU than tiles of 8 x 32: rounds of the launch x tile width (a
+        // 2048x1536 page at 1/8 resolution: 192 wide tiles on 256 CUs = 32 columns each, or 256 narrow ones = 24)
+        const int npg_ = e.batch_pages > 1 ? e.batch_pages : 1;
+        const int tiles24 = cdiv(a.Wout, 24) * cdiv(a.Hout, 8);
+        const bool narrow = P->sp24.ok && cdiv(tiles24 * npg_, cus_sp) * 24 < cdiv((int)grid.x * npg_, cus_sp) * 32;
+        int tiles_pp = (int)grid.x, sp_lds = P->sp_lds;
+        if (narrow) {
+            const auto& N = P->sp24;
+            c.tab = N.d_tab; c.row_pitch = N.row_pitch; c.TBLK = N.TBLK; c.RK = N.RK;
+            c.lds_ring_off = N.ring_off; c.lds_patch_off = N.patch_off; c.lds_tab_off = N.tab_off; c.lds_flag_off = N.flag_off;
+            tiles_pp = tiles24; sp_lds = N.lds;
+        }
         c.dst = a.dst; c.dst_bytes = a.dst_bytes; c.nch_out = a.nch_out; c.pool_dst = a.pool_dst; c.pool_bytes = a.pool_bytes;
         c.dq_bias = a.dq_bias; c.dq_dst = a.dq_dst; c.dq_bytes = a.dq_bytes; c.dq_nch = a.dq_nch; c.dq_relu = a.dq_relu;
         const int npg = e.batch_pages > 1 ? e.batch_pages : 1;               // page slots of this launch: a tile index carries the page
-        c.ntiles = (int)grid.x * npg; c.tiles_per_page = (int)grid.x;
+        c.ntiles = tiles_pp * npg; c.tiles_per_page = tiles_pp;
         c.xq = a.xq < 0 ? -1 : c.ntiles / 8; c.xr = c.ntiles % 8;
         c.err = P->d_sp_err;
         c.dbg = PSEG_DIAG_KNOB("PSEG_SP_DBG") ? atoi(PSEG_DIAG_KNOB("PSEG_SP_DBG")) : 0;
@@ -4486,19 +4538,22 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
             PSEG_HIP(hipMemset(c.trace, 0, (size_t)gs.x * 16 * 8));
         }
         bool launched = !sp_pays;
-#define PSEG_SP(NT_, SG_, FL_)                                                                                      \
-        if (!launched && P->sp_NT == NT_ && P->sp_sigma == SG_ && P->sp_fl == (FL_)) {                               \
+#define PSEG_SP_TW(NT_, SG_, FL_, TW_)                                                                              \
+        if (!launched && P->sp_NT == NT_ && P->sp_sigma == SG_ && P->sp_fl == (FL_) && narrow == (TW_ == 24)) {      \
             static bool attr_set[64] = {false};                                                                   \
             if (!attr_set[dev & 63]) {                                                                            \
-                PSEG_HIP(hipFuncSetAttribute((const void*)conv_sp_kernel<NT_, SG_, (FL_)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                PSEG_HIP(hipFuncSetAttribute((const void*)conv_sp_kernel<NT_, SG_, (FL_), TW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
                 attr_set[dev & 63] = true;                                                                        \
             }                                                                                                     \
-            conv_sp_kernel<NT_, SG_, (FL_)><<<gs, 512, P->sp_lds, st>>>(c);                                        \
+            conv_sp_kernel<NT_, SG_, (FL_), TW_><<<gs, 512, sp_lds, st>>>(c);                                      \
             PSEG_HIP(hipGetLastError());                                                                          \
             launched = true;                                                                                      \
         }
+#define PSEG_SP(NT_, SG_, FL_) PSEG_SP_TW(NT_, SG_, FL_, 32)
         PSEG_SP(5, 4, SP_PATCH)                 // conv7
         PSEG_SP(5, 4, SP_DQ)                    // deconv1 + deconv2 (k2 s2) on its accumulators
+        PSEG_SP_TW(5, 4, SP_PATCH, 24)          // ... and on tiles of 8 x 24 (one round of 256 tiles on a 2048x1536 page)
+        PSEG_SP_TW(5, 4, SP_DQ, 24)
         PSEG_SP(4, 5, SP_PATCH)                 // conv5
         PSEG_SP(4, 4, SP_PATCH | SP_POOL)       // conv6
         PSEG_SP(4, 4, SP_PATCH)
@@ -4506,6 +4561,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         PSEG_SP(3, 4, 0)                        // deconv3 (fcn_skip: four channel blocks, no room for the store patch)
         PSEG_SP(3, 4, SP_PATCH)                 // deconv3 (fcn)
 #undef PSEG_SP
+#undef PSEG_SP_TW
         if (!sp_pays) launched = false;
         if (launched && tracing) {
             PSEG_HIP(hipStreamSynchronize(st));

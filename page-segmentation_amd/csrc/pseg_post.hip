@@ -38,12 +38,28 @@ __device__ __forceinline__ int uf_find(const int* L, int x) {
     return x;
 }
 
+// find with path halving: every other node of the walked chain is pointed at its grandparent.  Links only ever point at a member of
+// the same component with a smaller index, a halving store replaces a non-root's link by one further up its own chain, and a
+// root (the only kind of node a union's atomicMin must find unchanged) is never stored to -- racing walkers may undo each other's
+// shortcut, never the structure.  Without it a component that percolates through a figure keeps chains of one hop per tile it
+// crosses (tens of dependent loads for every later find).
+__device__ __forceinline__ int uf_find_halve(int* L, int x) {
+    while (true) {
+        const int p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        const int g = __hip_atomic_load(&L[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g == p) return p;
+        __hip_atomic_store(&L[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = g;
+    }
+}
+
 // Labels only ever decrease and always point at a member of the same component, so a stale
 // read costs extra iterations, never correctness.
 __device__ __forceinline__ void uf_union(int* L, int a, int b) {
     while (true) {
-        a = uf_find(L, a);
-        b = uf_find(L, b);
+        a = uf_find_halve(L, a);
+        b = uf_find_halve(L, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
         const int old = atomicMin(&L[a], b);
@@ -212,8 +228,9 @@ __global__ __launch_bounds__(256) void ccl_border_kernel(const uint8_t* bin, con
         const int p = y * W + x, q = p - W;
         if (!is_fg<MODE>(bin, cls, p)) return;
         if (is_fg<MODE>(bin, cls, q) && connects<MODE>(bin, cls, p, q)) {
-            // as inside a tile: skip where the left neighbours already join the same two runs (not across a vertical border:
-            // the left link of such a pixel is itself a border union that may not have happened yet -- but it will)
+            // as inside a tile: skip where the left neighbours already join the same two runs -- but not at a tile corner: there
+            // the left links are border unions themselves, and the one of p's row is skipped for THIS pair's sake
+            if (MODE == 0 && (x % CT_W) != 0 && bin[p - 1] != 0 && bin[q - 1] != 0) return;
             uf_union(L, p, q);
         } else if (MODE == 2) {
             if (x > 0 && bin[q - 1] != 0) uf_union(L, p, q - 1);
@@ -226,7 +243,10 @@ __global__ __launch_bounds__(256) void ccl_border_kernel(const uint8_t* bin, con
     const int x = (u / H + 1) * CT_W, y = u % H;
     const int p = y * W + x;
     if (!is_fg<MODE>(bin, cls, p)) return;
-    if (is_fg<MODE>(bin, cls, p - 1) && connects<MODE>(bin, cls, p, p - 1)) uf_union(L, p, p - 1);
+    if (is_fg<MODE>(bin, cls, p - 1) && connects<MODE>(bin, cls, p, p - 1)) {
+        // (the pair above joins the same two column runs, unless a horizontal border runs between the two pairs)
+        if (!(MODE == 0 && (y % CT_H) != 0 && bin[p - W] != 0 && bin[p - W - 1] != 0)) uf_union(L, p, p - 1);
+    }
     if (MODE == 2) {
         // up-left diagonal of p (needed when the pixel above p is paper) and, seen from the other side, the up-right
         // diagonal of the pixel below-left of p (needed when the pixel above THAT one, i.e. left of p, is paper);
@@ -264,6 +284,7 @@ int ccl_roots(const uint8_t* d_bin, int* d_L, int H, int W, int connectivity, hi
 // ---------------------------------------------------------------------------------------------
 // majority vote (lib/postprocess.py:9-26)
 // ---------------------------------------------------------------------------------------------
+// ---- page-global path (PSEG_CCL_GLOBAL, or more than V_NCLS_MAX classes): ccl_run + the two kernels below ----
 // hist[root * ncls + class] += 1.  The histogram is as large as the page (one row of ncls counters per possible
 // root), so every counter update that reaches memory is a scattered read-modify-write: the kernel's cost is the
 // NUMBER of global atomics.  A workgroup therefore owns a 32 x 32 pixel tile (a glyph spans one to four tiles
@@ -331,18 +352,365 @@ __global__ void vote_apply_kernel(const int* L, const int* hist, LT* pred, int n
     pred[p] = (LT)best;
 }
 
-// (Round 3 measured a tile-local variant -- 32 x 64 tiles labelled AND counted in LDS, only components that cross a tile
-// border going through global memory, 4 launches, ~3 B/px of traffic: 0.262 ms against 0.182 ms for the path below on
-// configs[4]'s page, 0.161 against 0.145 ms with the speckled image rectangles blanked.  Its LDS union-find over 2 048
-// pixels per workgroup (112 us) costs more than the 32-bit label traffic it saves; removed again, DESIGN.md section 5.
-// Also measured: an apply pass of four pixels per thread that looks at the binarisation before the labels: 0.166 vs 0.160 ms.)
-// Label / histogram workspace of the vote: grow-only, one per device, shared by every caller.  A 4096x3072 6-class
-// page needs 50 + 302 MB; allocating and freeing it per call cost more than the kernels.  Calls are ordered by an
-// event: a call on another stream than the previous user's first waits for that user's kernels, so two streams (or
-// two threads) never run on the buffers at once.  pseg_release_workspace() frees it.
+// ---- the vote's own tile pass (default) ------------------------------------------------------------------------
+// One workgroup labels a 32 x 64 tile in LDS as ccl_tile_kernel does AND counts the classes of every tile-local component there,
+// so that the page-wide passes over a 4 B/px label image (write it, resolve + count it, read it again to apply) disappear:
+//   * the binarisation and the class map are read ONCE per pixel; a tile row's ink is one 64-bit ballot, and every later test
+//     -- left link, ink above, run start, run end -- is bit arithmetic on masks that are uniform over the wave.
+//     (ccl_tile_kernel re-reads bytes for each test: ~5 byte loads per pixel, and a CU's texture addresser takes a 64-lane byte
+//     load at the pace of a 64-lane dword load.)
+//   * a run of ink in a tile row has one root; per class one ballot, the run's first lane takes popcount(class mask & run
+//     mask) and adds it to a 16-bit counter of (class, root): LDS adds per (run, class present) that return nothing.
+//   * a component with no ink neighbour across the tile's edge is CLOSED: its counts are final, the winner is written to those
+//     of its pixels that differ, and nothing else of it ever reaches memory.  An OPEN component gets the next of the tile's
+//     V_OPEN_MAX root slots (id = tile * V_OPEN_MAX + slot): its counts go to row `id` of a compact histogram (plain stores:
+//     no clearing pass, no atomics), its slot to the tile's rim table at every pixel of it that has an ink neighbour across
+//     the edge (all that the border unions look at), one record per run to the tile's run list.
+// No page-sized array is left: the union-find runs over the root ids (tiles * 192 ints: L2-resident; page-sized label and
+// histogram arrays touched at scattered roots cost a TLB miss per access), the rim table is 192 bytes per tile.
+// vote_border_kernel then joins the open components across tile edges, vote_merge_kernel adds the counts of every root slot
+// that is no longer a root to its final root's row, vote_apply_runs_kernel resolves each listed run and writes its pixels.
+// (Round 3's tile-local attempt kept per-pixel LDS atomics for labelling AND counting and a page-sized label image: 0.262 vs
+// 0.182 ms.)
+constexpr int V_OPEN_MAX = 2 * (CT_H + CT_W);   // an open root owns at least one pixel of the tile's rim
+constexpr int V_RUN_MAX = CT_H * CT_W / 2;      // runs of a tile: at most every other pixel starts one
+constexpr int V_NCLS_MAX = 12;                  // LDS: 8 KiB of labels + 4 KiB of counters per class, under the 64 KiB a launch gets unasked (more classes: the page-global path)
+// a run of an open component in its tile's run list: tile-local root | tile row << 11 | first lane << 16 | last lane << 22; the root's
+// slot is in the tile's root-to-slot table (one byte per pixel of the tile, written at the open roots)
+typedef unsigned VRun;
+// rim table of a tile: slot of the root of the pixel at [0, 64) top row, [64, 128) bottom row, [128, 160) left column, [160, 192) right column
+constexpr int V_RIM = 2 * (CT_H + CT_W);
+// counters: 16 bits per (class, tile-local root) -- a tile has 2 048 pixels -- two roots to a word, bumped with 32-bit LDS adds
+// (no carry can cross: a half never exceeds 2 048)
+template <typename LT, int NW>
+__global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __restrict__ bin, LT* pred, int* __restrict__ P, int* __restrict__ hist,
+                                                            uint8_t* __restrict__ rimtab, uint8_t* __restrict__ slotof, int* __restrict__ rootn,
+                                                            VRun* __restrict__ runs, int* __restrict__ runn, int H, int W, int ncls) {
+    extern __shared__ __attribute__((aligned(16))) int vsm[];
+    int* const lab = vsm;                                 // [CT_H * CT_W]
+    unsigned* const cnt = (unsigned*)(vsm + CT_H * CT_W); // [ncls][CT_H * CT_W / 2]
+    __shared__ unsigned long long m64[CT_H + 2];          // ink of tile rows -1 .. CT_H
+    __shared__ unsigned lr[2];                            // ink left / right of the tile, bit = tile row
+    __shared__ unsigned openbits[CT_H * CT_W / 32];
+    __shared__ unsigned rlist[V_RUN_MAX];                 // the tile's runs
+    __shared__ int nboth;                                 // open runs | open roots << 16
+    __shared__ int wnf[NW];                               // runs of each wave's rows
+    constexpr int NTH = NW * 64, HALF = CT_H * CT_W / 2;
+    static_assert(NW >= 4 && CT_H % NW == 0, "waves 0-3 also fetch the tile's surroundings");
+    const int tiles_x = (W + CT_W - 1) / CT_W;
+    const int tile = blockIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y0 = ty * CT_H, x0 = tx * CT_W, x = x0 + lane;
+    constexpr int RPW = CT_H / NW;                        // rows per wave: wave * RPW ...
+    for (int i = threadIdx.x; i < ncls * HALF / 4; i += NTH) ((uint4*)cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x < CT_H * CT_W / 32) openbits[threadIdx.x] = 0;
+    if (threadIdx.x == 0) nboth = 0;
+    // ---- ink + class of this thread's pixels, the tile's surroundings; row pass ----
+    // A wave's RPW rows of 64 bytes are ONE dword load per map (lane -> row lane / 16, dword lane % 16) where the tile lies
+    // inside the page and rows are dword-aligned, handed to the lanes of the columns through the wave's own (still unused)
+    // label rows; byte loads per row otherwise.
+    uint8_t bb[RPW];
+    long long cc[RPW];
+    static_assert(RPW == 4, "a wave's rows are one 64-lane dword load");
+    const int rw0 = wave * RPW;                           // this wave's rows: rw0 .. rw0 + RPW - 1
+    const bool wide = (W & 3) == 0 && x0 + CT_W <= W;
+    if (wide) {
+        uint8_t* const stg = (uint8_t*)(lab + rw0 * CT_W);    // 1 KiB of this wave's own: 256 B ink, 256 B classes
+        const int yl = y0 + rw0 + (lane >> 4);
+        const size_t o = (size_t)yl * W + x0 + (lane & 15) * 4;
+        const unsigned vb = yl < H ? *(const unsigned*)(bin + o) : 0u;
+        ((unsigned*)stg)[lane] = vb;
+        if (sizeof(LT) == 1) {
+            const unsigned vc = yl < H ? *(const unsigned*)((const uint8_t*)pred + o) : 0u;
+            ((unsigned*)stg)[64 + lane] = vc;
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            bb[j] = stg[j * 64 + lane];
+            if (sizeof(LT) == 1) cc[j] = stg[256 + j * 64 + lane];
+            else cc[j] = y0 + rw0 + j < H ? (long long)pred[(size_t)(y0 + rw0 + j) * W + x] : -1ll;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int y = y0 + rw0 + j;
+            const bool in = y < H && x < W;
+            bb[j] = in ? bin[(size_t)y * W + x] : (uint8_t)0;
+            cc[j] = in ? (long long)pred[(size_t)y * W + x] : -1ll;   // (paper included: one round trip for both maps)
+        }
+    }
+    bool hv = false;                                      // waves 0, 1: the rows above / below; waves 2, 3: the columns left / right
+    if (wave < 2) {
+        const int y = wave == 0 ? y0 - 1 : y0 + CT_H;
+        hv = y >= 0 && y < H && x < W && bin[(size_t)y * W + x] != 0;
+    } else if (wave < 4) {
+        const int y = y0 + (lane & 31), xx = wave == 2 ? x0 - 1 : x0 + CT_W;
+        hv = lane < 32 && y < H && xx >= 0 && xx < W && bin[(size_t)y * W + xx] != 0;
+    }
+    int cls[RPW], sr[RPW];
+    unsigned long long mr[RPW];
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= this one
+    int nfirst = 0;                                       // runs of this wave's rows
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int r = rw0 + j;
+        const bool fg = bb[j] != 0;
+        const unsigned long long m = __ballot(fg);
+        mr[j] = m;
+        nfirst += __popcll(m & ~(m << 1));
+        if (lane == 0) m64[r + 1] = m;
+        cls[j] = (fg && cc[j] >= 0 && cc[j] < ncls) ? (int)cc[j] : -1;
+        // runs of ink: a lane's label is the first lane of its run
+        const unsigned long long brk = ~(m & (m << 1));   // lanes that do not continue the lane to their left (bit 0 always)
+        sr[j] = 63 - __clzll((long long)(brk & le));
+        lab[r * CT_W + lane] = fg ? r * CT_W + sr[j] : -1;
+    }
+    if (wave < 4) {
+        const unsigned long long b = __ballot(hv);
+        if (lane == 0) {
+            if (wave == 0) m64[0] = b;
+            else if (wave == 1) m64[CT_H + 1] = b;
+            else lr[wave - 2] = (unsigned)b;
+        }
+    }
+    if (lane == 0) wnf[wave] = nfirst;
+    if (!__syncthreads_or(nfirst)) {                      // a tile of paper
+        if (threadIdx.x == 0) { rootn[tile] = 0; runn[tile] = 0; }
+        return;
+    }
+    int rbase = 0, n_all = 0;                             // this wave's stretch of the tile's run list, all runs of the tile
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) {
+        const int v = wnf[w2];
+        rbase += w2 < wave ? v : 0;
+        n_all += v;
+    }
+    // ---- column pass: a union where a vertical overlap of two runs begins ----
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int r = rw0 + j;
+        if (r == 0) continue;
+        const unsigned long long cur = mr[j] & m64[r];
+        const unsigned long long need = cur & ~(cur << 1);
+        if ((need >> lane) & 1) lds_union(lab, r * CT_W + lane, (r - 1) * CT_W + lane);
+    }
+    __syncthreads();
+    // ---- per row: roots (only first lanes of runs were ever redirected), class counts, open components, the tile's runs ----
+    int root[RPW];
+    unsigned rimbits = 0;
+    // the four rows' chains walked together: four LDS reads in flight per step
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) root[j] = (((mr[j] >> lane) & 1) && sr[j] == lane) ? (rw0 + j) * CT_W + lane : -1;
+    while (true) {
+        bool moved = false;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j)
+            if (root[j] >= 0) {
+                const int up = __hip_atomic_load(&lab[root[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                moved |= up != root[j];
+                root[j] = up;
+            }
+        if (!__any(moved)) break;
+    }
+    // where ink lies across the tile's edge, per row: the rows above / below for the first / last row, bits 0 and 63 for the columns
+    const unsigned long long m_up = m64[0], m_dn = m64[CT_H + 1];
+    const unsigned lr0 = lr[0], lr1 = lr[1];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int r = rw0 + j;
+        const unsigned long long m = mr[j];
+        if (m == 0) continue;                             // (uniform) a row of paper
+        const bool fg = (m >> lane) & 1;
+        const bool first = fg && sr[j] == lane;
+        const int rt = __shfl(root[j], fg ? sr[j] : lane);
+        root[j] = rt;
+        // counts: one LDS add per stretch of one class inside a run (mostly: per run), by the stretch's first lane
+        const unsigned long long brk = ~(m & (m << 1));
+        const int cl = cls[j];
+        const unsigned long long sbrk = brk | __ballot(cl != __shfl_up(cl, 1));
+        const unsigned long long nxt = sbrk & ~le;        // the next stretch (or paper) begins
+        const int len = (nxt ? __builtin_ctzll(nxt) : 64) - lane;
+        if (cl >= 0 && ((sbrk >> lane) & 1))
+            __hip_atomic_fetch_add(&cnt[cl * HALF + (rt >> 1)], (unsigned)len << ((rt & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // ink across the tile's edge: the component is open
+        const unsigned long long rimm = (r == 0 ? m_up : 0ull) | (r == CT_H - 1 ? m_dn : 0ull) | (unsigned long long)((lr0 >> r) & 1u) |
+                                        ((unsigned long long)((lr1 >> r) & 1u) << 63);
+        if (fg && ((rimm >> lane) & 1)) { atomicOr(&openbits[rt >> 5], 1u << (rt & 31)); rimbits |= 1u << j; }
+        // the run list of the tile: root | row << 11 | first lane << 16 | last lane << 22
+        const unsigned long long fm = m & ~(m << 1);
+        if (first) {
+            const unsigned long long above = brk & ~le;
+            const int e = above ? __builtin_ctzll(above) - 1 : 63;
+            rlist[rbase + __popcll(fm & (le >> 1))] = (unsigned)(rt | r << 11 | lane << 16 | e << 22);
+        }
+        rbase += __popcll(fm);
+    }
+    __syncthreads();
+    // ---- per run: a closed component's winner, left where the run's label was (-1: open); an open run goes to the tile's run
+    // list; an open component's root takes a slot, leaves -(slot + 2) there, its counts in the slot's row and makes the slot a root ----
+    for (int i0 = 0; i0 < n_all; i0 += NTH) {
+        const int i = i0 + threadIdx.x;
+        bool open = false, open_root = false;
+        unsigned rec = 0;
+        int rt = 0, pos = 0;
+        if (i < n_all) {
+            rec = rlist[i];
+            rt = rec & 2047;
+            pos = ((rec >> 11) & 31) * CT_W + ((rec >> 16) & 63);
+            open = (openbits[rt >> 5] >> (rt & 31)) & 1;
+            open_root = open && rt == pos;
+            if (!open) {
+                int best = 0, bv = -1;
+                const unsigned* cp = cnt + (rt >> 1);
+                const int sh = (rt & 1) * 16;
+                for (int c = 0; c < ncls; ++c) {
+                    const int v = (int)((cp[c * HALF] >> sh) & 0xffffu);
+                    if (v > bv) { bv = v; best = c; }
+                }
+                lab[pos] = best;
+            } else if (!open_root) lab[pos] = -1;
+        }
+        const unsigned long long om = __ballot(open), orm = __ballot(open_root);
+        if (om) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&nboth, __popcll(om) | (__popcll(orm) << 16));   // runs | roots << 16: one round trip
+            base = __shfl(base, 0);
+            if (open) runs[(size_t)tile * V_RUN_MAX + (base & 0xffff) + __popcll(om & (le >> 1))] = rec;
+            if (open_root) {
+                const int k = (base >> 16) + __popcll(orm & (le >> 1)), id = tile * V_OPEN_MAX + k;
+                lab[pos] = -(k + 2);
+                slotof[(size_t)tile * (CT_H * CT_W) + rt] = (uint8_t)k;
+                P[id] = id;
+                const unsigned* cp = cnt + (rt >> 1);
+                const int sh = (rt & 1) * 16;
+                for (int c = 0; c < ncls; ++c) hist[(size_t)id * ncls + c] = (int)((cp[c * HALF] >> sh) & 0xffffu);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { rootn[tile] = nboth >> 16; runn[tile] = nboth & 0xffff; }
+    // ---- per pixel: the winner where it differs; an open component's slot where the border unions look ----
+    uint8_t* const rim = rimtab + (size_t)tile * V_RIM;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int r = rw0 + j;
+        const unsigned long long m = mr[j];
+        if (m == 0) continue;                             // (uniform; rows below the page are paper)
+        if (!((m >> lane) & 1)) continue;
+        const int rs = lab[r * CT_W + sr[j]];
+        if (rs >= 0) { if (cls[j] != rs) pred[(size_t)(y0 + r) * W + x] = (LT)rs; }
+        else if ((rimbits >> j) & 1) {
+            const uint8_t k = (uint8_t)(-lab[root[j]] - 2);
+            if (r == 0) rim[lane] = k;
+            if (r == CT_H - 1) rim[CT_W + lane] = k;
+            if (lane == 0) rim[2 * CT_W + r] = k;
+            if (lane == CT_W - 1) rim[2 * CT_W + CT_H + r] = k;
+        }
+    }
+}
+
+// unions of the open components across tile edges, on the root slot ids.  Threads exist only for border pixels, as in
+// ccl_border_kernel (same two redundancy rules); a pixel's root slot comes from its tile's rim table.
+__global__ __launch_bounds__(256) void vote_border_kernel(const uint8_t* __restrict__ bin, const uint8_t* __restrict__ rimtab, int* P, int H, int W, int nby, int nbx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tiles_x = (W + CT_W - 1) / CT_W;
+    int ta, tb, ea, eb;                                   // the two tiles and the pixels' places in their rim tables
+    if (t < nby * W) {                                    // horizontal borders: p = first row of a tile band, q above it
+        const int by = t / W + 1, x = t % W;
+        const size_t p = (size_t)by * CT_H * W + x, q = p - W;
+        if (bin[p] == 0 || bin[q] == 0) return;
+        if ((x % CT_W) != 0 && bin[p - 1] != 0 && bin[q - 1] != 0) return;      // the left neighbours join the same two runs (not at a tile corner)
+        ta = by * tiles_x + x / CT_W; tb = ta - tiles_x;
+        ea = x % CT_W; eb = CT_W + x % CT_W;
+    } else {
+        const int u = t - nby * W;
+        if (u >= nbx * H) return;                         // vertical borders: p = first column of a tile column, its left neighbour
+        const int bx = u / H + 1, y = u % H;
+        const size_t p = (size_t)y * W + (size_t)bx * CT_W;
+        if (bin[p] == 0 || bin[p - 1] == 0) return;
+        if ((y % CT_H) != 0 && bin[p - W] != 0 && bin[p - W - 1] != 0) return;  // the pair above joins the same two column runs
+        ta = (y / CT_H) * tiles_x + bx; tb = ta - 1;
+        ea = 2 * CT_W + y % CT_H; eb = 2 * CT_W + CT_H + y % CT_H;
+    }
+    uf_union(P, ta * V_OPEN_MAX + rimtab[(size_t)ta * V_RIM + ea], tb * V_OPEN_MAX + rimtab[(size_t)tb * V_RIM + eb]);
+}
+
+// counts of the root slots that a border union redirected: added to the final root's row (and the slot pointed straight at
+// it: the unions are over, the runs' finds end after one hop).  One wave per tile; the lanes of a wave that share their final
+// root (a figure's percolating component: thousands of slots on the page, one root) are summed first, one lane adds.
+__global__ __launch_bounds__(64) void vote_merge_kernel(int* P, int* hist, const int* rootn, int ncls) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int n = rootn[tile];
+    for (int base = 0; base < n; base += 64) {
+        int id = 0, r = -1;
+        if (base + lane < n) {
+            id = tile * V_OPEN_MAX + base + lane;
+            r = uf_find_halve(P, id);
+            if (r == id) r = -1;
+            else __hip_atomic_store(&P[id], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // lanes that share their final root are summed before one of them adds: group after group of the distinct roots among
+        // the lanes (a text tile: a few, each a lane or two; a figure tile: one or two of dozens of lanes)
+        int v[V_NCLS_MAX];
+#pragma unroll
+        for (int c = 0; c < V_NCLS_MAX; ++c) v[c] = (r >= 0 && c < ncls) ? hist[(size_t)id * ncls + c] : 0;
+        while (true) {
+            const unsigned long long act = __ballot(r >= 0);
+            if (act == 0) break;
+            const int r0 = __builtin_amdgcn_readlane(r, __builtin_ctzll(act));
+            const bool mine = r == r0;
+            const bool alone = __popcll(__ballot(mine)) == 1;
+#pragma unroll
+            for (int c = 0; c < V_NCLS_MAX; ++c) {
+                if (c < ncls) {                               // (uniform)
+                    int sum = mine ? v[c] : 0;
+                    if (!alone) {
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                    }
+                    if ((alone ? mine : lane == 0) && sum) atomicAdd(&hist[(size_t)r0 * ncls + c], sum);
+                }
+            }
+            if (mine) r = -1;
+        }
+    }
+}
+
+// the runs of the open components: final root, np.argmax of its counters (the lowest class among the most frequent,
+// lib/postprocess.py:22-23), written to the run's pixels
+template <typename LT>
+__global__ __launch_bounds__(256) void vote_apply_runs_kernel(const int* __restrict__ P, const int* __restrict__ hist, const VRun* __restrict__ runs,
+                                                              const int* __restrict__ runn, const uint8_t* __restrict__ slotof, LT* pred, int W, int ncls) {
+    const int tile = blockIdx.x;
+    const int n = runn[tile];
+    if (n == 0) return;
+    const int tiles_x = (W + CT_W - 1) / CT_W;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const VRun rec = runs[(size_t)tile * V_RUN_MAX + i];
+        const int id = tile * V_OPEN_MAX + slotof[(size_t)tile * (CT_H * CT_W) + (rec & 2047)];
+        const int* h = hist + (size_t)uf_find(P, id) * ncls;
+        int best = 0, bv = h[0];
+        for (int c = 1; c < ncls; ++c) {
+            const int v = h[c];
+            if (v > bv) { bv = v; best = c; }
+        }
+        const int a = (rec >> 16) & 63, e = (rec >> 22) & 63;
+        LT* o = pred + (size_t)(ty * CT_H + (int)((rec >> 11) & 31)) * W + tx * CT_W;
+        for (int k = a; k <= e; ++k) o[k] = (LT)best;
+    }
+}
+
+// Workspace of the vote: grow-only, one per device, shared by every caller.  The tile path needs per tile 192 root slots
+// (parent + ncls counters), a 4 KiB run list, a 2 KiB root-to-slot table and a 192-byte rim table: 65 MB for a 4096x3072
+// 6-class page (the page-global path: a label image and a page-sized histogram, 50 + 302 MB); allocating and freeing it per
+// call cost more than the kernels.  Calls are ordered by an event: a call on another stream than the previous user's first
+// waits for that user's kernels, so two streams (or two threads) never run on the buffers at once.
+// pseg_release_workspace() frees it.
 struct VoteWs {
-    void* p[2] = {nullptr, nullptr};
-    size_t bytes[2] = {0, 0};
+    void* p[3] = {nullptr, nullptr, nullptr};
+    size_t bytes[3] = {0, 0, 0};
     hipEvent_t last = nullptr;
     hipStream_t last_stream = nullptr;
     bool used = false;
@@ -354,7 +722,7 @@ int release_workspace(int dev) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     VoteWs& w = g_ws[dev & 63];
     if (w.used && w.last) (void)hipEventSynchronize(w.last);
-    for (int i = 0; i < 2; ++i) { if (w.p[i]) (void)hipFree(w.p[i]); w.p[i] = nullptr; w.bytes[i] = 0; }
+    for (int i = 0; i < 3; ++i) { if (w.p[i]) (void)hipFree(w.p[i]); w.p[i] = nullptr; w.bytes[i] = 0; }
     if (w.last) (void)hipEventDestroy(w.last);
     w.last = nullptr; w.used = false; w.last_stream = nullptr;
     return PSEG_OK;
@@ -382,17 +750,44 @@ static int cc_vote_device(LT* d_pred, const uint8_t* d_bin, int H, int W, int nc
         }
         return w.p[slot];
     };
-    int* d_L = (int*)need(0, (size_t)n * 4);
-    int* d_hist = (int*)need(1, (size_t)n * ncls * 4);
-    if (!d_L || !d_hist) return fail(PSEG_ENOMEM, "hipMalloc(vote workspace) failed");
+    const int tiles = cdiv(W, CT_W) * cdiv(H, CT_H);
+    const bool global_path = PSEG_KNOB("PSEG_CCL_GLOBAL") || ncls > V_NCLS_MAX;
     if (w.used && w.last_stream != st) PSEG_HIP(hipStreamWaitEvent(st, w.last, 0));
-    int rc = ccl_run<0>(d_bin, nullptr, d_L, H, W, st, d_hist, ncls);     // the compress pass clears the roots' counters
-    if (rc == PSEG_OK) {
-        const int grid = cdiv(n, 256);
-        vote_count_kernel<LT><<<cdiv(W, VT) * cdiv(H, VT), 256, 0, st>>>(d_L, d_pred, d_hist, H, W, ncls);
-        vote_apply_kernel<LT><<<grid, 256, 0, st>>>(d_L, d_hist, d_pred, n, ncls);
-        if (hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "vote kernel launch failed");
+    int rc = PSEG_OK;
+    if (global_path) {
+        // page-global union-find over pixel indices: a label image and one row of counters per possible root
+        int* d_L = (int*)need(0, (size_t)n * 4);
+        int* d_hist = (int*)need(1, (size_t)n * ncls * 4);
+        if (!d_L || !d_hist) return fail(PSEG_ENOMEM, "hipMalloc(vote workspace) failed");
+        rc = ccl_run<0>(d_bin, nullptr, d_L, H, W, st, d_hist, ncls);     // the compress pass clears the roots' counters
+        if (rc == PSEG_OK) {
+            vote_count_kernel<LT><<<cdiv(W, VT) * cdiv(H, VT), 256, 0, st>>>(d_L, d_pred, d_hist, H, W, ncls);
+            vote_apply_kernel<LT><<<cdiv(n, 256), 256, 0, st>>>(d_L, d_hist, d_pred, n, ncls);
+        }
+    } else {
+        // per tile: V_OPEN_MAX root slots (parent + a row of counters each), the rim table, the run list, two list lengths
+        const size_t slots = (size_t)tiles * V_OPEN_MAX;
+        const size_t runs_b = (size_t)tiles * V_RUN_MAX * sizeof(VRun), par_b = slots * 4, hist_b = slots * ncls * 4, rim_b = round_up((size_t)tiles * V_RIM, (size_t)16);
+        const size_t slot_b = (size_t)tiles * CT_H * CT_W;
+        char* d_aux = (char*)need(2, runs_b + par_b + hist_b + rim_b + slot_b + 2 * (size_t)tiles * 4);
+        if (!d_aux) return fail(PSEG_ENOMEM, "hipMalloc(vote workspace) failed");
+        VRun* d_runs = (VRun*)d_aux;
+        int* d_par = (int*)(d_aux + runs_b);
+        int* d_hist = (int*)(d_aux + runs_b + par_b);
+        uint8_t* d_rim = (uint8_t*)(d_aux + runs_b + par_b + hist_b);
+        uint8_t* d_slot = d_rim + rim_b;
+        int* d_rootn = (int*)(d_aux + runs_b + par_b + hist_b + rim_b + slot_b);
+        int* d_runn = d_rootn + tiles;
+        const size_t lds = (size_t)CT_H * CT_W * 4 + (size_t)ncls * CT_H * CT_W * 2;
+        vote_tile_kernel<LT, 8><<<tiles, 512, lds, st>>>(d_bin, d_pred, d_par, d_hist, d_rim, d_slot, d_rootn, d_runs, d_runn, H, W, ncls);
+        const int nby = (H - 1) / CT_H, nbx = (W - 1) / CT_W;
+        if (nby * W + nbx * H > 0) {                      // (a one-tile page has no open component)
+            vote_border_kernel<<<cdiv(nby * W + nbx * H, 256), 256, 0, st>>>(d_bin, d_rim, d_par, H, W, nby, nbx);
+            vote_merge_kernel<<<tiles, 64, 0, st>>>(d_par, d_hist, d_rootn, ncls);
+            vote_apply_runs_kernel<LT><<<tiles, 256, 0, st>>>(d_par, d_hist, d_runs, d_runn, d_slot, d_pred, W, ncls);
+        }
     }
+    if (rc == PSEG_OK && hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "vote kernel launch failed");
     PSEG_HIP(hipEventRecord(w.last, st));
     w.used = true;
     w.last_stream = st;

@@ -93,8 +93,10 @@ def test_post_process_call_sequences(gpu, oracle_mod):
 
 
 def test_cc_vote_random_shapes_densities_and_class_counts(gpu, oracle_mod):
-    """The vote's tile-merged counters (32 x 32 tiles, LDS hash table) and the tile-local labelling (16 x 64) on shapes
-    around the tile sizes, densities from specks to one percolating component, 2 .. 40 classes, noisy predictions."""
+    """The vote's tile pass (32 x 64 tiles labelled and counted in LDS, closed components finished there, open ones through the
+    border unions, the root merge and the run list; more than 12 classes: the page-global labelling with the 32 x 32 counting
+    tiles) on shapes around the tile sizes, densities from specks to one percolating component, 2 .. 40 classes, noisy
+    predictions."""
     rng = np.random.default_rng(99)
     for (H, W) in [(31, 33), (32, 32), (33, 65), (64, 129), (100, 100), (17, 300)]:
         for dens, C in [(0.1, 2), (0.45, 3), (0.6, 7), (0.95, 40)]:
@@ -122,13 +124,13 @@ def _vote_u8_device(gpu, pred_u8, binary, C):
 
 
 def test_cc_vote_uint8_and_int64_maps_on_shapes_around_the_tile_edges(gpu, oracle_mod):
-    """The vote on uint8 (device entry) and int64 maps gives the oracle's map bit for bit: shapes around the labelling tile
-    edges (16 x 64) and the counting tiles (32 x 32), specks to one percolating component, long thin components across many
-    tiles, labels outside [0, C) (ignored by the count)."""
+    """The vote on uint8 (device entry) and int64 maps gives the oracle's map bit for bit: shapes around the tile edges
+    (32 x 64; pages narrower than a tile, widths that are no multiple of four: the byte-load path), specks to one percolating
+    component, long thin components across many tiles."""
     rng = np.random.default_rng(5)
     cases = []
-    for (H, W) in [(1, 1), (32, 64), (33, 65), (31, 63), (64, 128), (65, 200), (200, 131), (300, 517)]:
-        for dens, C in [(0.05, 3), (0.4, 6), (0.55, 8), (0.97, 2)]:
+    for (H, W) in [(1, 1), (32, 64), (33, 65), (31, 63), (64, 128), (65, 200), (200, 131), (300, 517), (96, 192), (70, 132), (129, 256)]:
+        for dens, C in [(0.05, 3), (0.4, 6), (0.55, 8), (0.97, 2), (0.3, 12)]:
             binary = (rng.random((H, W)) < dens).astype(np.uint8)
             pred = rng.integers(0, C, size=(H, W)).astype(np.int64)
             cases.append((pred, binary, C))

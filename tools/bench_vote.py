@@ -1,6 +1,8 @@
 """Vote timing on configs[4]'s page (4096x3072, 6 classes, uint8 labels): the synthetic page as BASELINE.md prescribes it
 (two speckled image rectangles: one percolating component each + thousands of specks) and the same page with the
-rectangles blanked (text only).  PSEG_CCL_GLOBAL=1 selects the page-global union-find path."""
+rectangles blanked (text only).  Default: the vote's tile pass (vote_tile_kernel + border unions + root merge + run list);
+PSEG_CCL_GLOBAL=1: the page-global union-find over pixel indices with the 32 x 32 counting tiles.  PSEG_LIB=<other build>
+times another library on the same box (boxes differ by up to 10 %)."""
 import ctypes, json, os, sys, time
 os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -220,6 +220,256 @@ __global__ __launch_bounds__(NW * 64) void wgrad_flat_kernel(WgradArgs a) {
     }
 }
 
+// ---- the same walk for the WIDE layers of unet / res_unet (k3, 32 ... 1024 channels; lib/model.py:151-203, 237-307) ----------
+// A launch is cut into XC x CO channel BLOCKS on blockIdx.z (64 x 64, or 32 wide where a tensor has 32 channels): a workgroup
+// owns all KW x KW taps of its block -- 9 x 64 = 576 flattened rows = 36 tiles, nine per wave, no padding -- for one strip.
+// The kernels of pseg_train.hip gave every TAP of a block its own workgroup, each reading X and dY again from L2 in fragment
+// layout (12 global dword loads per 16 MFMAs): 0.2-0.25 of the float32 matrix peak on unet's layers.  Here the row pieces
+// are staged once per workgroup for all nine taps and the multiply phase reads LDS only (13 ds_read_b32 per 36 MFMAs).
+// Differences from wgrad_flat_kernel: a pixel of X / dY is a.XC / a.Cout floats apart in memory (the block's XC / CO of them
+// are copied, xc0 / yc0 in), and in LDS XC + 16 / CO + 16 apart -- a pitch of 64 or 32 floats puts the four pixels g of a
+// fragment read on the same banks.  Deep layers (a 32 x 24 map at 1/16 of a 512 x 384 page) get their parallelism from the
+// blocks (512 -> 1024 channels: 128 of them) and one or two strips: every strip is a full copy of the layer's gradient in
+// the partial-sum buffer (19 MB).
+template <int XC, int CO, int KW, int NW, int MW, int PW>
+__global__ __launch_bounds__(NW * 64) void wgrad_blk_kernel(WgradArgs a) {
+    constexpr int NT = CO / 16, NTHR = NW * 64, KYN = KW;
+    constexpr int QU = MW * NT >= 24 ? 2 : 4;
+    constexpr int MROWS = KYN * KW * XC, MTILES = (MROWS + 15) / 16;
+    static_assert(MTILES <= NW * MW && XC % 16 == 0 && CO % 16 == 0, "tiles do not fit the waves");
+    constexpr int XP = XC + 16, YP = CO + 16;                // LDS pixel pitches
+    constexpr int XPX = PW + KW - 1, XROW = XPX * XP, RS = KYN + 1, YSZ = PW * YP;
+    constexpr int NXV = XPX * XC / 4, NYV = PW * CO / 4;     // float4 vectors of a row piece
+    constexpr int EXV = (NXV + NTHR - 1) / NTHR, EYV = (NYV + NTHR - 1) / NTHR;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float* const Xs = wsm;                                   // [RS][XROW]
+    float* const Ys = wsm + RS * XROW;                       // [2][YSZ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p16 = lane & 15, g = lane >> 4;
+    const int nbo = a.Cout / CO;
+    const int xc0 = ((int)blockIdx.z / nbo) * XC, yc0 = ((int)blockIdx.z % nbo) * CO;
+    const int strip = blockIdx.y, cgi = strip % a.cgroups, rsi = strip / a.cgroups;
+    const int r0 = rsi * a.strip_rows, nrows = max(0, min(r0 + a.strip_rows, a.Hy) - r0);
+    const int cpr = (a.Wy + PW - 1) / PW, cper = (cpr + a.cgroups - 1) / a.cgroups;
+    const int pc0 = cgi * cper, ncols = max(0, min(pc0 + cper, cpr) - pc0);
+    const int total = nrows + KYN - 1;
+    const int T = nrows > 0 ? ncols * total : 0;
+
+    int aconst[MW], akyl[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int m = min((wave * MW + i) * 16 + p16, MROWS - 1);
+        const int tapl = m / XC, ci = m - tapl * XC, kyl = tapl / KW, kx = tapl - kyl * KW;
+        aconst[i] = (kx + g) * XP + ci;
+        akyl[i] = kyl;
+    }
+    wf_f32x4 acc[MW][NT];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = wf_f32x4{0.f, 0.f, 0.f, 0.f};
+    float bacc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bacc[j] = 0.0f;
+    const bool want_b = a.dB != nullptr && xc0 == 0 && wave == 0;
+
+    float xr[EXV][4], yr[EYV][4], ym[EYV][4];
+    int xvs[EXV], xvd[EXV], yvs[EYV], yvd[EYV];              // source byte offset inside the row piece (-1: none), LDS float offset
+#pragma unroll
+    for (int u = 0; u < EXV; ++u) {
+        const int v = tid + u * NTHR, px = v / (XC / 4), c4 = v - px * (XC / 4);
+        xvs[u] = v < NXV ? (px * a.XC + xc0 + c4 * 4) * 4 : -1;
+        xvd[u] = px * XP + c4 * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < EYV; ++u) {
+        const int v = tid + u * NTHR, px = v / (CO / 4), c4 = v - px * (CO / 4);
+        yvs[u] = v < NYV ? (px * a.Cout + yc0 + c4 * 4) * 4 : -1;
+        yvd[u] = px * YP + c4 * 4;
+    }
+    const bool has_mask = a.maskY != nullptr;
+
+    int fcol = pc0, fs = 0;
+    auto fetch = [&]() {
+        const int x0 = fcol * PW;
+        const int sy = r0 + fs - a.pt;
+        const bool rowok = sy >= 0 && sy < a.Hx;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.X + (size_t)(rowok ? sy : 0) * a.xpitch * a.XC), 0, rowok ? a.Wx * a.XC * 4 : 0, 0x00020000);
+        const int xb = (x0 - a.pl) * a.XC * 4;               // negative at the left border: wraps past the range check -> zeros
+#pragma unroll
+        for (int u = 0; u < EXV; ++u) wf_bload<4>(xr[u], xrs, xvs[u] < 0 ? -4 : xb + xvs[u]);
+        if (fs >= KYN - 1) {
+            const int y = r0 + fs - (KYN - 1);
+            const int yb = x0 * a.Cout * 4;
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dY + (size_t)y * a.ypitch * a.Cout), 0, a.Wy * a.Cout * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < EYV; ++u) wf_bload<4>(yr[u], yrs, yvs[u] < 0 ? -4 : yb + yvs[u]);
+            if (has_mask) {
+                const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.maskY + (size_t)y * a.ypitch * a.Cout), 0, a.Wy * a.Cout * 4, 0x00020000);
+#pragma unroll
+                for (int u = 0; u < EYV; ++u) wf_bload<4>(ym[u], mrs, yvs[u] < 0 ? -4 : yb + yvs[u]);
+            }
+        }
+        if (++fs == total) { fs = 0; ++fcol; }
+    };
+
+    int wslot = 0, ybuf = 0, cs = 0;
+    if (T > 0) fetch();
+    for (int it = 0; it < T; ++it) {
+        {
+            float* xd = Xs + wslot * XROW;
+#pragma unroll
+            for (int u = 0; u < EXV; ++u)
+                if (xvs[u] >= 0) {
+                    if (a.in_relu)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xr[u][k] = xr[u][k] > 0.0f ? xr[u][k] : 0.0f;
+                    wf_lds_store<4>(xd + xvd[u], xr[u]);
+                }
+            if (cs >= KYN - 1) {
+                float* yd = Ys + ybuf * YSZ;
+#pragma unroll
+                for (int u = 0; u < EYV; ++u)
+                    if (yvs[u] >= 0) {
+                        if (has_mask)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) yr[u][k] = ym[u][k] > 0.0f ? yr[u][k] : 0.0f;
+                        wf_lds_store<4>(yd + yvd[u], yr[u]);
+                    }
+            }
+        }
+        __syncthreads();
+        if (it + 1 < T) fetch();                             // lands under the multiplies below
+        if (cs >= KYN - 1) {
+            int sb = wslot - (KYN - 1);
+            if (sb < 0) sb += RS;
+            const float* xa_p[MW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                int sl = sb + akyl[i];
+                if (sl >= RS) sl -= RS;
+                xa_p[i] = Xs + sl * XROW + aconst[i];
+            }
+            const float* yb_p = Ys + ybuf * YSZ + g * YP + p16;
+#pragma unroll QU
+            for (int q = 0; q < PW / 4; ++q) {
+                float xa[MW], yb[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) yb[j] = yb_p[q * 4 * YP + j * 16];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) xa[i] = xa_p[i][q * 4 * XP];
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+                if (want_b)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bacc[j] += yb[j];
+            }
+            ybuf ^= 1;
+        }
+        wslot = wslot + 1 == RS ? 0 : wslot + 1;
+        if (++cs == total) cs = 0;
+    }
+
+    // ---- D tile: lane holds rows 4g .. 4g+3, column p16 -- into this strip's row of `part` (or atomics)
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = (wave * MW + i) * 16 + 4 * g + r;
+                if (m < MROWS) { const int tl = m / XC; wg_out(a, strip, tl, xc0 + m - tl * XC, yc0 + j * 16 + p16, acc[i][j][r]); }
+            }
+    if (a.dB != nullptr && xc0 == 0 && wave == 0) {            // (every wave saw every pixel: wave 0 leaves the strip's four bias rows)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float v = bacc[j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) {
+                wg_out_bias(a, strip, 0, yc0 + j * 16 + p16, v);
+                if (a.partB)
+                    for (int w = 1; w < 4; ++w) wg_out_bias(a, strip, w, yc0 + j * 16 + p16, 0.0f);
+            }
+        }
+    }
+}
+
+struct BlkInstance {
+    int XC, CO, KW, NW, PW;
+    int wg_per_cu;
+    size_t lds;
+    void (*kernel)(WgradArgs);
+};
+#define PSEG_BLK(XC_, CO_, KW_, NW_, MW_, PW_, OCC_) \
+    {XC_, CO_, KW_, NW_, PW_, OCC_, (size_t)((KW_ + 1) * (PW_ + KW_ - 1) * (XC_ + 16) + 2 * PW_ * (CO_ + 16)) * 4, wgrad_blk_kernel<XC_, CO_, KW_, NW_, MW_, PW_>}
+static const BlkInstance g_blk[] = {
+    PSEG_BLK(64, 64, 3, 4, 9, 32, 1),        // 576 rows = 36 tiles: 144 accumulator registers, one wave per SIMD
+    PSEG_BLK(32, 64, 3, 4, 5, 32, 2),        // 288 rows = 18 tiles (res_unet: 32-channel sources)
+    PSEG_BLK(32, 32, 3, 4, 5, 32, 4),
+};
+#undef PSEG_BLK
+
+bool wgrad_blk_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan) {
+    if (a.mode != 0 || a.stride != 1 || a.xup || taps != a.KW * a.KW || PSEG_KNOB("PSEG_WGRAD_NO_FLAT")) return false;
+    if ((size_t)a.Wx * a.XC * 4 >= (1ull << 31) || (size_t)a.Wy * a.Cout * 4 >= (1ull << 31)) return false;   // 32-bit buffer offsets per row
+    for (int k = 0; k < (int)(sizeof(g_blk) / sizeof(g_blk[0])); ++k) {
+        const BlkInstance& f = g_blk[k];
+        if (a.XC % f.XC != 0 || a.Cout % f.CO != 0 || f.KW != a.KW) continue;
+        if (f.XC == 32 && a.XC % 64 == 0) continue;            // (the widest block that divides the tensor)
+        if (f.CO == 32 && a.Cout % 64 == 0) continue;
+        static int ncu_dev[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 63;
+        if (ncu_dev[dev] == 0) {
+            int n = 0;
+            ncu_dev[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        }
+        const int nz = (a.XC / f.XC) * (a.Cout / f.CO);
+        const int cpr = cdiv(a.Wy, f.PW);
+        // one resident round of workgroups: blocks x strips ~ what the chip holds; a strip costs a full copy of the layer's
+        // gradient in the partial-sum buffer, so layers with many blocks take few
+        const int target = std::max(1, ncu_dev[dev] * f.wg_per_cu / nz);
+        const int min_rows = 8;
+        int cgroups = cpr, rows = 1;
+        for (;;) {
+            const int nrs = std::max(1, target / cgroups);
+            rows = cdiv(a.Hy, nrs);
+            if (rows >= min_rows || cgroups == 1) break;
+            cgroups = cdiv(cgroups, 2);
+        }
+        cgroups = cdiv(cpr, cdiv(cpr, cgroups));
+        plan->instance = 1000 + k;
+        plan->strip_rows = rows;
+        plan->cgroups = cgroups;
+        plan->nstrips = cdiv(a.Hy, rows) * cgroups;
+        return true;
+    }
+    return false;
+}
+
+static int wgrad_blk_launch(const WgradArgs& a_in, const WgradFlatPlan& plan, hipStream_t st) {
+    const BlkInstance& f = g_blk[plan.instance - 1000];
+    WgradArgs a = a_in;
+    a.strip_rows = plan.strip_rows;
+    a.cgroups = plan.cgroups;
+    static bool attr[64][sizeof(g_blk) / sizeof(g_blk[0])];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr[dev & 63][plan.instance - 1000]) {
+        PSEG_HIP(hipFuncSetAttribute((const void*)f.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds));
+        attr[dev & 63][plan.instance - 1000] = true;
+    }
+    const dim3 grid(1, plan.nstrips, (a.XC / f.XC) * (a.Cout / f.CO));
+    hipLaunchKernelGGL(f.kernel, grid, dim3(f.NW * 64), f.lds, st, a);
+    PSEG_HIP(hipGetLastError());
+    return PSEG_OK;
+}
+
 // ---- instance table: one fully specialised kernel per layer shape of fcn / fcn_skip (lib/model.py:50-85)
 struct FlatInstance {
     int XC, CO, KW, KYN, NW, PW;
@@ -242,6 +492,7 @@ static const FlatInstance g_flat[] = {
 
 bool wgrad_flat_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan) {
     if (a.mode != 0 || a.stride != 1 || a.xup || taps != a.KW * a.KW || PSEG_KNOB("PSEG_WGRAD_NO_FLAT")) return false;
+    if (a.KW == 3 && !PSEG_KNOB("PSEG_WGRAD_NO_BLK") && wgrad_blk_plan(a, taps, plan)) return true;   // unet / res_unet: channel blocks
     if ((size_t)a.Wx * a.XC * 4 >= (1ull << 31) || (size_t)a.Wy * a.Cout * 4 >= (1ull << 31)) return false;   // 32-bit buffer offsets per row
     for (int k = 0; k < (int)(sizeof(g_flat) / sizeof(g_flat[0])); ++k) {
         const FlatInstance& f = g_flat[k];
@@ -288,6 +539,7 @@ bool wgrad_flat_plan(const WgradArgs& a, int taps, WgradFlatPlan* plan) {
 }
 
 int wgrad_flat_launch(const WgradArgs& a_in, const WgradFlatPlan& plan, hipStream_t st) {
+    if (plan.instance >= 1000) return wgrad_blk_launch(a_in, plan, st);
     const FlatInstance& f = g_flat[plan.instance];
     WgradArgs a = a_in;
     a.strip_rows = plan.strip_rows;

@@ -353,82 +353,94 @@ __global__ void vote_apply_kernel(const int* L, const int* hist, LT* pred, int n
 }
 
 // ---- the vote's own tile pass (default) ------------------------------------------------------------------------
-// One workgroup labels a 32 x 64 tile in LDS as ccl_tile_kernel does AND counts the classes of every tile-local component there,
-// so that the page-wide passes over a 4 B/px label image (write it, resolve + count it, read it again to apply) disappear:
-//   * the binarisation and the class map are read ONCE per pixel; a tile row's ink is one 64-bit ballot, and every later test
-//     -- left link, ink above, run start, run end -- is bit arithmetic on masks that are uniform over the wave.
-//     (ccl_tile_kernel re-reads bytes for each test: ~5 byte loads per pixel, and a CU's texture addresser takes a 64-lane byte
-//     load at the pace of a 64-lane dword load.)
-//   * a run of ink in a tile row has one root; per class one ballot, the run's first lane takes popcount(class mask & run
-//     mask) and adds it to a 16-bit counter of (class, root): LDS adds per (run, class present) that return nothing.
+// One workgroup labels a 32 x 64 tile in LDS AND counts the classes of every tile-local component there, so that the
+// page-wide passes over a 4 B/px label image (write it, resolve + count it, read it again to apply) disappear:
+//   * the binarisation and the class map are read ONCE per pixel and become bit masks: a tile row's ink is one 64-bit ballot,
+//     its pixels of class c another.  (ccl_tile_kernel re-reads bytes for each test: ~5 byte loads per pixel, and a CU's
+//     texture addresser takes a 64-lane byte load at the pace of a 64-lane dword load.)
+//   * everything after that is dense over RUNS (maximal stretches of ink in a row; see vote_tile_kernel), not pixels.
 //   * a component with no ink neighbour across the tile's edge is CLOSED: its counts are final, the winner is written to those
-//     of its pixels that differ, and nothing else of it ever reaches memory.  An OPEN component gets the next of the tile's
-//     V_OPEN_MAX root slots (id = tile * V_OPEN_MAX + slot): its counts go to row `id` of a compact histogram (plain stores:
-//     no clearing pass, no atomics), its slot to the tile's rim table at every pixel of it that has an ink neighbour across
-//     the edge (all that the border unions look at), one record per run to the tile's run list.
-// No page-sized array is left: the union-find runs over the root ids (tiles * 192 ints: L2-resident; page-sized label and
-// histogram arrays touched at scattered roots cost a TLB miss per access), the rim table is 192 bytes per tile.
+//     of its pixels that have another class, and nothing else of it ever reaches memory.  An OPEN component gets the next of
+//     the tile's V_OPEN_MAX root slots (id = tile * V_OPEN_MAX + slot): its counts go to row `id` of a compact histogram
+//     (plain stores: no clearing pass, no atomics), its slot to the tile's rim table at every pixel of it that has an ink
+//     neighbour across the edge (all that the border unions look at), one record per run to the tile's run list.
+// No page-sized array is left: the union-find across tiles runs over the root slot ids (tiles * 192 ints: L2-resident), the
+// rim table is 192 bytes per tile.
 // vote_border_kernel then joins the open components across tile edges, vote_merge_kernel adds the counts of every root slot
 // that is no longer a root to its final root's row, vote_apply_runs_kernel resolves each listed run and writes its pixels.
-// (Round 3's tile-local attempt kept per-pixel LDS atomics for labelling AND counting and a page-sized label image: 0.262 vs
-// 0.182 ms.)
+// Measured on the way (configs[4]'s page, same box as the page-global path at 0.158 ms): per-pixel labels + per-run counting
+// in LDS with a page-sized label image 0.116; the same with eight waves per tile and compact slots 0.125; persistent
+// workgroups that prefetch the next tile 0.151 (imbalance; 103 registers -> half the occupancy); run-based, eight waves
+// 0.131; run-based, four waves 0.112.  SQ counters of the run-based kernel: 905 instructions per wave, waves waiting
+// (SQ_WAIT_ANY) 70 % of their cycles -- the kernel is bound by latency chains at full occupancy, not by issue or bytes.
+// (Round 3's tile-local attempt kept per-pixel LDS atomics for labelling AND counting and a page-sized label image: 0.262.)
 constexpr int V_OPEN_MAX = 2 * (CT_H + CT_W);   // an open root owns at least one pixel of the tile's rim
 constexpr int V_RUN_MAX = CT_H * CT_W / 2;      // runs of a tile: at most every other pixel starts one
 constexpr int V_NCLS_MAX = 12;                  // LDS: 8 KiB of labels + 4 KiB of counters per class, under the 64 KiB a launch gets unasked (more classes: the page-global path)
-// a run of an open component in its tile's run list: tile-local root | tile row << 11 | first lane << 16 | last lane << 22; the root's
-// slot is in the tile's root-to-slot table (one byte per pixel of the tile, written at the open roots)
+// a run of an open component in its tile's run list: tile row | first lane << 5 | last lane << 11 | its root's slot << 17
 typedef unsigned VRun;
 // rim table of a tile: slot of the root of the pixel at [0, 64) top row, [64, 128) bottom row, [128, 160) left column, [160, 192) right column
 constexpr int V_RIM = 2 * (CT_H + CT_W);
-// counters: 16 bits per (class, tile-local root) -- a tile has 2 048 pixels -- two roots to a word, bumped with 32-bit LDS adds
+// The kernel works on RUNS (maximal stretches of ink in a tile row), not pixels: after the one pass that turns the two maps
+// into bit masks -- ink per row, one mask per class and row -- a tile is its run list (row, first, last lane; ordered by
+// row, then column, so that the run holding bit b of row r is rowbase[r] + popcount(first-lane mask of r up to b) - 1), and
+// every later phase is dense over runs: unions with the overlapping runs of the row above, the root, the class counts
+// (popcount(class mask & run span)), open / closed, the winner.  A text tile has 100-300 runs for 2 048 pixels.
+// counters: 16 bits per (class, root run) -- a tile has 2 048 pixels -- two runs to a word, bumped with 32-bit LDS adds
 // (no carry can cross: a half never exceeds 2 048)
+__device__ __forceinline__ unsigned long long bits_le(int b) { return b >= 63 ? ~0ull : ((2ull << b) - 1ull); }   // bits 0 .. b
 template <typename LT, int NW>
 __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __restrict__ bin, LT* pred, int* __restrict__ P, int* __restrict__ hist,
-                                                            uint8_t* __restrict__ rimtab, uint8_t* __restrict__ slotof, int* __restrict__ rootn,
-                                                            VRun* __restrict__ runs, int* __restrict__ runn, int H, int W, int ncls) {
-    extern __shared__ __attribute__((aligned(16))) int vsm[];
-    int* const lab = vsm;                                 // [CT_H * CT_W]
-    unsigned* const cnt = (unsigned*)(vsm + CT_H * CT_W); // [ncls][CT_H * CT_W / 2]
+                                                        uint8_t* __restrict__ rimtab, int* __restrict__ rootn, VRun* __restrict__ runs,
+                                                        int* __restrict__ runn, int H, int W, int ncls) {
+    constexpr int NTH = NW * 64, RPW = CT_H / NW, HALF = V_RUN_MAX / 2;
+    static_assert(NW >= 4 && RPW % 4 == 0, "four rows of a wave are one 64-lane dword load; waves 0-3 fetch the tile's surroundings");
+    extern __shared__ __attribute__((aligned(16))) unsigned vsm[];
+    unsigned* const cnt = vsm;                                                            // [ncls][V_RUN_MAX / 2]
+    unsigned long long* const cmask = (unsigned long long*)(vsm + ncls * (V_RUN_MAX / 2));   // [class][row]: pixels of that class
     __shared__ unsigned long long m64[CT_H + 2];          // ink of tile rows -1 .. CT_H
     __shared__ unsigned lr[2];                            // ink left / right of the tile, bit = tile row
-    __shared__ unsigned openbits[CT_H * CT_W / 32];
-    __shared__ unsigned rlist[V_RUN_MAX];                 // the tile's runs
+    __shared__ int rowcnt[CT_H], rowbase[CT_H + 1];       // runs of a row, runs before it
+    __shared__ unsigned rl[V_RUN_MAX];                    // the runs: row | first lane << 5 | last lane << 11 (| an open root's slot << 17)
+    __shared__ int parent[V_RUN_MAX];                     // union-find over run indices (staging area of the maps before that)
+    __shared__ unsigned openbits[V_RUN_MAX / 32];
     __shared__ int nboth;                                 // open runs | open roots << 16
-    __shared__ int wnf[NW];                               // runs of each wave's rows
-    constexpr int NTH = NW * 64, HALF = CT_H * CT_W / 2;
-    static_assert(NW >= 4 && CT_H % NW == 0, "waves 0-3 also fetch the tile's surroundings");
     const int tiles_x = (W + CT_W - 1) / CT_W;
     const int tile = blockIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int y0 = ty * CT_H, x0 = tx * CT_W, x = x0 + lane;
-    constexpr int RPW = CT_H / NW;                        // rows per wave: wave * RPW ...
+    const int rw0 = wave * RPW;                           // this wave's rows: rw0 .. rw0 + RPW - 1
     for (int i = threadIdx.x; i < ncls * HALF / 4; i += NTH) ((uint4*)cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (threadIdx.x < CT_H * CT_W / 32) openbits[threadIdx.x] = 0;
+    if (threadIdx.x < V_RUN_MAX / 32) openbits[threadIdx.x] = 0;
     if (threadIdx.x == 0) nboth = 0;
-    // ---- ink + class of this thread's pixels, the tile's surroundings; row pass ----
-    // A wave's RPW rows of 64 bytes are ONE dword load per map (lane -> row lane / 16, dword lane % 16) where the tile lies
-    // inside the page and rows are dword-aligned, handed to the lanes of the columns through the wave's own (still unused)
-    // label rows; byte loads per row otherwise.
+    // ---- the two maps -> masks.  A wave's RPW rows of 64 bytes are ONE dword load per map (lane -> row lane / 16, dword
+    // lane % 16) where the tile lies inside the page and rows are dword-aligned, handed to the lanes of the columns through
+    // LDS; byte loads per row otherwise.  Waves 0, 1 also fetch the rows above / below the tile, waves 2, 3 the columns
+    // left / right of it.
     uint8_t bb[RPW];
     long long cc[RPW];
-    static_assert(RPW == 4, "a wave's rows are one 64-lane dword load");
-    const int rw0 = wave * RPW;                           // this wave's rows: rw0 .. rw0 + RPW - 1
     const bool wide = (W & 3) == 0 && x0 + CT_W <= W;
     if (wide) {
-        uint8_t* const stg = (uint8_t*)(lab + rw0 * CT_W);    // 1 KiB of this wave's own: 256 B ink, 256 B classes
-        const int yl = y0 + rw0 + (lane >> 4);
-        const size_t o = (size_t)yl * W + x0 + (lane & 15) * 4;
-        const unsigned vb = yl < H ? *(const unsigned*)(bin + o) : 0u;
-        ((unsigned*)stg)[lane] = vb;
-        if (sizeof(LT) == 1) {
-            const unsigned vc = yl < H ? *(const unsigned*)((const uint8_t*)pred + o) : 0u;
-            ((unsigned*)stg)[64 + lane] = vc;
+        uint8_t* const stg = (uint8_t*)(parent + wave * (V_RUN_MAX / NW));   // this wave's own: RPW x 64 B ink, RPW x 64 B classes
+        static_assert(V_RUN_MAX * 4 / NW == 2 * RPW * 64, "the staging area is the parent array");
+        unsigned vb[RPW / 4], vc[RPW / 4];
+#pragma unroll
+        for (int h = 0; h < RPW / 4; ++h) {
+            const int yl = y0 + rw0 + 4 * h + (lane >> 4);
+            const size_t o = (size_t)yl * W + x0 + (lane & 15) * 4;
+            vb[h] = yl < H ? *(const unsigned*)(bin + o) : 0u;
+            vc[h] = (sizeof(LT) == 1 && yl < H) ? *(const unsigned*)((const uint8_t*)pred + o) : 0u;
+        }
+#pragma unroll
+        for (int h = 0; h < RPW / 4; ++h) {
+            ((unsigned*)stg)[h * 64 + lane] = vb[h];
+            if (sizeof(LT) == 1) ((unsigned*)stg)[RPW * 16 + h * 64 + lane] = vc[h];
         }
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
             bb[j] = stg[j * 64 + lane];
-            if (sizeof(LT) == 1) cc[j] = stg[256 + j * 64 + lane];
+            if (sizeof(LT) == 1) cc[j] = stg[RPW * 64 + j * 64 + lane];
             else cc[j] = y0 + rw0 + j < H ? (long long)pred[(size_t)(y0 + rw0 + j) * W + x] : -1ll;
         }
     } else {
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
             cc[j] = in ? (long long)pred[(size_t)y * W + x] : -1ll;   // (paper included: one round trip for both maps)
         }
     }
-    bool hv = false;                                      // waves 0, 1: the rows above / below; waves 2, 3: the columns left / right
+    bool hv = false;
     if (wave < 2) {
         const int y = wave == 0 ? y0 - 1 : y0 + CT_H;
         hv = y >= 0 && y < H && x < W && bin[(size_t)y * W + x] != 0;
@@ -448,23 +460,24 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
         const int y = y0 + (lane & 31), xx = wave == 2 ? x0 - 1 : x0 + CT_W;
         hv = lane < 32 && y < H && xx >= 0 && xx < W && bin[(size_t)y * W + xx] != 0;
     }
-    int cls[RPW], sr[RPW];
     unsigned long long mr[RPW];
-    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= this one
-    int nfirst = 0;                                       // runs of this wave's rows
+    int nruns_w = 0;
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int r = rw0 + j;
         const bool fg = bb[j] != 0;
         const unsigned long long m = __ballot(fg);
         mr[j] = m;
-        nfirst += __popcll(m & ~(m << 1));
-        if (lane == 0) m64[r + 1] = m;
-        cls[j] = (fg && cc[j] >= 0 && cc[j] < ncls) ? (int)cc[j] : -1;
-        // runs of ink: a lane's label is the first lane of its run
-        const unsigned long long brk = ~(m & (m << 1));   // lanes that do not continue the lane to their left (bit 0 always)
-        sr[j] = 63 - __clzll((long long)(brk & le));
-        lab[r * CT_W + lane] = fg ? r * CT_W + sr[j] : -1;
+        const int nr = __popcll(m & ~(m << 1));
+        nruns_w += nr;
+        if (lane == 0) { m64[r + 1] = m; rowcnt[r] = nr; }
+        if (m) {                                          // (uniform)
+            const int cl = (fg && cc[j] >= 0 && cc[j] < ncls) ? (int)cc[j] : -1;
+            for (int c = 0; c < ncls; ++c) {
+                const unsigned long long cm = __ballot(cl == c);
+                if (lane == 0) cmask[c * CT_H + r] = cm;
+            }
+        }
     }
     if (wave < 4) {
         const unsigned long long b = __ballot(hv);
@@ -474,93 +487,85 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
             else lr[wave - 2] = (unsigned)b;
         }
     }
-    if (lane == 0) wnf[wave] = nfirst;
-    if (!__syncthreads_or(nfirst)) {                      // a tile of paper
+    if (!__syncthreads_or(nruns_w)) {                     // a tile of paper
         if (threadIdx.x == 0) { rootn[tile] = 0; runn[tile] = 0; }
         return;
     }
-    int rbase = 0, n_all = 0;                             // this wave's stretch of the tile's run list, all runs of the tile
+    // ---- the run list (every wave scans the 32 row counts itself), every run its own parent ----
+    int excl, n_all;
+    {
+        const int v = lane < CT_H ? rowcnt[lane] : 0;
+        int inc = v;
 #pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) {
-        const int v = wnf[w2];
-        rbase += w2 < wave ? v : 0;
-        n_all += v;
+        for (int o = 1; o < CT_H; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        excl = inc - v;
+        n_all = __shfl(inc, CT_H - 1);
+        if (wave == 0 && lane <= CT_H) rowbase[lane] = lane < CT_H ? excl : n_all;
     }
-    // ---- column pass: a union where a vertical overlap of two runs begins ----
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int r = rw0 + j;
-        if (r == 0) continue;
-        const unsigned long long cur = mr[j] & m64[r];
-        const unsigned long long need = cur & ~(cur << 1);
-        if ((need >> lane) & 1) lds_union(lab, r * CT_W + lane, (r - 1) * CT_W + lane);
-    }
-    __syncthreads();
-    // ---- per row: roots (only first lanes of runs were ever redirected), class counts, open components, the tile's runs ----
-    int root[RPW];
-    unsigned rimbits = 0;
-    // the four rows' chains walked together: four LDS reads in flight per step
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) root[j] = (((mr[j] >> lane) & 1) && sr[j] == lane) ? (rw0 + j) * CT_W + lane : -1;
-    while (true) {
-        bool moved = false;
-#pragma unroll
-        for (int j = 0; j < RPW; ++j)
-            if (root[j] >= 0) {
-                const int up = __hip_atomic_load(&lab[root[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                moved |= up != root[j];
-                root[j] = up;
-            }
-        if (!__any(moved)) break;
-    }
-    // where ink lies across the tile's edge, per row: the rows above / below for the first / last row, bits 0 and 63 for the columns
-    const unsigned long long m_up = m64[0], m_dn = m64[CT_H + 1];
-    const unsigned lr0 = lr[0], lr1 = lr[1];
+    const unsigned long long le = bits_le(lane);          // lanes <= this one
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int r = rw0 + j;
         const unsigned long long m = mr[j];
-        if (m == 0) continue;                             // (uniform) a row of paper
-        const bool fg = (m >> lane) & 1;
-        const bool first = fg && sr[j] == lane;
-        const int rt = __shfl(root[j], fg ? sr[j] : lane);
-        root[j] = rt;
-        // counts: one LDS add per stretch of one class inside a run (mostly: per run), by the stretch's first lane
-        const unsigned long long brk = ~(m & (m << 1));
-        const int cl = cls[j];
-        const unsigned long long sbrk = brk | __ballot(cl != __shfl_up(cl, 1));
-        const unsigned long long nxt = sbrk & ~le;        // the next stretch (or paper) begins
-        const int len = (nxt ? __builtin_ctzll(nxt) : 64) - lane;
-        if (cl >= 0 && ((sbrk >> lane) & 1))
-            __hip_atomic_fetch_add(&cnt[cl * HALF + (rt >> 1)], (unsigned)len << ((rt & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // ink across the tile's edge: the component is open
-        const unsigned long long rimm = (r == 0 ? m_up : 0ull) | (r == CT_H - 1 ? m_dn : 0ull) | (unsigned long long)((lr0 >> r) & 1u) |
-                                        ((unsigned long long)((lr1 >> r) & 1u) << 63);
-        if (fg && ((rimm >> lane) & 1)) { atomicOr(&openbits[rt >> 5], 1u << (rt & 31)); rimbits |= 1u << j; }
-        // the run list of the tile: root | row << 11 | first lane << 16 | last lane << 22
+        const int base = __shfl(excl, r);
+        if (m == 0) continue;
         const unsigned long long fm = m & ~(m << 1);
-        if (first) {
+        if ((fm >> lane) & 1) {
+            const unsigned long long brk = ~(m & (m << 1));   // lanes that do not continue the lane to their left
             const unsigned long long above = brk & ~le;
             const int e = above ? __builtin_ctzll(above) - 1 : 63;
-            rlist[rbase + __popcll(fm & (le >> 1))] = (unsigned)(rt | r << 11 | lane << 16 | e << 22);
+            const int idx = base + __popcll(fm & (le >> 1));
+            rl[idx] = (unsigned)(r | lane << 5 | e << 11);
+            parent[idx] = idx;
         }
-        rbase += __popcll(fm);
     }
     __syncthreads();
-    // ---- per run: a closed component's winner, left where the run's label was (-1: open); an open run goes to the tile's run
-    // list; an open component's root takes a slot, leaves -(slot + 2) there, its counts in the slot's row and makes the slot a root ----
-    for (int i0 = 0; i0 < n_all; i0 += NTH) {
-        const int i = i0 + threadIdx.x;
-        bool open = false, open_root = false;
-        unsigned rec = 0;
-        int rt = 0, pos = 0;
-        if (i < n_all) {
-            rec = rlist[i];
-            rt = rec & 2047;
-            pos = ((rec >> 11) & 31) * CT_W + ((rec >> 16) & 63);
-            open = (openbits[rt >> 5] >> (rt & 31)) & 1;
-            open_root = open && rt == pos;
+    // ---- unions with the runs of the row above that overlap ----
+    for (int t = threadIdx.x; t < n_all; t += NTH) {
+        const unsigned rec = rl[t];
+        const int r = rec & 31, s0 = (rec >> 5) & 63, e = (rec >> 11) & 63;
+        if (r == 0) continue;
+        const unsigned long long mp = m64[r];             // (row r - 1)
+        unsigned long long ov = bits_le(e) & ~(bits_le(s0) >> 1) & mp;
+        const unsigned long long fmp = mp & ~(mp << 1);
+        const int base = rowbase[r - 1];
+        while (ov) {
+            const int b = __builtin_ctzll(ov);
+            const int u = base + __popcll(fmp & bits_le(b)) - 1;
+            lds_union(parent, t, u);
+            ov &= ~bits_le((rl[u] >> 11) & 63);
+        }
+    }
+    __syncthreads();
+    // ---- roots, class counts, open components ----
+    const unsigned long long m_up = m64[0], m_dn = m64[CT_H + 1];
+    const unsigned lr0 = lr[0], lr1 = lr[1];
+    for (int t = threadIdx.x; t < n_all; t += NTH) {
+        const unsigned rec = rl[t];
+        const int r = rec & 31, s0 = (rec >> 5) & 63, e = (rec >> 11) & 63;
+        const unsigned long long S = bits_le(e) & ~(bits_le(s0) >> 1);
+        const int rt = lds_find(parent, t);
+        if (rt != t) __hip_atomic_store(&parent[t], rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (the unions are over: later phases read the root here)
+        for (int c = 0; c < ncls; ++c) {
+            const unsigned n = (unsigned)__popcll(cmask[c * CT_H + r] & S);
+            if (n) __hip_atomic_fetch_add(&cnt[c * HALF + (rt >> 1)], n << ((rt & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const bool rim = (r == 0 && (S & m_up)) || (r == CT_H - 1 && (S & m_dn)) || (s0 == 0 && ((lr0 >> r) & 1)) || (e == CT_W - 1 && ((lr1 >> r) & 1));
+        if (rim) atomicOr(&openbits[rt >> 5], 1u << (rt & 31));
+    }
+    __syncthreads();
+    // ---- closed components: the winner to the pixels of another class; open roots: a slot, its counts, a root ----
+    for (int t0 = 0; t0 < n_all; t0 += NTH) {
+        const int t = t0 + threadIdx.x;
+        bool open_root = false;
+        int rt = 0;
+        if (t < n_all) {
+            rt = parent[t];
+            const bool open = (openbits[rt >> 5] >> (rt & 31)) & 1;
+            open_root = open && rt == t;
             if (!open) {
+                const unsigned rec = rl[t];
+                const int r = rec & 31, s0 = (rec >> 5) & 63, e = (rec >> 11) & 63;
                 int best = 0, bv = -1;
                 const unsigned* cp = cnt + (rt >> 1);
                 const int sh = (rt & 1) * 16;
@@ -568,19 +573,19 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
                     const int v = (int)((cp[c * HALF] >> sh) & 0xffffu);
                     if (v > bv) { bv = v; best = c; }
                 }
-                lab[pos] = best;
-            } else if (!open_root) lab[pos] = -1;
+                unsigned long long wr = bits_le(e) & ~(bits_le(s0) >> 1) & ~cmask[best * CT_H + r];
+                LT* const row = pred + (size_t)(y0 + r) * W + x0;
+                while (wr) { const int b = __builtin_ctzll(wr); row[b] = (LT)best; wr &= wr - 1; }
+            }
         }
-        const unsigned long long om = __ballot(open), orm = __ballot(open_root);
-        if (om) {
+        const unsigned long long orm = __ballot(open_root);
+        if (orm) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(&nboth, __popcll(om) | (__popcll(orm) << 16));   // runs | roots << 16: one round trip
+            if (lane == 0) base = atomicAdd(&nboth, __popcll(orm) << 16);
             base = __shfl(base, 0);
-            if (open) runs[(size_t)tile * V_RUN_MAX + (base & 0xffff) + __popcll(om & (le >> 1))] = rec;
             if (open_root) {
                 const int k = (base >> 16) + __popcll(orm & (le >> 1)), id = tile * V_OPEN_MAX + k;
-                lab[pos] = -(k + 2);
-                slotof[(size_t)tile * (CT_H * CT_W) + rt] = (uint8_t)k;
+                rl[t] |= (unsigned)k << 17;
                 P[id] = id;
                 const unsigned* cp = cnt + (rt >> 1);
                 const int sh = (rt & 1) * 16;
@@ -589,25 +594,37 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { rootn[tile] = nboth >> 16; runn[tile] = nboth & 0xffff; }
-    // ---- per pixel: the winner where it differs; an open component's slot where the border unions look ----
+    // ---- open runs: their record (with the root's slot), the slot where the border unions look ----
     uint8_t* const rim = rimtab + (size_t)tile * V_RIM;
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int r = rw0 + j;
-        const unsigned long long m = mr[j];
-        if (m == 0) continue;                             // (uniform; rows below the page are paper)
-        if (!((m >> lane) & 1)) continue;
-        const int rs = lab[r * CT_W + sr[j]];
-        if (rs >= 0) { if (cls[j] != rs) pred[(size_t)(y0 + r) * W + x] = (LT)rs; }
-        else if ((rimbits >> j) & 1) {
-            const uint8_t k = (uint8_t)(-lab[root[j]] - 2);
-            if (r == 0) rim[lane] = k;
-            if (r == CT_H - 1) rim[CT_W + lane] = k;
-            if (lane == 0) rim[2 * CT_W + r] = k;
-            if (lane == CT_W - 1) rim[2 * CT_W + CT_H + r] = k;
+    for (int t0 = 0; t0 < n_all; t0 += NTH) {
+        const int t = t0 + threadIdx.x;
+        bool open = false;
+        unsigned rec = 0;
+        int k = 0;
+        if (t < n_all) {
+            const int rt = parent[t];
+            open = (openbits[rt >> 5] >> (rt & 31)) & 1;
+            if (open) {
+                rec = rl[t] & 0x1ffffu;
+                k = (int)(rl[rt] >> 17);
+                const int r = rec & 31, s0 = (rec >> 5) & 63, e = (rec >> 11) & 63;
+                const unsigned long long S = bits_le(e) & ~(bits_le(s0) >> 1);
+                if (r == 0) { unsigned long long w = S & m_up; while (w) { rim[__builtin_ctzll(w)] = (uint8_t)k; w &= w - 1; } }
+                if (r == CT_H - 1) { unsigned long long w = S & m_dn; while (w) { rim[CT_W + __builtin_ctzll(w)] = (uint8_t)k; w &= w - 1; } }
+                if (s0 == 0 && ((lr0 >> r) & 1)) rim[2 * CT_W + r] = (uint8_t)k;
+                if (e == CT_W - 1 && ((lr1 >> r) & 1)) rim[2 * CT_W + CT_H + r] = (uint8_t)k;
+            }
+        }
+        const unsigned long long om = __ballot(open);
+        if (om) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&nboth, __popcll(om));
+            base = __shfl(base, 0);
+            if (open) runs[(size_t)tile * V_RUN_MAX + (base & 0xffff) + __popcll(om & (le >> 1))] = rec | (unsigned)k << 17;
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) { rootn[tile] = nboth >> 16; runn[tile] = nboth & 0xffff; }
 }
 
 // unions of the open components across tile edges, on the root slot ids.  Threads exist only for border pixels, as in
@@ -681,7 +698,7 @@ __global__ __launch_bounds__(64) void vote_merge_kernel(int* P, int* hist, const
 // lib/postprocess.py:22-23), written to the run's pixels
 template <typename LT>
 __global__ __launch_bounds__(256) void vote_apply_runs_kernel(const int* __restrict__ P, const int* __restrict__ hist, const VRun* __restrict__ runs,
-                                                              const int* __restrict__ runn, const uint8_t* __restrict__ slotof, LT* pred, int W, int ncls) {
+                                                              const int* __restrict__ runn, LT* pred, int W, int ncls) {
     const int tile = blockIdx.x;
     const int n = runn[tile];
     if (n == 0) return;
@@ -689,15 +706,14 @@ __global__ __launch_bounds__(256) void vote_apply_runs_kernel(const int* __restr
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     for (int i = threadIdx.x; i < n; i += 256) {
         const VRun rec = runs[(size_t)tile * V_RUN_MAX + i];
-        const int id = tile * V_OPEN_MAX + slotof[(size_t)tile * (CT_H * CT_W) + (rec & 2047)];
-        const int* h = hist + (size_t)uf_find(P, id) * ncls;
+        const int* h = hist + (size_t)uf_find(P, tile * V_OPEN_MAX + (int)(rec >> 17)) * ncls;
         int best = 0, bv = h[0];
         for (int c = 1; c < ncls; ++c) {
             const int v = h[c];
             if (v > bv) { bv = v; best = c; }
         }
-        const int a = (rec >> 16) & 63, e = (rec >> 22) & 63;
-        LT* o = pred + (size_t)(ty * CT_H + (int)((rec >> 11) & 31)) * W + tx * CT_W;
+        const int a = (rec >> 5) & 63, e = (rec >> 11) & 63;
+        LT* o = pred + (size_t)(ty * CT_H + (int)(rec & 31)) * W + tx * CT_W;
         for (int k = a; k <= e; ++k) o[k] = (LT)best;
     }
 }
@@ -768,23 +784,23 @@ static int cc_vote_device(LT* d_pred, const uint8_t* d_bin, int H, int W, int nc
         // per tile: V_OPEN_MAX root slots (parent + a row of counters each), the rim table, the run list, two list lengths
         const size_t slots = (size_t)tiles * V_OPEN_MAX;
         const size_t runs_b = (size_t)tiles * V_RUN_MAX * sizeof(VRun), par_b = slots * 4, hist_b = slots * ncls * 4, rim_b = round_up((size_t)tiles * V_RIM, (size_t)16);
-        const size_t slot_b = (size_t)tiles * CT_H * CT_W;
-        char* d_aux = (char*)need(2, runs_b + par_b + hist_b + rim_b + slot_b + 2 * (size_t)tiles * 4);
+        char* d_aux = (char*)need(2, runs_b + par_b + hist_b + rim_b + 2 * (size_t)tiles * 4);
         if (!d_aux) return fail(PSEG_ENOMEM, "hipMalloc(vote workspace) failed");
         VRun* d_runs = (VRun*)d_aux;
         int* d_par = (int*)(d_aux + runs_b);
         int* d_hist = (int*)(d_aux + runs_b + par_b);
         uint8_t* d_rim = (uint8_t*)(d_aux + runs_b + par_b + hist_b);
-        uint8_t* d_slot = d_rim + rim_b;
-        int* d_rootn = (int*)(d_aux + runs_b + par_b + hist_b + rim_b + slot_b);
+        int* d_rootn = (int*)(d_aux + runs_b + par_b + hist_b + rim_b);
         int* d_runn = d_rootn + tiles;
-        const size_t lds = (size_t)CT_H * CT_W * 4 + (size_t)ncls * CT_H * CT_W * 2;
-        vote_tile_kernel<LT, 8><<<tiles, 512, lds, st>>>(d_bin, d_pred, d_par, d_hist, d_rim, d_slot, d_rootn, d_runs, d_runn, H, W, ncls);
+        const size_t lds = (size_t)ncls * V_RUN_MAX * 2 + (size_t)ncls * CT_H * 8;
+        // four waves per tile: the kernel waits (loads, LDS round trips, barriers) for 70 % of its wave cycles, and a CU's 32 wave slots
+        // hold seven tiles of four waves (LDS) but four of eight -- same box, configs[4]'s page: 0.112 against 0.131 ms
+        vote_tile_kernel<LT, 4><<<tiles, 256, lds, st>>>(d_bin, d_pred, d_par, d_hist, d_rim, d_rootn, d_runs, d_runn, H, W, ncls);
         const int nby = (H - 1) / CT_H, nbx = (W - 1) / CT_W;
         if (nby * W + nbx * H > 0) {                      // (a one-tile page has no open component)
             vote_border_kernel<<<cdiv(nby * W + nbx * H, 256), 256, 0, st>>>(d_bin, d_rim, d_par, H, W, nby, nbx);
             vote_merge_kernel<<<tiles, 64, 0, st>>>(d_par, d_hist, d_rootn, ncls);
-            vote_apply_runs_kernel<LT><<<tiles, 256, 0, st>>>(d_par, d_hist, d_runs, d_runn, d_slot, d_pred, W, ncls);
+            vote_apply_runs_kernel<LT><<<tiles, 256, 0, st>>>(d_par, d_hist, d_runs, d_runn, d_pred, W, ncls);
         }
     }
     if (rc == PSEG_OK && hipGetLastError() != hipSuccess) rc = fail(PSEG_EHIP, "vote kernel launch failed");

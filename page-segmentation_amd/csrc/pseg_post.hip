@@ -381,6 +381,7 @@ constexpr int V_NCLS_MAX = 12;                  // LDS: 8 KiB of labels + 4 KiB 
 typedef unsigned VRun;
 // rim table of a tile: slot of the root of the pixel at [0, 64) top row, [64, 128) bottom row, [128, 160) left column, [160, 192) right column
 constexpr int V_RIM = 2 * (CT_H + CT_W);
+constexpr int V_TASK_MAX = 64;                 // border unions a tile lists: <= 32 overlap starts along its top row, <= 16 pairs across its left edge
 // The kernel works on RUNS (maximal stretches of ink in a tile row), not pixels: after the one pass that turns the two maps
 // into bit masks -- ink per row, one mask per class and row -- a tile is its run list (row, first, last lane; ordered by
 // row, then column, so that the run holding bit b of row r is rowbase[r] + popcount(first-lane mask of r up to b) - 1), and
@@ -392,7 +393,8 @@ __device__ __forceinline__ unsigned long long bits_le(int b) { return b >= 63 ? 
 template <typename LT, int NW>
 __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __restrict__ bin, LT* pred, int* __restrict__ P, int* __restrict__ hist,
                                                         uint8_t* __restrict__ rimtab, int* __restrict__ rootn, VRun* __restrict__ runs,
-                                                        int* __restrict__ runn, int H, int W, int ncls) {
+                                                        int* __restrict__ runn, unsigned short* __restrict__ tasks, int* __restrict__ taskn,
+                                                        int H, int W, int ncls) {
     constexpr int NTH = NW * 64, RPW = CT_H / NW, HALF = V_RUN_MAX / 2;
     static_assert(NW >= 4 && RPW % 4 == 0, "four rows of a wave are one 64-lane dword load; waves 0-3 fetch the tile's surroundings");
     extern __shared__ __attribute__((aligned(16))) unsigned vsm[];
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
     __shared__ unsigned rl[V_RUN_MAX];                    // the runs: row | first lane << 5 | last lane << 11 (| an open root's slot << 17)
     __shared__ int parent[V_RUN_MAX];                     // union-find over run indices (staging area of the maps before that)
     __shared__ unsigned openbits[V_RUN_MAX / 32];
-    __shared__ int nboth;                                 // open runs | open roots << 16
+    __shared__ int nboth, ntask;                          // open runs | open roots << 16; border unions of this tile
     const int tiles_x = (W + CT_W - 1) / CT_W;
     const int tile = blockIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
     const int rw0 = wave * RPW;                           // this wave's rows: rw0 .. rw0 + RPW - 1
     for (int i = threadIdx.x; i < ncls * HALF / 4; i += NTH) ((uint4*)cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (threadIdx.x < V_RUN_MAX / 32) openbits[threadIdx.x] = 0;
-    if (threadIdx.x == 0) nboth = 0;
+    if (threadIdx.x == 0) { nboth = 0; ntask = 0; }
     // ---- the two maps -> masks.  A wave's RPW rows of 64 bytes are ONE dword load per map (lane -> row lane / 16, dword
     // lane % 16) where the tile lies inside the page and rows are dword-aligned, handed to the lanes of the columns through
     // LDS; byte loads per row otherwise.  Waves 0, 1 also fetch the rows above / below the tile, waves 2, 3 the columns
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
         }
     }
     if (!__syncthreads_or(nruns_w)) {                     // a tile of paper
-        if (threadIdx.x == 0) { rootn[tile] = 0; runn[tile] = 0; }
+        if (threadIdx.x == 0) { rootn[tile] = 0; runn[tile] = 0; taskn[tile] = 0; }
         return;
     }
     // ---- the run list (every wave scans the 32 row counts itself), every run its own parent ----
@@ -613,6 +615,19 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
                 if (r == CT_H - 1) { unsigned long long w = S & m_dn; while (w) { rim[CT_W + __builtin_ctzll(w)] = (uint8_t)k; w &= w - 1; } }
                 if (s0 == 0 && ((lr0 >> r) & 1)) rim[2 * CT_W + r] = (uint8_t)k;
                 if (e == CT_W - 1 && ((lr1 >> r) & 1)) rim[2 * CT_W + CT_H + r] = (uint8_t)k;
+                // the unions across this tile's top and left edge (the tiles below / right list theirs): one where an overlap with
+                // a run of the row above begins; one per pixel pair across the left edge unless the pair above joins the same two
+                // column runs.  slot | place in the neighbour's rim table << 8
+                if (r == 0) {
+                    const unsigned long long w = S & m_up;
+                    unsigned long long st = w & ~(w << 1);
+                    while (st) {
+                        tasks[(size_t)tile * V_TASK_MAX + atomicAdd(&ntask, 1)] = (unsigned short)(k | (CT_W + __builtin_ctzll(st)) << 8);
+                        st &= st - 1;
+                    }
+                }
+                if (s0 == 0 && ((lr0 >> r) & 1) && !(r > 0 && (m64[r] & 1) && ((lr0 >> (r - 1)) & 1)))
+                    tasks[(size_t)tile * V_TASK_MAX + atomicAdd(&ntask, 1)] = (unsigned short)(k | (2 * CT_W + CT_H + r) << 8);
             }
         }
         const unsigned long long om = __ballot(open);
@@ -624,33 +639,20 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { rootn[tile] = nboth >> 16; runn[tile] = nboth & 0xffff; }
+    if (threadIdx.x == 0) { rootn[tile] = nboth >> 16; runn[tile] = nboth & 0xffff; taskn[tile] = ntask; }
 }
 
-// unions of the open components across tile edges, on the root slot ids.  Threads exist only for border pixels, as in
-// ccl_border_kernel (same two redundancy rules); a pixel's root slot comes from its tile's rim table.
-__global__ __launch_bounds__(256) void vote_border_kernel(const uint8_t* __restrict__ bin, const uint8_t* __restrict__ rimtab, int* P, int H, int W, int nby, int nbx) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int tiles_x = (W + CT_W - 1) / CT_W;
-    int ta, tb, ea, eb;                                   // the two tiles and the pixels' places in their rim tables
-    if (t < nby * W) {                                    // horizontal borders: p = first row of a tile band, q above it
-        const int by = t / W + 1, x = t % W;
-        const size_t p = (size_t)by * CT_H * W + x, q = p - W;
-        if (bin[p] == 0 || bin[q] == 0) return;
-        if ((x % CT_W) != 0 && bin[p - 1] != 0 && bin[q - 1] != 0) return;      // the left neighbours join the same two runs (not at a tile corner)
-        ta = by * tiles_x + x / CT_W; tb = ta - tiles_x;
-        ea = x % CT_W; eb = CT_W + x % CT_W;
-    } else {
-        const int u = t - nby * W;
-        if (u >= nbx * H) return;                         // vertical borders: p = first column of a tile column, its left neighbour
-        const int bx = u / H + 1, y = u % H;
-        const size_t p = (size_t)y * W + (size_t)bx * CT_W;
-        if (bin[p] == 0 || bin[p - 1] == 0) return;
-        if ((y % CT_H) != 0 && bin[p - W] != 0 && bin[p - W - 1] != 0) return;  // the pair above joins the same two column runs
-        ta = (y / CT_H) * tiles_x + bx; tb = ta - 1;
-        ea = 2 * CT_W + y % CT_H; eb = 2 * CT_W + CT_H + y % CT_H;
-    }
-    uf_union(P, ta * V_OPEN_MAX + rimtab[(size_t)ta * V_RIM + ea], tb * V_OPEN_MAX + rimtab[(size_t)tb * V_RIM + eb]);
+// unions of the open components across tile edges, on the root slot ids: a wave per tile takes the tile's task list (written by
+// vote_tile_kernel from its masks -- the binarisation is not read again), looks the neighbour's slot up in ITS rim table (places
+// >= 2 CT_W: the left neighbour's right column, else the upper neighbour's bottom row) and joins.
+__global__ __launch_bounds__(64) void vote_border_kernel(const uint8_t* __restrict__ rimtab, const unsigned short* __restrict__ tasks,
+                                                         const int* __restrict__ taskn, int* P, int tiles_x) {
+    const int tile = blockIdx.x;
+    const int n = taskn[tile];
+    if ((int)threadIdx.x >= n) return;
+    const unsigned t = tasks[(size_t)tile * V_TASK_MAX + threadIdx.x];
+    const int place = (int)(t >> 8), nb = place >= 2 * CT_W ? tile - 1 : tile - tiles_x;
+    uf_union(P, tile * V_OPEN_MAX + (int)(t & 255u), nb * V_OPEN_MAX + rimtab[(size_t)nb * V_RIM + place]);
 }
 
 // counts of the root slots that a border union redirected: added to the final root's row (and the slot pointed straight at
@@ -784,21 +786,24 @@ static int cc_vote_device(LT* d_pred, const uint8_t* d_bin, int H, int W, int nc
         // per tile: V_OPEN_MAX root slots (parent + a row of counters each), the rim table, the run list, two list lengths
         const size_t slots = (size_t)tiles * V_OPEN_MAX;
         const size_t runs_b = (size_t)tiles * V_RUN_MAX * sizeof(VRun), par_b = slots * 4, hist_b = slots * ncls * 4, rim_b = round_up((size_t)tiles * V_RIM, (size_t)16);
-        char* d_aux = (char*)need(2, runs_b + par_b + hist_b + rim_b + 2 * (size_t)tiles * 4);
+        const size_t task_b = (size_t)tiles * V_TASK_MAX * 2;
+        char* d_aux = (char*)need(2, runs_b + par_b + hist_b + rim_b + task_b + 3 * (size_t)tiles * 4);
         if (!d_aux) return fail(PSEG_ENOMEM, "hipMalloc(vote workspace) failed");
         VRun* d_runs = (VRun*)d_aux;
         int* d_par = (int*)(d_aux + runs_b);
         int* d_hist = (int*)(d_aux + runs_b + par_b);
         uint8_t* d_rim = (uint8_t*)(d_aux + runs_b + par_b + hist_b);
-        int* d_rootn = (int*)(d_aux + runs_b + par_b + hist_b + rim_b);
+        unsigned short* d_tasks = (unsigned short*)(d_aux + runs_b + par_b + hist_b + rim_b);
+        int* d_rootn = (int*)(d_aux + runs_b + par_b + hist_b + rim_b + task_b);
         int* d_runn = d_rootn + tiles;
+        int* d_taskn = d_runn + tiles;
         const size_t lds = (size_t)ncls * V_RUN_MAX * 2 + (size_t)ncls * CT_H * 8;
         // four waves per tile: the kernel waits (loads, LDS round trips, barriers) for 70 % of its wave cycles, and a CU's 32 wave slots
         // hold seven tiles of four waves (LDS) but four of eight -- same box, configs[4]'s page: 0.112 against 0.131 ms
-        vote_tile_kernel<LT, 4><<<tiles, 256, lds, st>>>(d_bin, d_pred, d_par, d_hist, d_rim, d_rootn, d_runs, d_runn, H, W, ncls);
+        vote_tile_kernel<LT, 4><<<tiles, 256, lds, st>>>(d_bin, d_pred, d_par, d_hist, d_rim, d_rootn, d_runs, d_runn, d_tasks, d_taskn, H, W, ncls);
         const int nby = (H - 1) / CT_H, nbx = (W - 1) / CT_W;
         if (nby * W + nbx * H > 0) {                      // (a one-tile page has no open component)
-            vote_border_kernel<<<cdiv(nby * W + nbx * H, 256), 256, 0, st>>>(d_bin, d_rim, d_par, H, W, nby, nbx);
+            vote_border_kernel<<<tiles, 64, 0, st>>>(d_rim, d_tasks, d_taskn, d_par, cdiv(W, CT_W));
             vote_merge_kernel<<<tiles, 64, 0, st>>>(d_par, d_hist, d_rootn, ncls);
             vote_apply_runs_kernel<LT><<<tiles, 256, 0, st>>>(d_par, d_hist, d_runs, d_runn, d_pred, W, ncls);
         }

@@ -150,6 +150,41 @@ def test_cc_vote_uint8_and_int64_maps_on_shapes_around_the_tile_edges(gpu, oracl
         assert np.array_equal(got8.astype(np.int64), want), ("u8", pred.shape, C)
 
 
+def test_cc_vote_structured_extremes_of_the_run_lists(gpu, oracle_mod):
+    """The tile pass keeps runs, root slots and border-union tasks in fixed-size per-tile lists: the patterns that fill them -- a
+    checkerboard (every other pixel a run of its own: 1 024 runs in a 32 x 64 tile), all ink (one component through every tile
+    edge), single-pixel rows / columns (a run per row; a task per row across the left edge), a comb, a spiral through many tiles,
+    diagonal stripes -- against the oracle, uint8 and int64 maps, 3 and 12 classes."""
+    rng = np.random.default_rng(17)
+    H, W = 131, 262
+    yy, xx = np.mgrid[0:H, 0:W]
+    pats = {
+        "checkerboard": ((yy + xx) & 1),
+        "all_ink": np.ones((H, W), int),
+        "rows": (yy & 1) * np.ones((H, W), int),
+        "columns": (xx & 1) * np.ones((H, W), int),
+        "comb": ((yy == 3) | ((xx % 3 == 0) & (yy > 3))),
+        "diagonals": ((yy + xx) % 4 < 2),
+        "border_pairs": (((xx % 64) >= 62) | ((xx % 64) <= 1) | ((yy % 32) == 31) | ((yy % 32) == 0)) & (((yy // 2 + xx // 2) & 1) == 0),
+    }
+    sp = np.zeros((H, W), int)
+    t, l, b, r = 0, 0, H - 1, W - 1
+    while t <= b and l <= r:                      # a spiral with gaps of one pixel: one long component
+        sp[t, l:r + 1] = 1; sp[t:b + 1, r] = 1
+        if t + 2 <= b: sp[b, l + 2:r + 1] = 1
+        if l + 2 <= r and t + 2 <= b: sp[t + 2:b + 1, l + 2] = 1
+        t += 2; l += 2; b -= 2; r -= 2
+        if t <= b and l <= r: sp[t, l] = 1
+    pats["spiral"] = sp
+    for name, pat in pats.items():
+        binary = pat.astype(np.uint8)
+        for C in (3, 12):
+            pred = rng.integers(0, C, size=(H, W)).astype(np.int64)
+            want = oracle_mod.vote_connected_component_class(pred, binary)
+            assert np.array_equal(gpu.cc_vote(pred.copy(), binary, C), want), (name, C)
+            assert np.array_equal(_vote_u8_device(gpu, pred.astype(np.uint8), binary, C).astype(np.int64), want), (name, C, "u8")
+
+
 def test_cc_vote_full_size_page_properties(gpu):
     """configs[4] size (4096 x 3072, 6 classes), where the oracle is too slow: the vote is idempotent, leaves paper pixels
     alone, makes every ink run of a row uniform, and the uint8 and int64 entries agree."""

@@ -258,6 +258,10 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
     constexpr bool c_persist = FIXED && (FL_ & FL_PERSIST) != 0;
     const int c_dbg = PSEG_DIAG ? a.dbg : 0;
     const bool getenv_vgpr_inrelu = (a.dbg & 16) != 0;   // host knob PSEG_INRELU_VGPR: old VGPR staging path for pre-activation ReLU
+    // pre-activation ReLU (res_unet) of the compiled instances: on the pixel FRAGMENTS, four v_pk_max_i16 per fragment in the shadow
+    // of the k-step's MFMAs (bf16 as int16: negative <=> sign bit), not a pass over the LDS tile behind every channel block's DMA
+    // (read-modify-write of the whole tile + a barrier: 637 vs 544 us for the two full-resolution layers on the same input)
+    constexpr bool c_relu_frag = FIXED && (FL_ & FL_INRELU) != 0;
     unsigned long long* const c_trace = PSEG_DIAG ? a.trace : nullptr;
     char* in_t = smem;
     char* w_t = smem + a.lds_w_off;
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             lds_barrier();
             if (c_trace) { const long long t1 = __builtin_amdgcn_s_memtime(); acc_wait += t1 - tw0; tw0 = t1; }
             if (b == 0 && lg == 0) { PSEG_STAMP(4) }
-            if (c_inrelu && lg == 0 && !getenv_vgpr_inrelu) {
+            if (c_inrelu && !c_relu_frag && lg == 0 && !getenv_vgpr_inrelu) {
                 // pre-activation ReLU (res_unet) on the tile the DMA just delivered: one in-place pass over
                 // the LDS tile (zeros of the padding stay zeros), then every wave may read it
                 const int tile_bytes = c_THH * a.row_pitch;
@@ -679,25 +683,36 @@ __global__ __launch_bounds__(NW_ * 64) __attribute__((amdgpu_waves_per_eu((MT ==
             _Pragma("unroll") for (int q_ = 0; q_ < MT * NT; ++q_) {                              \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                \
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                \
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                \
+                __builtin_amdgcn_sched_group_barrier(0x002, c_relu_frag ? 2 : 1, 0);              \
+            }
+#define PSEG_RELU(XF)                                                                            \
+            if constexpr (c_relu_frag) {                                                         \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                 \
+                    const uint4 q_ = __builtin_bit_cast(uint4, XF[m]);                           \
+                    XF[m] = __builtin_bit_cast(bf16x8, make_uint4(relu_pk_bf16(q_.x, 0u), relu_pk_bf16(q_.y, 0u), relu_pk_bf16(q_.z, 0u), relu_pk_bf16(q_.w, 0u))); \
+                }                                                                                \
             }
             int offa = PSEG_TAB(0), offb = PSEG_TAB(1);
             PSEG_LOAD(xa, wa, 0, offa)
+            PSEG_RELU(xa)
             int s = 0;
             for (; s + 2 <= n; s += 2) {
                 __builtin_amdgcn_sched_barrier(0);
                 offa = PSEG_TAB(s + 2);                     // the table read goes first: the next region opens with its result
                 PSEG_LOAD(xb, wbq, s + 1, offb)
                 PSEG_MMA(xa, wa)
+                PSEG_RELU(xb)
                 PSEG_INTERLEAVE
                 __builtin_amdgcn_sched_barrier(0);
                 offb = PSEG_TAB(s + 3);
                 PSEG_LOAD(xa, wa, s + 2, offa)
                 PSEG_MMA(xb, wbq)
+                PSEG_RELU(xa)
                 PSEG_INTERLEAVE
             }
             __builtin_amdgcn_sched_barrier(0);
             if (n & 1) { PSEG_MMA(xa, wa) }
+#undef PSEG_RELU
 #undef PSEG_INTERLEAVE
 #undef PSEG_TAB
 #undef PSEG_LOAD

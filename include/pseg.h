@@ -349,6 +349,12 @@ int pseg_scale_image(int device, const void* src, int src_is_f64, int H, int W, 
  * nearest (binary, mask).  float32 (H,W) planes, host pointers. */
 int pseg_affine_warp(int device, const float* src, int H, int W, const double m[4], const double off[2],
                      int order, float* dst);
+/* ... with the other fill mode the reference's AugmentationSettings name (lib/trainer.py:23-28 image_fill_mode / binary_fill_mode /
+ * mask_fill_mode and *_cval -> keras-preprocessing apply_affine_transform(fill_mode, cval)): fill_mode 0 'nearest', 1 'constant'
+ * (scipy mode='constant': cval where the source coordinate leaves [0, n - 1]; the spline prefilter runs on the unpadded plane).
+ * 'reflect' / 'wrap' are not built. */
+int pseg_affine_warp_fill(int device, const float* src, int H, int W, const double m[4], const double off[2],
+                          int order, int fill_mode, float cval, float* dst);
 
 /* ---- evaluation reductions ------------------------------------------------------------ */
 

@@ -208,11 +208,11 @@ __global__ __launch_bounds__(256) void prep_map_kernel(const void* src, void* ds
 // M (r, c) + offset with coordinates clamped to the padded plane; order 0: floor(coord + 0.5), clamped.
 constexpr int WARP_PAD = 12;
 
-__global__ __launch_bounds__(256) void warp_pad_kernel(const float* src, int H, int W, double* dst) {
-    const int Wp = W + 2 * WARP_PAD, Hp = H + 2 * WARP_PAD;
+__global__ __launch_bounds__(256) void warp_pad_kernel(const float* src, int H, int W, double* dst, int pad) {
+    const int Wp = W + 2 * pad, Hp = H + 2 * pad;
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= Wp || y >= Hp) return;
-    const int sy = min(max(y - WARP_PAD, 0), H - 1), sx = min(max(x - WARP_PAD, 0), W - 1);
+    const int sy = min(max(y - pad, 0), H - 1), sx = min(max(x - pad, 0), W - 1);
     dst[(size_t)y * Wp + x] = (double)src[(size_t)sy * W + sx];
 }
 
@@ -248,6 +248,49 @@ __global__ __launch_bounds__(64) void spline3_prefilter_kernel(double* c, int Hp
     for (int i = 1; i < n; ++i) p[i * st] += z * p[(i - 1) * st];
     p[(size_t)(n - 1) * st] = (z / (z * z - 1.0)) * (n > 1 ? z * p[(size_t)(n - 2) * st] + p[(size_t)(n - 1) * st] : p[0] * (1.0 + z));
     for (int i = n - 2; i >= 0; --i) p[i * st] = z * (p[(i + 1) * st] - p[i * st]);
+}
+
+// fill_mode 'constant' (scipy.ndimage mode='constant'): the plane is NOT padded, the prefilter runs on it with the same mirror
+// initialisation, a coordinate outside [0, n - 1] on either axis gives `cval`, taps past the edge read the mirrored coefficient
+__device__ __forceinline__ int warp_mirror(int i, int n) {
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    i = (i < 0 ? -i : i) % p;
+    return i < n ? i : p - i;
+}
+template <int ORDER>
+__global__ __launch_bounds__(256) void affine_warp_const_kernel(const double* coef, const float* src, int H, int W, float* dst,
+                                                                double m00, double m01, double m10, double m11, double o0, double o1, float cval) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const double y = m00 * (double)r + m01 * (double)c + o0, x = m10 * (double)r + m11 * (double)c + o1;
+    if (y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1)) { dst[(size_t)r * W + c] = cval; return; }
+    if (ORDER == 0) {
+        dst[(size_t)r * W + c] = src[(size_t)(int)floor(y + 0.5) * W + (int)floor(x + 0.5)];
+        return;
+    }
+    const int y0 = (int)floor(y), x0 = (int)floor(x);
+    const double ty = y - y0, tx = x - x0;
+    auto w3 = [](double t, double* w) {
+        const double u = 1.0 - t;
+        w[0] = u * u * u / 6.0;
+        w[1] = (4.0 - 6.0 * t * t + 3.0 * t * t * t) / 6.0;
+        w[2] = (4.0 - 6.0 * u * u + 3.0 * u * u * u) / 6.0;
+        w[3] = t * t * t / 6.0;
+    };
+    double wy[4], wx[4];
+    w3(ty, wy);
+    w3(tx, wx);
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = warp_mirror(y0 - 1 + i, H);
+        double row = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row += wx[j] * coef[(size_t)yy * W + warp_mirror(x0 - 1 + j, W)];
+        acc += wy[i] * row;
+    }
+    dst[(size_t)r * W + c] = (float)acc;
 }
 
 template <int ORDER>
@@ -480,8 +523,14 @@ int pseg_scale_image(int device, const void* src, int src_is_f64, int H, int W, 
 
 int pseg_affine_warp(int device, const float* src, int H, int W, const double m[4], const double off[2], int order,
                      float* dst) {
+    return pseg_affine_warp_fill(device, src, H, W, m, off, order, 0, 0.0f, dst);
+}
+
+int pseg_affine_warp_fill(int device, const float* src, int H, int W, const double m[4], const double off[2], int order,
+                          int fill_mode, float cval, float* dst) {
     if (!src || !dst || !m || !off) return fail(PSEG_EINVAL, "NULL argument");
     if (order != 0 && order != 3) return fail(PSEG_EUNSUPPORTED, "interpolation order %d (0 and 3 are built)", order);
+    if (fill_mode != 0 && fill_mode != 1) return fail(PSEG_EUNSUPPORTED, "fill mode %d (0 'nearest' and 1 'constant' are built)", fill_mode);
     PSEG_TRY(check_shape(H, W, H, W));
     PSEG_TRY(rz_set_dev(device));
     DevMem mem;
@@ -492,15 +541,18 @@ int pseg_affine_warp(int device, const float* src, int H, int W, const double m[
     PSEG_HIP(hipMemcpy(d_s, src, n * 4, hipMemcpyHostToDevice));
     const dim3 grid(cdiv(W, 256), H);
     if (order == 0) {
-        affine_warp_kernel<0><<<grid, 256>>>(nullptr, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1]);
+        if (fill_mode == 1) affine_warp_const_kernel<0><<<grid, 256>>>(nullptr, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1], cval);
+        else affine_warp_kernel<0><<<grid, 256>>>(nullptr, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1]);
     } else {
-        const int Hp = H + 2 * WARP_PAD, Wp = W + 2 * WARP_PAD;
+        const int pad = fill_mode == 1 ? 0 : WARP_PAD;       // ('constant': scipy filters the plane itself)
+        const int Hp = H + 2 * pad, Wp = W + 2 * pad;
         double* d_c = nullptr;
         PSEG_TRY(mem.alloc(&d_c, (size_t)Hp * Wp));
-        warp_pad_kernel<<<dim3(cdiv(Wp, 256), Hp), 256>>>(d_s, H, W, d_c);
+        warp_pad_kernel<<<dim3(cdiv(Wp, 256), Hp), 256>>>(d_s, H, W, d_c, pad);
         spline3_prefilter_kernel<0><<<cdiv(Wp, 64), 64>>>(d_c, Hp, Wp);     // axis 0 first, as scipy's spline_filter
         spline3_prefilter_kernel<1><<<cdiv(Hp, 64), 64>>>(d_c, Hp, Wp);
-        affine_warp_kernel<3><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1]);
+        if (fill_mode == 1) affine_warp_const_kernel<3><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1], cval);
+        else affine_warp_kernel<3><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1]);
     }
     PSEG_HIP(hipGetLastError());
     PSEG_HIP(hipMemcpy(dst, d_d, n * 4, hipMemcpyDeviceToHost));

@@ -2,8 +2,9 @@
 ImageDataGenerator).  Only what the reference's augmentation uses is restated (lib/trainer.py:14-56,
 lib/network.py:109-125,149-161): rotation / shift / shear / zoom parameters drawn from NumPy's global
 RandomState in keras-preprocessing's order, horizontal / vertical flips, one affine warp per sample with
-`fill_mode='nearest'`; the warp itself runs on the GPU (pseg_affine_warp: cubic B-spline for the image,
-nearest for binary and mask).  Brightness / channel shifts, other fill modes and featurewise statistics raise.
+`fill_mode='nearest'` (the reference default) or `'constant'` with `cval`; the warp itself runs on the GPU
+(pseg_affine_warp_fill: cubic B-spline for the image, nearest for binary and mask).  Brightness / channel shifts, the fill
+modes 'reflect' / 'wrap' and featurewise statistics raise.
 keras-preprocessing and the scipy release it ran on are absent offline: parity unpinned (tests compare the
 warp with the installed scipy, the parameter stream with its published algorithm)."""
 import numpy as np
@@ -16,8 +17,8 @@ class ImageDataGeneratorCustom:
                  data_format='channels_last', validation_split=0.0, dtype='float32', interpolation_order=1, **unused):
         if data_format != 'channels_last':
             raise Exception("only data_format='channels_last' is built")
-        if fill_mode != 'nearest':
-            raise Exception("only fill_mode='nearest' (the reference default) is built on the GPU")
+        if fill_mode not in ('nearest', 'constant'):
+            raise Exception("fill_mode 'nearest' (the reference default) and 'constant' are built on the GPU, not %r" % (fill_mode,))
         if brightness_range is not None or channel_shift_range:
             raise Exception("brightness / channel shifts are not built (the reference default is None)")
         if interpolation_order not in (0, 3):
@@ -34,6 +35,8 @@ class ImageDataGeneratorCustom:
         self.vertical_flip = vertical_flip
         self.rescale = rescale
         self.interpolation_order = interpolation_order
+        self.fill_mode = fill_mode
+        self.cval = cval
         self.dtype = dtype
 
     # keras_preprocessing/image/image_data_generator.py: get_random_transform (order of the RNG draws kept)
@@ -96,7 +99,7 @@ class ImageDataGeneratorCustom:
         x = np.asarray(x, dtype=np.float32)
         mo = self.affine_matrix(params, x.shape[0], x.shape[1])
         if mo is not None:
-            x = np.stack([_eng.affine_warp(x[..., c], mo[0], mo[1], self.interpolation_order)
+            x = np.stack([_eng.affine_warp(x[..., c], mo[0], mo[1], self.interpolation_order, fill_mode=self.fill_mode, cval=self.cval)
                           for c in range(x.shape[2])], axis=-1)
         if params.get('flip_horizontal', False):
             x = x[:, ::-1]

@@ -34,6 +34,43 @@ def test_affine_warp_matches_scipy(gpu, shape, order):
             assert np.abs(got - want).max() <= 2e-3 * 255    # B-spline overshoot scale; typically 1e-5
 
 
+@pytest.mark.parametrize("shape", [(64, 96), (33, 50), (7, 5), (1, 9)])
+@pytest.mark.parametrize("order", [0, 3])
+def test_affine_warp_constant_fill_matches_scipy(gpu, shape, order):
+    """fill_mode='constant' with a cval (lib/trainer.py:23-28 image_/binary_/mask_fill_mode and *_cval) against the installed
+    scipy.ndimage.affine_transform(mode='constant'): the fill value wherever the source coordinate leaves the plane, the
+    unpadded spline prefilter inside; 'reflect' / 'wrap' raise."""
+    from scipy import ndimage
+    from pseg_amd import engine as E
+    rng = np.random.default_rng(shape[0] * 10 + order + 1)
+    x = (rng.random(shape) * 255).astype(np.float32)
+    if order == 0:
+        x = np.round(x / 50)
+    for cval in (0.0, 255.0, 3.0):
+        for theta, tx, ty, zx, zy in [(2.5, 1.6, -2.4, 0.95, 1.05), (0.0, 3.0, 2.0, 1.0, 1.0), (40.0, 5.0, -7.0, 0.7, 1.4)]:
+            m, off = _params(shape[0], shape[1], theta, tx, ty, zx, zy)
+            got = E.affine_warp(x, m, off, order, fill_mode="constant", cval=cval)
+            want = ndimage.affine_transform(x.astype(np.float64), m, off, order=order, mode="constant", cval=cval).astype(np.float32)
+            assert got.dtype == np.float32 and got.shape == want.shape
+            if order == 0:
+                assert (got != want).mean() <= 0.01             # .5 ties, and coordinates within rounding of the plane's edge
+            else:
+                edge = (got == np.float32(cval)) != (want == np.float32(cval))      # coordinates within float64 rounding of the edge
+                assert edge.mean() <= 0.01
+                assert np.abs(got - want)[~edge].max(initial=0.0) <= 2e-3 * 255
+    with pytest.raises(E.PsegError):
+        E.affine_warp(x, np.eye(2), np.zeros(2), order, fill_mode="reflect")
+    from ocr4all_pixel_classifier.lib.data_generator import ImageDataGeneratorCustom as G
+    g = G(rotation_range=5, fill_mode="constant", cval=7.0, interpolation_order=order)
+    img = np.stack([x, x[::-1]], -1)
+    p = {'theta': 5.0, 'tx': 2.0, 'ty': -1.0, 'shear': 0.0, 'zx': 0.9, 'zy': 1.1, 'flip_horizontal': False, 'flip_vertical': False}
+    out = g.apply_transform(img, p)
+    m, off = G.affine_matrix(p, shape[0], shape[1])
+    assert np.array_equal(out[..., 1], E.affine_warp(np.ascontiguousarray(img[..., 1]), m, off, order, fill_mode="constant", cval=7.0))
+    with pytest.raises(Exception):
+        G(fill_mode="wrap")
+
+
 def test_generator_parameter_stream_and_flow(gpu):
     from ocr4all_pixel_classifier.lib.data_generator import ImageDataGeneratorCustom as G
     from ocr4all_pixel_classifier.lib.trainer import AugmentationSettings

@@ -3693,7 +3693,8 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
     // 128->64 the two extra passes over the full-resolution tensor cost more than the direct kernel (PSEG_UPSPLIT_MIN_CIN).
     if (op.type == OP_CONV && k == 2 && op.up0 && !s1 && op.stride == 1 && !op.in_relu && op.add < 0 && op.pool_dst < 0 &&
         op.tail_logits < 0 && op.fuse1 < 0 && !op.transposed && !PSEG_KNOB("PSEG_NO_UPSPLIT") && !PSEG_KNOB("PSEG_GENERIC")) {
-        const int min_cin = 256;
+        // (the two-pass form lost to the direct kernel at 128 -> 64 channels on the full-resolution map; the fused form does not)
+        const int min_cin = PSEG_KNOB("PSEG_UPSPLIT_TWO_PASS") ? 256 : 64;
         if (Cin >= min_cin) {
             P->kind = PLAN_UPSPLIT;
             return upsplit_create(&P->upsplit, w, bias, Cin, Cs0, Cout, e.tensors[op.dst].Cs);

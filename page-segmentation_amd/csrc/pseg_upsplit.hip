@@ -7,7 +7,10 @@
 // 4-term gather-sum over D (+ bias, ReLU), an HBM-bound pass.  The GEMM is upsplit_gemm_kernel below (hand-written MFMA
 // kernel, bf16 operands, f32 accumulation, both operands K-contiguous); the partial products are stored as
 // bf16, one more rounding than the direct kernel (same class as the per-layer activation rounding; the bf16
-// parity tests cover it).  Used where the deep layers make the direct kernel weight-stream bound (Cin >= 256).
+// parity tests cover it).  That two-pass form (plan switch PSEG_UPSPLIT_TWO_PASS) served the deep layers (Cin >= 256); the default
+// now is upsplit_fused_kernel below -- the products of a patch of source pixels stay in LDS and the same workgroup writes the
+// outputs -- for every upsample -> k2 layer of unet: 2048x1536, same box, two-pass (direct kernel for the last) -> fused:
+// 1024->512 80 -> 80 us, 512->256 121 -> 94, 256->128 191 -> 141, 128->64 258 -> 222; unet page 4.72 -> 4.60 ms.
 #include <algorithm>
 #include <cstring>
 
@@ -161,6 +164,153 @@ __global__ __launch_bounds__(256, 2) void upsplit_gemm_kernel(const uint16_t* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same products WITHOUT the trip through HBM: one workgroup takes an 8 x 16 patch of source pixels (the GEMM's 128 rows)
+// and 32 output channels (128 columns: 4 taps x 32), keeps the 128 x 128 float32 products in the LDS the operand ring no longer
+// needs and writes the 14 x 30 output pixels whose four terms all lie inside the patch -- patches step by 7 x 15 source pixels,
+// so 22 % of the products are computed twice, which is cheap (the GEMM has a quarter of the direct form's MACs) next to what
+// the split form moved: D written and gathered again, 0.8-1.4 GB per layer at 1/2 and full resolution against 0.3-0.6 GB here.
+// The products stay float32 until the sum (the split form rounded them to bf16): one rounding per output, as the direct kernel.
+// Source pixels outside the image are the descriptor's zeros = the 'same' padding of the k2 kernel on the upsampled map.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int UF_TY = 8, UF_TX = 16;                      // source patch (rows of the GEMM: r = ty * 16 + tx)
+__global__ __launch_bounds__(256, 2) void upsplit_fused_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                               const float* __restrict__ bias, uint16_t* __restrict__ dst,
+                                                               int Hs, int Ws, int K, int CoS, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 stages][A tile 16 KiB | B tile 16 KiB], then D [128][128] f32
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntx = (Ws + UF_TX - 2) / (UF_TX - 1);
+    const int nb = blockIdx.x, tile = blockIdx.y;          // cout block fastest: the blocks of a patch run together and share its pixels in L2
+    const int Y0 = (tile / ntx) * (UF_TY - 1), X0 = (tile % ntx) * (UF_TX - 1);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)Hs * Ws * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)4 * CoS * K * 2), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    unsigned offA[4], offB[4], chk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sl = (wave * 4 + j) * 64 + lane, row = sl >> 3, c = (sl & 7) ^ (row & 7);
+        chk[j] = (unsigned)c;
+        const int y = Y0 + (row >> 4), x = X0 + (row & 15);
+        offA[j] = (y < Hs && x < Ws) ? (unsigned)((((size_t)y * Ws + x) * K + c * 8) * 2) : OOB;
+        const int ab = row >> 5, co = nb * 32 + (row & 31);                     // column n = tap * 32 + output channel of the block
+        offB[j] = co < CoS ? (unsigned)((((size_t)ab * CoS + co) * K + c * 8) * 2) : OOB;
+    }
+    auto stage = [&](int k0, int buf) {
+        char* base = smem + buf * 32768 + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool kin = k0 + (int)chk[j] * 8 < K;
+            const unsigned oa = (offA[j] == OOB || !kin) ? OOB : offA[j] + (unsigned)k0 * 2u;
+            const unsigned ob = (offB[j] == OOB || !kin) ? OOB : offB[j] + (unsigned)k0 * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + j * 1024), 16, oa, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base + 16384 + j * 1024), 16, ob, 0, 0, 0);
+        }
+    };
+    const int nk = (K + GK - 1) / GK;
+    stage(0, 0);
+    if (nk > 1) stage(GK, 1);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw0 = ((g) ^ (p16 & 7)) * 16, sw1 = ((4 + g) ^ (p16 & 7)) * 16;
+    const int rowA = (wm * 64 + p16) * 128, rowB = 16384 + (wn * 64 + p16) * 128;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gemm_lds_barrier();
+        const char* sb = smem + (kt & 1) * 32768;
+        bf16x8 xf[2][4], wf[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xf[0][i] = *(const bf16x8*)(sb + rowA + i * 2048 + sw0);
+            wf[0][i] = *(const bf16x8*)(sb + rowB + i * 2048 + sw0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xf[1][i] = *(const bf16x8*)(sb + rowA + i * 2048 + sw1);
+            wf[1][i] = *(const bf16x8*)(sb + rowB + i * 2048 + sw1);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ni], xf[0][mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ni], xf[1][mi], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) {
+            gemm_lds_barrier();
+            stage((kt + 2) * GK, kt & 1);
+        }
+    }
+    // the products: row r (source pixel) x 32 slots of four floats, slot s of row r at position s ^ (r & 31) -- an accumulator
+    // tile's 16 pixels write 16 different positions, the readers below (one row, consecutive slots per lane) stay conflict-free
+    gemm_lds_barrier();                                                       // every wave is done with the last stage
+    float* const Dl = (float*)smem;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int r = wm * 64 + mi * 16 + p16, sl = wn * 16 + ni * 4 + g;
+            *(f32x4*)(Dl + r * 128 + ((sl ^ (r & 31)) << 2)) = acc[mi][ni];
+        }
+    gemm_lds_barrier();
+    // outputs (2 (Y0 + ty) + i, 2 (X0 + tx) + j), ty < 7, tx < 15: bias + the four taps in order 00, 01, 10, 11.  A thread takes the
+    // 2 x 2 outputs of ONE source pixel for eight channels: nine products (18 reads of four floats) instead of sixteen
+    const int Ho = 2 * Hs, Wo = 2 * Ws;
+    for (int it = tid; it < (UF_TY - 1) * (UF_TX - 1) * 4; it += 256) {
+        const int c8 = it & 3, px = it >> 2, ty = px / (UF_TX - 1), tx = px - ty * (UF_TX - 1);
+        const int co = nb * 32 + c8 * 8;
+        if (2 * (Y0 + ty) >= Ho || 2 * (X0 + tx) >= Wo || co >= CoS) continue;
+        auto ld = [&](int ab, int dy, int dx, float* v) {
+            const int r = (ty + dy) * 16 + tx + dx, s0 = ab * 8 + c8 * 2;
+            const f32x4 v0 = *(const f32x4*)(Dl + r * 128 + ((s0 ^ (r & 31)) << 2));
+            const f32x4 v1 = *(const f32x4*)(Dl + r * 128 + (((s0 + 1) ^ (r & 31)) << 2));
+            v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+        };
+        float p00[8], p01[2][8], p10[2][8], p11[2][2][8], bb[8];
+        ld(0, 0, 0, p00);
+        ld(1, 0, 0, p01[0]); ld(1, 0, 1, p01[1]);
+        ld(2, 0, 0, p10[0]); ld(2, 1, 0, p10[1]);
+        ld(3, 0, 0, p11[0][0]); ld(3, 0, 1, p11[0][1]); ld(3, 1, 0, p11[1][0]); ld(3, 1, 1, p11[1][1]);
+        const float4 b0 = *(const float4*)(bias + co), b1 = *(const float4*)(bias + co + 4);
+        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = 2 * (Y0 + ty) + i, x = 2 * (X0 + tx) + j;
+                if (y >= Ho || x >= Wo) continue;
+                uint32_t o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a0 = (((bb[2 * q] + p00[2 * q]) + p01[j][2 * q]) + p10[i][2 * q]) + p11[i][j][2 * q];
+                    float a1 = (((bb[2 * q + 1] + p00[2 * q + 1]) + p01[j][2 * q + 1]) + p10[i][2 * q + 1]) + p11[i][j][2 * q + 1];
+                    if (relu) { a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f; }
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                    o[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a0, a1}, b2));
+                }
+                *(uint4*)(dst + ((size_t)y * Wo + x) * CoS + co) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+    }
+}
+
 static inline uint16_t h_f2bf(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -232,6 +382,20 @@ int upsplit_launch(UpSplit* u, const uint16_t* src, int Hs, int Ws, uint16_t* ds
     const int64_t M = (int64_t)Hs * Ws, N = 4 * (int64_t)u->CoS, K = u->Cs0;
     if (M * K * 2 >= (int64_t)0xfffffff0u || N * K * 2 >= (int64_t)0xfffffff0u)
         return fail(PSEG_EUNSUPPORTED, "split up-conv operand larger than a 32-bit buffer range");
+    if (!PSEG_KNOB("PSEG_UPSPLIT_TWO_PASS")) {
+        // products kept in LDS, outputs written by the same workgroup (upsplit_fused_kernel)
+        static bool fattr[64] = {false};
+        int fdev = 0;
+        PSEG_HIP(hipGetDevice(&fdev));
+        if (!fattr[fdev & 63]) {
+            PSEG_HIP(hipFuncSetAttribute((const void*)upsplit_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+            fattr[fdev & 63] = true;
+        }
+        const dim3 grid((unsigned)cdiv(u->CoS, 32), (unsigned)(cdiv(Hs, UF_TY - 1) * cdiv(Ws, UF_TX - 1)));
+        upsplit_fused_kernel<<<grid, 256, 65536, st>>>(src, u->d_w, u->d_bias, dst, Hs, Ws, (int)K, u->CoS, relu);
+        PSEG_HIP(hipGetLastError());
+        return PSEG_OK;
+    }
     const size_t need = (size_t)M * N * 2;
     if (need > u->D_bytes) {
         PSEG_HIP(hipStreamSynchronize(st));                            // the old buffer may still be read by a queued pass

@@ -8,9 +8,10 @@
 // kernel, bf16 operands, f32 accumulation, both operands K-contiguous); the partial products are stored as
 // bf16, one more rounding than the direct kernel (same class as the per-layer activation rounding; the bf16
 // parity tests cover it).  That two-pass form (plan switch PSEG_UPSPLIT_TWO_PASS) served the deep layers (Cin >= 256); the default
-// now is upsplit_fused_kernel below -- the products of a patch of source pixels stay in LDS and the same workgroup writes the
-// outputs -- for every upsample -> k2 layer of unet: 2048x1536, same box, two-pass (direct kernel for the last) -> fused:
-// 1024->512 80 -> 80 us, 512->256 121 -> 94, 256->128 191 -> 141, 128->64 258 -> 222; unet page 4.72 -> 4.60 ms.
+// now are the one-pass kernels below -- the products of a patch of source pixels stay in LDS (upsplit_fused_kernel) or in registers
+// (upsplit_reg_kernel, short GEMMs) and the same workgroup writes the outputs -- for every upsample -> k2 layer of unet: 2048x1536,
+// same box, two-pass (direct kernel for the last) -> one pass: 1024->512 80 -> 80 us, 512->256 121 -> 94, 256->128 191 -> 141,
+// 128->64 258 -> 200; unet page 4.72 -> 4.58 ms.
 #include <algorithm>
 #include <cstring>
 
@@ -311,6 +312,145 @@ __global__ __launch_bounds__(256, 2) void upsplit_fused_kernel(const uint16_t* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ... and WITHOUT the trip through LDS.  The GEMM's columns are ordered so that the four accumulator values of a lane are the
+// four TAPS of one output channel -- column n = 16 nt + 4 g + t holds (tap t, channel 8 g + nt): lane (pixel p16, g) ends up
+// with the products of channels 8 g .. 8 g + 7 (its eight column tiles) of its pixel, 16 contiguous bytes of every output.
+// A wave owns three source rows of 16 pixels (rows 2 w, 2 w + 1 and the halo row 2 w + 2 of a 9 x 16 patch: the even rows
+// between waves are multiplied twice), so the terms of an output that belong to the row below are the lane's own registers
+// (next row tile) and the terms of the pixel to the right come from the neighbouring lane: no product leaves the registers.
+// A workgroup writes the 16 x 30 outputs of 8 x 15 source pixels for 32 channels; LDS holds the operand ring only.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int UR_ROWS = 9, UR_APIECES = UR_ROWS * 16 * 8 / 64, UR_PIECES = UR_APIECES + 16;   // 64-slot DMA pieces of a stage: 18 of A, 16 of B
+constexpr int UR_STAGE = UR_PIECES * 1024;                                                   // 34 KiB
+__global__ __launch_bounds__(256, 2) void upsplit_reg_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                             const float* __restrict__ bias, uint16_t* __restrict__ dst,
+                                                             int Hs, int Ws, int K, int CoS, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 stages][A: 144 pixel rows x 128 B | B: 128 column rows x 128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, g = lane >> 4;
+    const int ntx = (Ws + 14) / 15;
+    const int nb = blockIdx.x, tile = blockIdx.y;
+    const int Y0 = (tile / ntx) * 8, X0 = (tile % ntx) * 15;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)Hs * Ws * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)4 * CoS * K * 2), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    // pieces wave, wave + 4, ... of a stage (nine for waves 0 and 1, eight for the others)
+    unsigned off[9], chk[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int piece = wave + 4 * j;
+        off[j] = OOB; chk[j] = 0;
+        if (piece < UR_PIECES) {
+            const bool isA = piece < UR_APIECES;
+            const int sl = (isA ? piece : piece - UR_APIECES) * 64 + lane, row = sl >> 3, c = (sl & 7) ^ (row & 7);
+            chk[j] = (unsigned)c;
+            if (isA) {
+                const int y = Y0 + (row >> 4), x = X0 + (row & 15);
+                if (y < Hs && x < Ws) off[j] = (unsigned)((((size_t)y * Ws + x) * K + c * 8) * 2);
+            } else {
+                const int t = row & 3, co = nb * 32 + ((row >> 2) & 3) * 8 + (row >> 4);   // column row = 16 nt + 4 g + t
+                if (co < CoS) off[j] = (unsigned)((((size_t)t * CoS + co) * K + c * 8) * 2);
+            }
+        }
+    }
+    auto stage = [&](int k0, int buf) {
+        char* base = smem + buf * UR_STAGE;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int piece = wave + 4 * j;
+            if (piece < UR_PIECES) {                                         // (uniform)
+                const bool kin = k0 + (int)chk[j] * 8 < K;
+                const unsigned o = (off[j] == OOB || !kin) ? OOB : off[j] + (unsigned)k0 * 2u;
+                if (piece < UR_APIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + piece * 1024), 16, o, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base + piece * 1024), 16, o, 0, 0, 0);
+            }
+        }
+    };
+    const int nk = (K + GK - 1) / GK;
+    stage(0, 0);
+    if (nk > 1) stage(GK, 1);
+    f32x4 acc[3][8];
+#pragma unroll
+    for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw0 = ((g) ^ (p16 & 7)) * 16, sw1 = ((4 + g) ^ (p16 & 7)) * 16;
+    const int rowA = ((2 * wave) * 16 + p16) * 128, rowB = UR_APIECES * 1024 + p16 * 128;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) { if (wave < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gemm_lds_barrier();
+        const char* sb = smem + (kt & 1) * UR_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int sw = ks ? sw1 : sw0;
+            bf16x8 xf[3], wf[8];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xf[i] = *(const bf16x8*)(sb + rowA + i * 2048 + sw);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wf[i] = *(const bf16x8*)(sb + rowB + i * 2048 + sw);
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 3; ++mi)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
+        }
+        if (kt + 2 < nk) {
+            gemm_lds_barrier();
+            stage((kt + 2) * GK, kt & 1);
+        }
+    }
+    // acc[mi][ni][t]: source pixel (row 2 wave + mi, column p16), channel 8 g + ni, tap t = 2 a + b
+    const int Wo = 2 * Ws;
+    const int cob = nb * 32 + g * 8;
+    float bb[8];
+    {
+        const bool okc = cob < CoS;
+        const float4 b0 = okc ? *(const float4*)(bias + cob) : make_float4(0.f, 0.f, 0.f, 0.f), b1 = okc ? *(const float4*)(bias + cob + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+    }
+    // the right neighbour's b = 1 terms: tap 01 of rows 0, 1, tap 11 of rows 0 .. 2
+    float r01[2][8], r11[3][8];
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) r01[mi][ni] = __shfl_down(acc[mi][ni][1], 1, 16);
+#pragma unroll
+        for (int mi = 0; mi < 3; ++mi) r11[mi][ni] = __shfl_down(acc[mi][ni][3], 1, 16);
+    }
+    if (p16 < 15 && cob < CoS && X0 + p16 < Ws) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int sy = Y0 + 2 * wave + mi;
+            if (sy >= Hs) continue;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int y = 2 * sy + i, x = 2 * (X0 + p16) + j;
+                    uint32_t o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v2[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int ni = 2 * q + h;
+                            float v = ((bb[ni] + acc[mi][ni][0]) + (j ? r01[mi][ni] : acc[mi][ni][1])) + acc[mi + i][ni][2];
+                            v += j ? r11[mi + i][ni] : acc[mi + i][ni][3];
+                            v2[h] = relu ? (v > 0.f ? v : 0.f) : v;
+                        }
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                        o[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{v2[0], v2[1]}, b2));
+                    }
+                    *(uint4*)(dst + ((size_t)y * Wo + x) * CoS + cob) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+        }
+    }
+}
+
 static inline uint16_t h_f2bf(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -390,6 +530,20 @@ int upsplit_launch(UpSplit* u, const uint16_t* src, int Hs, int Ws, uint16_t* ds
         if (!fattr[fdev & 63]) {
             PSEG_HIP(hipFuncSetAttribute((const void*)upsplit_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
             fattr[fdev & 63] = true;
+        }
+        // products in registers (upsplit_reg_kernel) where the GEMM is short, in LDS (upsplit_fused_kernel) where it is long -- same box,
+        // 2048x1536 unet, registers / LDS: 128 -> 64 channels 200 / 215 us, 256 -> 128 141 / 141, 512 -> 256 103 / 96, 1024 -> 512 91 / 80
+        // (the register form multiplies every other source row twice and reads 11 fragments per 24 MFMAs)
+        if (K <= 128 && !PSEG_KNOB("PSEG_UPSPLIT_LDS")) {
+            static bool rattr[64] = {false};
+            if (!rattr[fdev & 63]) {
+                PSEG_HIP(hipFuncSetAttribute((const void*)upsplit_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * UR_STAGE));
+                rattr[fdev & 63] = true;
+            }
+            const dim3 gr((unsigned)cdiv(u->CoS, 32), (unsigned)(cdiv(Hs, 8) * cdiv(Ws, 15)));
+            upsplit_reg_kernel<<<gr, 256, 2 * UR_STAGE, st>>>(src, u->d_w, u->d_bias, dst, Hs, Ws, (int)K, u->CoS, relu);
+            PSEG_HIP(hipGetLastError());
+            return PSEG_OK;
         }
         const dim3 grid((unsigned)cdiv(u->CoS, 32), (unsigned)(cdiv(Hs, UF_TY - 1) * cdiv(Ws, UF_TX - 1)));
         upsplit_fused_kernel<<<grid, 256, 65536, st>>>(src, u->d_w, u->d_bias, dst, Hs, Ws, (int)K, u->CoS, relu);

@@ -155,6 +155,24 @@ def leg_host_path(np, pseg_amd, eng, synth, H, W, C, n_pages=32, reps=3):
     return out
 
 
+def leg_pages32(torch, np, eng, synth, H, W, C, dev, steps, warmup, n_pages=32):
+    """configs[2]'s share of ONE rank, HBM-resident: 32 pages per step through pseg_predict_pages_device, the same
+    timed-region protocol as the headline (W warm-up steps, K steps between two synchronisations).  This is the per-rank
+    baseline of the `--gpus N` line (which runs exactly this per rank): scaling efficiency N x this, not N x `value`
+    (one page per step: no page units, +7 % per page)."""
+    d_pages = torch.from_numpy(np.stack([synth.synth_page(p, H, W, C)[0] for p in range(n_pages)])).to(dev)
+    d_labels = torch.empty((n_pages, H, W), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    fn = lambda: eng.predict_pages_device(d_pages.data_ptr(), n_pages, H, W, d_labels_u8=d_labels.data_ptr(), stream=st)
+    steps = max(3, min(steps, 10))
+    t = _sync_time(torch, fn, steps, warm=max(1, min(warmup, 3)))
+    eng.status(st)
+    return {"Mpixels_s": round(n_pages * H * W / t / 1e6, 1), "ms_per_page": round(t / n_pages * 1e3, 4), "ms_per_step": round(t * 1e3, 4),
+            "pages_per_step": n_pages, "steps": steps,
+            "what": "HBM-resident, one pseg_predict_pages_device call per step, pages 0..%d of the synthetic set (rank 0's share of configs[2]); "
+                    "the per-rank baseline for the --gpus N line" % (n_pages - 1)}
+
+
 def leg_arch(torch, pseg_amd, synth, arch, H, W, C, dev, steps=5):
     """ms/page and roofline fractions of another graph (unet = the 3x3 stack north_star's 40 % names) on the same page."""
     eng = pseg_amd.Engine(arch, C, device=dev.index, mode=pseg_amd.MODE_BF16)
@@ -474,6 +492,7 @@ def run_rank(args):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    eng.status(stream)      # (outside the timed region) a kernel-side error of any step above is an error of the bench
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -526,7 +545,8 @@ def run_rank(args):
     if rank == 0 and world == 1:
         default_cfg = (H, W, C, args.arch, args.mode) == (2048, 1536, 3, "fcn_skip", "bf16")
         if not args.no_extra and default_cfg:
-            for key, fn in (("host_path", lambda: leg_host_path(np, pseg_amd, eng, synth, H, W, C)),
+            for key, fn in (("pages32", lambda: leg_pages32(torch, np, eng, synth, H, W, C, dev, args.steps, args.warmup)),
+                            ("host_path", lambda: leg_host_path(np, pseg_amd, eng, synth, H, W, C)),
                             ("f32", lambda: leg_f32(torch, pseg_amd, synth, weights, pages[0], H, W, C, dev, args.arch)),
                             ("train", lambda: leg_train(torch, np, pseg_amd, synth, H, W, C, dev, args.arch)),
                             ("label_exact", lambda: leg_label_exact(torch, np, pseg_amd, eng, pages[0], H, W, dev, synth, C, args.arch)),
@@ -564,7 +584,9 @@ def run_rank(args):
                                      "one pseg_predict_device call per page" if args.page_by_page else "one pseg_predict_pages_device call per step (page slots: the low-resolution layers take all pages of a unit in one launch)")))
                                    + ", inputs resident in HBM, uint8 label maps left in HBM (value = HBM-resident rate per the measurement "
                                      "contract; SURVEY 8d's pinned-host-in / host-out rate is value_host_path)",
-                       "pages_per_rank_per_step": args.pages, "parallelism": "page-parallel x%d" % world},
+                       "pages_per_rank_per_step": args.pages, "parallelism": "page-parallel x%d" % world,
+                       "per_rank_baseline": ("extra.pages32 of the --gpus 1 line (the same %d pages per step through pseg_predict_pages_device on one GPU), "
+                                             "not its `value` (one page per step)" % args.pages) if world > 1 else None},
             "roofline": roof,
             "cpu_baseline": cpu,
             "extra": extra,

@@ -107,9 +107,23 @@ int pseg_predict_device(pseg_engine* e, const uint8_t* d_img, int H, int W, floa
  * one behind the other (either may be NULL).  bf16 fcn / fcn_skip engines keep a page slot per page in every activation
  * tensor and give the low-resolution layers all slots in one launch (a page alone leaves them a partly filled chip); any
  * other engine runs the pages one after the other.  Each map equals pseg_predict_device's for that page.  Asynchronous
- * on `stream`. */
+ * on `stream`.  The slots per unit (16, PSEG_BATCH_PAGES) are cut to what the device's free memory holds, and halved
+ * again when an allocation fails all the same (PSEG_ENOMEM only when a single slot does not fit). */
 int pseg_predict_pages_device(pseg_engine* e, const uint8_t* d_imgs, int n_pages, int H, int W, int64_t* d_labels,
                               uint8_t* d_labels_u8, void* stream);
+
+/* Device-side error record of the engine -- the asynchronous `_device` entries cannot report what a kernel finds while it
+ * runs.  Waits for `stream` (NULL: the engine's own), then reports AND clears: PSEG_OK, or PSEG_EHIP when one of the bounded
+ * counter waits of the streamed-weights kernel (conv_sp_kernel: the 1/8-resolution layers of every page) gave up since the last
+ * report -- the label maps produced since then are not valid (lib/network.py:256-259 has no such state: predict_on_batch either
+ * returns the map or raises).  Every host-synchronous entry (pseg_predict, _batch, _chain, _exact_labels) runs the same check
+ * before it returns; callers of pseg_predict_device / pseg_predict_pages_device call this where they synchronise. */
+int pseg_engine_status(pseg_engine* e, void* stream);
+
+/* Frees the activation tensors (all page slots) of the engine; the next predict call allocates what its page needs.  An
+ * engine grows to the largest canvas x page-slot count it has seen (16 slots at 2048x1536: 14 GB) and keeps that; this is the
+ * way back (tf.keras.backend.clear_session in lib/trainer.py:112 is the reference's).  Waits for the device. */
+int pseg_engine_trim(pseg_engine* e);
 
 /* Predictor.predict (lib/predictor.py:27-30): label maps of a list of pages of individual sizes.
  * The upload of page i+1 and the download of page i-1 overlap the compute of page i (two staging

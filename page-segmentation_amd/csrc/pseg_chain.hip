@@ -132,7 +132,6 @@ extern "C" int pseg_predict_chain(pseg_engine* h, const uint8_t* img, int H, int
         for (int k = 0; k < 4; ++k)
             if (hm[k]) PSEG_HIP(hipMemcpyAsync(hm[k], dm[k], nl * 3, hipMemcpyDeviceToHost, st));
     }
-    PSEG_HIP(hipStreamSynchronize(st));
     PSEG_HIP(hipStreamSynchronize(c.s_aux));
-    return PSEG_OK;
+    return engine_status(e, st);
 }

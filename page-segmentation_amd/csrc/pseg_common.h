@@ -216,6 +216,8 @@ struct Engine {
     int relaxed_f32 = 0;     // != 0 during a train / eval step: wide float32 layers may run channel-blocked on the matrix cores
     uint32_t drop_key = 0;   // != 0 while a TRAINING forward runs: Dropout layers are live (key = seed / step mix)
     const float* cur_img_f32 = nullptr;   // float32 exact mode: float page (0..255 scale) instead of the uint8 one (augmented training samples)
+    int* d_sp_err = nullptr;   // bf16 mode: the give-up record of conv_sp_kernel's bounded counter waits (8 ints: code, wave, need, have,
+    int* h_sp_err = nullptr;   //   need2, have2, workgroup, op index), zero while all is well; h_: its pinned read-back slot (engine_status)
     // timing
     bool timing = false;
     std::vector<TimingSlot> slots;
@@ -295,6 +297,10 @@ void exact_free(Engine& e);
 void chain_free(Engine& e);
 void dist_free(Engine& e);                      // RCCL communicator (pseg_dist.hip)                     // Predictor chain buffers (pseg_chain.hip)                     // label-exact mode state (pseg_exactlabels.hip)
 int set_canvas(Engine& e, int H, int W, hipStream_t st, int pages = 1);
+// Waits for `st`, then reports -- and clears -- the engine's device-side error record: PSEG_EHIP when a counter wait of
+// conv_sp_kernel gave up since the last report (the label maps produced since then are not to be trusted).  Called by every
+// entry that synchronises with the host anyway and by pseg_engine_status (for the callers of the asynchronous _device entries).
+int engine_status(Engine& e, hipStream_t st);
 bool mfma_op_batchable(const Engine& e, const Op& op);      // the op's kernel takes several page slots in one launch
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs, int64_t* d_labels,
               uint8_t* d_labels_u8, hipStream_t st);

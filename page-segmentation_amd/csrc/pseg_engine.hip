@@ -558,23 +558,36 @@ int set_canvas(Engine& e, int H, int W, hipStream_t st, int pages) {
                                            "predict it in tiles or use the float32 mode", H, W);
     }
     PSEG_HIP(hipDeviceSynchronize());
-    e.Hp = Hp;
-    e.Wp = Wp;
-    e.pages = pages;
+    // The new canvas is committed only when every tensor has its buffer: a failed allocation leaves the engine with NO canvas
+    // (Hp = Wp = 0, one slot, every pointer null or valid for its recorded size), so the next call allocates again instead of
+    // returning early on the "same shape" test and running kernels on freed or undersized buffers.
+    e.Hp = e.Wp = 0;
+    e.pages = 1;
     for (auto& t : e.tensors) {
-        t.page_bytes = (size_t)e.tH(t) * e.tW(t) * t.Cs * esz;
-        const size_t bytes = t.page_bytes * pages;
+        const size_t pb = (size_t)(Hp >> t.s) * (Wp >> t.s) * t.Cs * esz;
+        const size_t bytes = pb * pages;
         if (bytes > t.bytes) {
             free_dev(t.base);
+            t.d = nullptr;
             t.bytes = 0;
-            PSEG_HIP(hipMalloc(&t.base, bytes));
+            const hipError_t er = hipMalloc(&t.base, bytes);
+            if (er != hipSuccess) {
+                (void)hipGetLastError();
+                t.base = nullptr;
+                return fail(er == hipErrorOutOfMemory ? PSEG_ENOMEM : PSEG_EHIP, "canvas %dx%d x %d page slot(s): hipMalloc of %zu bytes for tensor '%s' failed: %s",
+                            Hp, Wp, pages, bytes, t.name.c_str(), hipGetErrorString(er));
+            }
             t.bytes = bytes;
         }
+        t.page_bytes = pb;
         t.d = t.base;
         // float32 mode: fresh buffers start at zero; bf16 mode: the pad channels no kernel writes must read as
         // zero after every layout change
         if (t.d && bytes) PSEG_HIP(hipMemsetAsync(t.d, 0, bytes, st));
     }
+    e.Hp = Hp;
+    e.Wp = Wp;
+    e.pages = pages;
     const double px = (double)Hp * Wp;
     for (auto& op : e.ops) e.slots[op.timing_slot].flops = op.flops_per_canvas_px * px;
     // a launch that also runs a fused-away layer (conv1 inside conv2, logits inside the tail) does that layer's work too
@@ -599,6 +612,39 @@ __global__ void dropout_kernel(float* x, size_t n, uint32_t key, uint32_t thresh
 void launch_dropout(float* x, size_t n, uint32_t key, float rate, hipStream_t st) {
     const uint32_t thresh = (uint32_t)(rate * 16777216.0f);
     dropout_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(x, n, key, thresh, 1.0f / (1.0f - rate));
+}
+
+int engine_status(Engine& e, hipStream_t st) {
+    if (!e.d_sp_err) {                    // (float32 engines, graphs without a conv_sp_kernel layer)
+        PSEG_HIP(hipStreamSynchronize(st));
+        return PSEG_OK;
+    }
+    PSEG_HIP(hipMemcpyAsync(e.h_sp_err, e.d_sp_err, 32, hipMemcpyDeviceToHost, st));
+    PSEG_HIP(hipStreamSynchronize(st));
+    if (e.h_sp_err[0] == 0) return PSEG_OK;
+    int r[8];
+    memcpy(r, e.h_sp_err, 32);
+    PSEG_HIP(hipMemsetAsync(e.d_sp_err, 0, 32, st));          // reported once: the next call starts clean
+    PSEG_HIP(hipStreamSynchronize(st));
+    const char* layer = r[7] >= 0 && r[7] < (int)e.ops.size() ? e.ops[r[7]].layer.c_str() : "?";
+    return fail(PSEG_EHIP, "conv_sp_kernel (%s): a counter wait gave up -- the results since the last status check are not valid "
+                           "(code %d: 1 tile loader, 2 weight loader, 3 compute; wave %d of workgroup %d needed %d had %d / needed %d had %d)",
+                layer, r[0], r[1], r[6], r[2], r[3], r[4], r[5]);
+}
+
+// Page slots that fit the device: `want` slots of this canvas, halved until the activation tensors of the unit (what the engine
+// already holds counts as free) leave a fifth of the free memory untouched.  >= 1 (one slot is what a single page needs anyway).
+static int fit_page_slots(Engine& e, int H, int W, int want) {
+    if (want <= 1) return 1;
+    const int Hp = round_up(H, 32), Wp = round_up(W, 32);
+    const size_t esz = e.mode == PSEG_MODE_BF16 ? 2 : 4;
+    size_t per_slot = (size_t)Hp * Wp * 16, held = 0;          // (skip logits: 16 B/px per slot)
+    for (auto& t : e.tensors) { per_slot += (size_t)(Hp >> t.s) * (Wp >> t.s) * t.Cs * esz; held += t.bytes; }
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return want; }
+    const double room = 0.8 * ((double)fr + (double)held);
+    while (want > 1 && (double)per_slot * want > room) want = (want + 1) / 2;
+    return want;
 }
 
 int run_exact(Engine& e, const uint8_t* d_img, float* d_logits, float* d_probs,
@@ -1024,6 +1070,12 @@ static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int
     // upload and its last download with nothing beside them (8 pages as one unit: 0.70 ms per page against 0.49 page by page)
     cap = std::min(cap, std::max(1, n / 4));
     if (!pages_capable(e)) cap = 1;
+    if (cap > 1) {                          // ... and by what the device has room for (the largest page of the list decides)
+        int hm = 0, wm = 0;
+        for (int i = 0; i < n; ++i)
+            if ((size_t)H[i] * W[i] > (size_t)hm * wm) { hm = H[i]; wm = W[i]; }
+        cap = fit_page_slots(e, hm, wm, cap);
+    }
     std::vector<int> ub, ug;                 // first page, page count of every unit
     for (int i = 0; i < n;) {
         int g = 1;
@@ -1097,6 +1149,9 @@ static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int
         }
         return PSEG_OK;
     };
+    // every way out -- also an error return in the middle -- ends with the three streams drained: copies from / to the caller's
+    // host arrays and the ring slots must not be in flight when the caller gets its buffers back
+    struct Drain { hipStream_t a, b, c; ~Drain() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(c); } } drain{b->s_in, e.stream, b->s_out};
     // a reallocation of a slot must not race with work still using it: size every slot for the largest unit up front
     size_t max_in = 0, max_out = 0;
     for (int u = 0; u < nu; ++u) { max_in = std::max(max_in, upx(u) * e.in_ch * ug[u]); max_out = std::max(max_out, unit_out_bytes(u)); }
@@ -1120,8 +1175,7 @@ static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int
     }
     if (nu > 0) PSEG_TRY(finish(nu - 1));
     PSEG_HIP(hipStreamSynchronize(b->s_out));
-    PSEG_HIP(hipStreamSynchronize(e.stream));
-    return PSEG_OK;
+    return engine_status(e, e.stream);     // (waits for the stream; a give-up of conv_sp_kernel in any unit is an error here)
 }
 
 }  // namespace pseg
@@ -1230,6 +1284,8 @@ int pseg_destroy(pseg_engine* h) {
         mfma_free_op(op);
     }
     free_dev((void*&)e.d_lut);
+    free_dev((void*&)e.d_sp_err);
+    if (e.h_sp_err) { (void)hipHostFree(e.h_sp_err); e.h_sp_err = nullptr; }
     free_dev((void*&)e.d_logits_tmp);
     free_dev((void*&)e.d_img_stage);
     free_dev((void*&)e.d_lab_stage);
@@ -1314,10 +1370,16 @@ int pseg_predict_pages_device(pseg_engine* h, const uint8_t* d_imgs, int n, int 
     if (n > 1 && pages_capable(e)) {
         int cap = 16;                         // page slots per unit of a device-resident batch (14 GB of activations at 2048x1536; 8 and 16 measure alike)
         if (const char* ev = PSEG_KNOB("PSEG_BATCH_PAGES")) cap = std::max(1, std::min(64, atoi(ev)));
-        for (int i = 0; i < n; i += cap) {
+        cap = fit_page_slots(e, H, W, std::min(cap, n));
+        for (int i = 0; i < n;) {
             const int g = std::min(cap, n - i);
-            PSEG_TRY(predict_device_pages(e, d_imgs + (size_t)i * npx * e.in_ch, g, H, W, d_labels ? d_labels + (size_t)i * npx : nullptr,
-                                          d_labels_u8 ? d_labels_u8 + (size_t)i * npx : nullptr, st));
+            const int rc = g > 1 ? predict_device_pages(e, d_imgs + (size_t)i * npx * e.in_ch, g, H, W, d_labels ? d_labels + (size_t)i * npx : nullptr,
+                                                        d_labels_u8 ? d_labels_u8 + (size_t)i * npx : nullptr, st)
+                                 : predict_device(e, d_imgs + (size_t)i * npx * e.in_ch, H, W, nullptr, nullptr, d_labels ? d_labels + (size_t)i * npx : nullptr,
+                                                  d_labels_u8 ? d_labels_u8 + (size_t)i * npx : nullptr, st, nullptr);
+            if (rc == PSEG_ENOMEM && cap > 1) { cap = (cap + 1) / 2; continue; }     // (set_canvas left the engine without a canvas: half the slots)
+            PSEG_TRY(rc);
+            i += g;
         }
         return PSEG_OK;
     }
@@ -1346,7 +1408,25 @@ int pseg_predict(pseg_engine* h, const uint8_t* img, int H, int W, float* logits
     if (logits) PSEG_HIP(hipMemcpyAsync(logits, e.d_logit_stage, npx * C * 4, hipMemcpyDeviceToHost, e.stream));
     if (probs) PSEG_HIP(hipMemcpyAsync(probs, e.d_prob_stage, npx * C * 4, hipMemcpyDeviceToHost, e.stream));
     if (labels) PSEG_HIP(hipMemcpyAsync(labels, e.d_lab_stage, npx * 8, hipMemcpyDeviceToHost, e.stream));
-    PSEG_HIP(hipStreamSynchronize(e.stream));
+    return engine_status(e, e.stream);
+}
+
+int pseg_engine_status(pseg_engine* h, void* stream) {
+    if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    KnobScope knob_scope(h->e);
+    PSEG_HIP(hipSetDevice(h->e.device));
+    return engine_status(h->e, stream ? (hipStream_t)stream : h->e.stream);
+}
+
+int pseg_engine_trim(pseg_engine* h) {
+    if (!h) return fail(PSEG_EINVAL, "NULL engine");
+    Engine& e = h->e;
+    PSEG_HIP(hipSetDevice(e.device));
+    PSEG_HIP(hipDeviceSynchronize());
+    for (auto& t : e.tensors) { free_dev(t.base); t.d = nullptr; t.bytes = 0; t.page_bytes = 0; }
+    e.Hp = e.Wp = 0;
+    e.pages = 1;
+    free_dev((void*&)e.d_logits_tmp); e.logits_tmp_bytes = 0;
     return PSEG_OK;
 }
 

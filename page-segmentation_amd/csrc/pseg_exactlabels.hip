@@ -460,8 +460,7 @@ int pseg_predict_exact_labels(pseg_engine* h, const uint8_t* img, int H, int W, 
     PSEG_TRY(exact_labels(e, d_img, H, W, d_u8, d_i64, nullptr, e.stream));
     if (labels_u8) PSEG_HIP(hipMemcpyAsync(labels_u8, d_u8, npx, hipMemcpyDeviceToHost, e.stream));
     if (labels) PSEG_HIP(hipMemcpyAsync(labels, d_i64, npx * 8, hipMemcpyDeviceToHost, e.stream));
-    PSEG_HIP(hipStreamSynchronize(e.stream));
-    return PSEG_OK;
+    return engine_status(e, e.stream);
 }
 
 int pseg_label_exact_stats(const pseg_engine* h, double out[8]) {

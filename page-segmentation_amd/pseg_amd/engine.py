@@ -16,7 +16,7 @@ FLAG_BATCHNORM = 1
 EXPORTED_SYMBOLS = (
     "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_create_ex", "pseg_create_plan", "pseg_env_knobs", "pseg_destroy",
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
-    "pseg_predict", "pseg_predict_device", "pseg_predict_pages_device", "pseg_rccl_abi_pinned", "pseg_predict_batch", "pseg_predict_chain", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
+    "pseg_predict", "pseg_predict_device", "pseg_predict_pages_device", "pseg_engine_status", "pseg_engine_trim", "pseg_rccl_abi_pinned", "pseg_predict_batch", "pseg_predict_chain", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
     "pseg_host_alloc", "pseg_host_free", "pseg_host_register", "pseg_host_unregister",
     "pseg_predict_margin_device", "pseg_predict_exact_labels_device", "pseg_predict_exact_labels", "pseg_label_exact_stats", "pseg_label_exact_stats_ex",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
@@ -71,6 +71,8 @@ def lib():
     L.pseg_predict.argtypes = [vp, vp, i, i, vp, vp, vp]
     L.pseg_predict_device.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp]
     L.pseg_predict_pages_device.argtypes = [vp, vp, i, i, i, vp, vp, vp]
+    L.pseg_engine_status.argtypes = [vp, vp]
+    L.pseg_engine_trim.argtypes = [vp]
     L.pseg_predict_batch.argtypes = [vp, i, vp, vp, vp, vp, vp]
     L.pseg_predict_chain.argtypes = [vp, vp, i, i, i, i, vp, c.POINTER(i), i, c.c_uint, vp, vp, vp, i, vp, vp, vp, vp]
     L.pseg_bbox_fill_device_u8.argtypes = [i, vp, vp, i, i, i, vp]
@@ -331,6 +333,15 @@ class Engine:
         """n_pages pages of one shape, contiguous on the device -> their label maps, contiguous (lib/predictor.py:27-30); asynchronous."""
         _check(lib().pseg_predict_pages_device(self._h, ctypes.c_void_p(d_imgs), int(n_pages), int(H), int(W), ctypes.c_void_p(d_labels or None),
                                                ctypes.c_void_p(d_labels_u8 or None), ctypes.c_void_p(stream or None)))
+
+    def status(self, stream=0):
+        """Waits for `stream` (0: the engine's own), then raises PsegError if a kernel reported an error since the last check
+        (pseg_engine_status): what the asynchronous *_device calls cannot tell their caller."""
+        _check(lib().pseg_engine_status(self._h, ctypes.c_void_p(stream or None)))
+
+    def trim(self):
+        """Frees the activation tensors (every page slot); the next predict call allocates what it needs (pseg_engine_trim)."""
+        _check(lib().pseg_engine_trim(self._h))
 
     def predict_margin_device(self, d_img, H, W, d_margin, d_labels_u8=0, stream=0):
         """As predict_device, plus the float32 (H,W) margin map: top-1 minus top-2 logit per pixel."""

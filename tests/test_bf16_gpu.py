@@ -517,3 +517,75 @@ def test_engines_keep_their_own_knob_snapshot(gpu, oracle_mod, monkeypatch):
     assert np.abs(zb - za).max() <= 2e-2 * max(1.0, float(np.abs(za).max()))
     a.close()
     b.close()
+
+
+_GIVE_UP_SCRIPT = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.join(os.environ["PSEG_ROOT"], "page-segmentation_amd"))
+import pseg_amd
+from pseg_amd import synth
+from pseg_amd.engine import PsegError
+assert "PSEG_SP_CHECK" not in os.environ
+img = synth.synth_page(9, 300, 420, 3)[0]
+e = pseg_amd.Engine("fcn_skip", 3, mode=pseg_amd.MODE_BF16)
+e.set_weights(synth.glorot_weights(e.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+good = e.predict(img, want_logits=False, want_probs=False)[2]
+out = {}
+os.environ["PSEG_SP_DBG"] = "8"            # diagnostic build: the weight loaders of conv_sp_kernel stop, every wait gives up after 64 polls
+for name, call in (("predict", lambda: e.predict(img, want_logits=False, want_probs=False)),
+                   ("predict_batch", lambda: e.predict_batch([img, img])),
+                   ("predict_chain", lambda: e.predict_chain(img))):
+    try:
+        call()
+        out[name] = "no error"
+    except PsegError as ex:
+        out[name] = str(ex)
+# an asynchronous entry cannot tell: pseg_engine_status does, once
+import ctypes
+from pseg_amd.engine import lib
+L = lib()
+d_img, d_lab = ctypes.c_void_p(), ctypes.c_void_p()
+hip = ctypes.CDLL("libamdhip64.so")
+assert hip.hipMalloc(ctypes.byref(d_img), img.size) == 0 and hip.hipMalloc(ctypes.byref(d_lab), img.size) == 0
+assert hip.hipMemcpy(d_img, img.ctypes.data_as(ctypes.c_void_p), img.size, 1) == 0
+e.predict_device(d_img.value, 300, 420, d_labels_u8=d_lab.value)
+try:
+    e.status()
+    out["status"] = "no error"
+except PsegError as ex:
+    out["status"] = str(ex)
+try:
+    e.status()
+    out["status_again"] = "no error"
+except PsegError as ex:
+    out["status_again"] = str(ex)
+del os.environ["PSEG_SP_DBG"]
+again = e.predict(img, want_logits=False, want_probs=False)[2]     # the record was cleared by the report: the engine works again
+out["recovered"] = bool(np.array_equal(good, again))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_bf16_streamed_weights_kernel_give_up_is_an_error_in_the_default_path(gpu):
+    """A counter wait of conv_sp_kernel that gives up (bounded polling: a protocol bug must not hang the GPU) leaves a record in
+    device memory; EVERY host-synchronous entry reads it before returning and fails with PSEG_EHIP -- without PSEG_SP_CHECK, which
+    only adds a check after each launch -- and pseg_engine_status reports it for the asynchronous entries, once (report = clear).
+    The give-up is forced in the diagnostic build (libpseg_diag.so, PSEG_SP_DBG=8: the weight loaders stop after their first
+    groups); the release library does not contain the switch."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "page-segmentation_amd", "csrc", "libpseg_diag.so")
+    assert os.path.exists(diag), "libpseg_diag.so is not built (__graft_entry__.build() builds it)"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PSEG_")}
+    env.update({"PSEG_LIB": diag, "PSEG_ROOT": root})
+    r = subprocess.run([sys.executable, "-c", _GIVE_UP_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for name in ("predict", "predict_batch", "predict_chain", "status"):
+        assert "a counter wait gave up" in out[name] and "conv2d" in out[name], (name, out[name])
+    assert out["status_again"] == "no error"
+    assert out["recovered"] is True

@@ -365,10 +365,17 @@ int pseg_affine_warp(int device, const float* src, int H, int W, const double m[
                      int order, float* dst);
 /* ... with the other fill mode the reference's AugmentationSettings name (lib/trainer.py:23-28 image_fill_mode / binary_fill_mode /
  * mask_fill_mode and *_cval -> keras-preprocessing apply_affine_transform(fill_mode, cval)): fill_mode 0 'nearest', 1 'constant'
- * (scipy mode='constant': cval where the source coordinate leaves [0, n - 1]; the spline prefilter runs on the unpadded plane).
- * 'reflect' / 'wrap' are not built. */
+ * (scipy mode='constant': cval where the source coordinate leaves [0, n - 1]; the spline prefilter runs on the unpadded plane),
+ * 2 'reflect' (d c b a | a b c d | d c b a; half-sample-symmetric prefilter), 3 'wrap' (scipy's legacy 'wrap': period n - 1,
+ * mirror prefilter) -- the four values keras-preprocessing accepts; semantics of scipy >= 1.6's map_coordinate. */
 int pseg_affine_warp_fill(int device, const float* src, int H, int W, const double m[4], const double off[2],
                           int order, int fill_mode, float cval, float* dst);
+/* AugmentationSettings.brightness_range (lib/trainer.py:21,33; removed from the binary / mask generators at :45,50): the image
+ * generator draws one factor per sample and keras-preprocessing 1.1.2 applies apply_brightness_shift(x, factor, scale=False) --
+ * through an 8-bit PIL image: planes outside [0, 255] are stretched to it first and mapped back afterwards, the gain is
+ * PIL's ImageEnhance.Brightness (truncating blend with black, clipped).  src / dst: float32 planes of n values (all channels of
+ * the sample: min / max are taken over the whole array), host pointers; dst may equal src. */
+int pseg_brightness_shift(int device, const float* src, int64_t n, float brightness, float* dst);
 
 /* ---- evaluation reductions ------------------------------------------------------------ */
 

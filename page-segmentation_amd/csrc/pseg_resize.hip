@@ -217,8 +217,10 @@ __global__ __launch_bounds__(256) void warp_pad_kernel(const float* src, int H, 
 }
 
 // one thread = one line (row: AXIS 1, column: AXIS 0) of the padded plane, in place
+// reflect = 0: mirror boundary (whole-sample symmetric: scipy's 'mirror', and what it uses for 'constant' and 'wrap');
+// reflect = 1: half-sample symmetric ('reflect': c[-1 - i] = c[i]) -- scipy >= 1.6 ni_splines.c _init_causal_reflect / _anticausal_reflect
 template <int AXIS>
-__global__ __launch_bounds__(64) void spline3_prefilter_kernel(double* c, int Hp, int Wp) {
+__global__ __launch_bounds__(64) void spline3_prefilter_kernel(double* c, int Hp, int Wp, int reflect = 0) {
     const int line = blockIdx.x * 64 + threadIdx.x;
     const int nlines = AXIS == 1 ? Hp : Wp, n = AXIS == 1 ? Wp : Hp;
     if (line >= nlines) return;
@@ -226,6 +228,30 @@ __global__ __launch_bounds__(64) void spline3_prefilter_kernel(double* c, int Hp
     const size_t st = AXIS == 1 ? 1 : (size_t)Wp;
     const double z = -0.2679491924311227;          // sqrt(3) - 2
     for (int i = 0; i < n; ++i) p[i * st] *= 6.0;   // gain (1 - z)(1 - 1/z)
+    if (reflect) {
+        // c+[0] = c[0] + z sum_{i >= 0} z^i c[i] over the half-sample-symmetric extension; exact closed form for short lines
+        const int hor = min(n, 28);
+        const double c0 = p[0];
+        double sum;
+        if (hor < n) {
+            double zi = 1.0;
+            sum = 0.0;
+            for (int i = 0; i < hor; ++i) { sum += zi * p[i * st]; zi *= z; }
+            sum *= z;
+        } else {
+            double zn = 1.0;
+            for (int i = 0; i < n; ++i) zn *= z;              // z^n
+            double zi = z;
+            sum = p[0] + zn * p[(size_t)(n - 1) * st];
+            for (int i = 1; i < n; ++i) { sum += zi * (p[i * st] + zn * p[(size_t)(n - 1 - i) * st]); zi *= z; }
+            sum *= z / (1.0 - zn * zn);
+        }
+        p[0] = sum + c0;
+        for (int i = 1; i < n; ++i) p[i * st] += z * p[(i - 1) * st];
+        p[(size_t)(n - 1) * st] *= z / (z - 1.0);
+        for (int i = n - 2; i >= 0; --i) p[i * st] = z * (p[(i + 1) * st] - p[i * st]);
+        return;
+    }
     // causal initialisation, mirror boundary: c+[0] = sum_k z^k c[k] (|z|^k < 1e-15 after 27 terms)
     {
         const int hor = min(n, 28);
@@ -250,23 +276,67 @@ __global__ __launch_bounds__(64) void spline3_prefilter_kernel(double* c, int Hp
     for (int i = n - 2; i >= 0; --i) p[i * st] = z * (p[(i + 1) * st] - p[i * st]);
 }
 
-// fill_mode 'constant' (scipy.ndimage mode='constant'): the plane is NOT padded, the prefilter runs on it with the same mirror
-// initialisation, a coordinate outside [0, n - 1] on either axis gives `cval`, taps past the edge read the mirrored coefficient
+// fill_mode 'constant' / 'reflect' / 'wrap' (scipy.ndimage >= 1.6 geometric transforms, ni_interpolation.c map_coordinate): the plane
+// is NOT padded; the prefilter runs on it with the boundary of the mode ('reflect': half-sample symmetric; 'constant' and 'wrap':
+// mirror -- scipy has no exact spline boundary for those two); the coordinate is mapped by the mode ('constant': outside [0, n - 1]
+// on either axis gives `cval`; 'reflect': d c b a | a b c d | d c b a; 'wrap': period n - 1, scipy's legacy 'wrap'), may stay a
+// fraction outside the plane, and the tap INDICES are mapped by the prefilter's boundary.
 __device__ __forceinline__ int warp_mirror(int i, int n) {
     if (n == 1) return 0;
     const int p = 2 * (n - 1);
     i = (i < 0 ? -i : i) % p;
     return i < n ? i : p - i;
 }
-template <int ORDER>
-__global__ __launch_bounds__(256) void affine_warp_const_kernel(const double* coef, const float* src, int H, int W, float* dst,
-                                                                double m00, double m01, double m10, double m11, double o0, double o1, float cval) {
+__device__ __forceinline__ int warp_reflect_idx(int i, int n) {       // ... -2 -> 1, -1 -> 0, n -> n - 1, n + 1 -> n - 2 ...
+    if (n == 1) return 0;
+    const int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+enum { WARP_CONST = 1, WARP_REFLECT = 2, WARP_WRAP = 3 };
+template <int MODE>
+__device__ __forceinline__ double warp_map_coord(double x, int n) {   // scipy map_coordinate, same operations in the same order
+    if (MODE == WARP_REFLECT) {
+        if (x < 0.0) {
+            if (n <= 1) return 0.0;
+            const double sz2 = 2.0 * n;
+            if (x < -sz2) x = sz2 * (double)(long long)(-x / sz2) + x;
+            x = x < -(double)n ? x + sz2 : -x - 1.0;
+        } else if (x > (double)(n - 1)) {
+            if (n <= 1) return 0.0;
+            const double sz2 = 2.0 * n;
+            x -= sz2 * (double)(long long)(x / sz2);
+            if (x >= (double)n) x = sz2 - x - 1.0;
+        }
+    } else if (MODE == WARP_WRAP) {
+        if (x < 0.0) {
+            if (n <= 1) return 0.0;
+            const double sz = n - 1;
+            x += sz * ((double)(long long)(-x / sz) + 1.0);
+        } else if (x > (double)(n - 1)) {
+            if (n <= 1) return 0.0;
+            const double sz = n - 1;
+            x -= sz * (double)(long long)(x / sz);
+        }
+    }
+    return x;
+}
+template <int ORDER, int MODE>
+__global__ __launch_bounds__(256) void affine_warp_mode_kernel(const double* coef, const float* src, int H, int W, float* dst,
+                                                               double m00, double m01, double m10, double m11, double o0, double o1, float cval) {
     const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
     if (c >= W) return;
-    const double y = m00 * (double)r + m01 * (double)c + o0, x = m10 * (double)r + m11 * (double)c + o1;
-    if (y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1)) { dst[(size_t)r * W + c] = cval; return; }
+    double y = m00 * (double)r + m01 * (double)c + o0, x = m10 * (double)r + m11 * (double)c + o1;
+    if (MODE == WARP_CONST) {
+        if (y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1)) { dst[(size_t)r * W + c] = cval; return; }
+    } else {
+        y = warp_map_coord<MODE>(y, H);
+        x = warp_map_coord<MODE>(x, W);
+    }
+    auto tap = [](int i, int n) { return MODE == WARP_REFLECT ? warp_reflect_idx(i, n) : warp_mirror(i, n); };
     if (ORDER == 0) {
-        dst[(size_t)r * W + c] = src[(size_t)(int)floor(y + 0.5) * W + (int)floor(x + 0.5)];
+        dst[(size_t)r * W + c] = src[(size_t)tap((int)floor(y + 0.5), H) * W + tap((int)floor(x + 0.5), W)];
         return;
     }
     const int y0 = (int)floor(y), x0 = (int)floor(x);
@@ -284,10 +354,10 @@ __global__ __launch_bounds__(256) void affine_warp_const_kernel(const double* co
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int yy = warp_mirror(y0 - 1 + i, H);
+        const int yy = tap(y0 - 1 + i, H);
         double row = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) row += wx[j] * coef[(size_t)yy * W + warp_mirror(x0 - 1 + j, W)];
+        for (int j = 0; j < 4; ++j) row += wx[j] * coef[(size_t)yy * W + tap(x0 - 1 + j, W)];
         acc += wy[i] * row;
     }
     dst[(size_t)r * W + c] = (float)acc;
@@ -530,7 +600,7 @@ int pseg_affine_warp_fill(int device, const float* src, int H, int W, const doub
                           int fill_mode, float cval, float* dst) {
     if (!src || !dst || !m || !off) return fail(PSEG_EINVAL, "NULL argument");
     if (order != 0 && order != 3) return fail(PSEG_EUNSUPPORTED, "interpolation order %d (0 and 3 are built)", order);
-    if (fill_mode != 0 && fill_mode != 1) return fail(PSEG_EUNSUPPORTED, "fill mode %d (0 'nearest' and 1 'constant' are built)", fill_mode);
+    if (fill_mode < 0 || fill_mode > 3) return fail(PSEG_EUNSUPPORTED, "fill mode %d (0 'nearest', 1 'constant', 2 'reflect', 3 'wrap')", fill_mode);
     PSEG_TRY(check_shape(H, W, H, W));
     PSEG_TRY(rz_set_dev(device));
     DevMem mem;
@@ -540,22 +610,80 @@ int pseg_affine_warp_fill(int device, const float* src, int H, int W, const doub
     PSEG_TRY(mem.alloc(&d_d, n));
     PSEG_HIP(hipMemcpy(d_s, src, n * 4, hipMemcpyHostToDevice));
     const dim3 grid(cdiv(W, 256), H);
-    if (order == 0) {
-        if (fill_mode == 1) affine_warp_const_kernel<0><<<grid, 256>>>(nullptr, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1], cval);
-        else affine_warp_kernel<0><<<grid, 256>>>(nullptr, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1]);
-    } else {
-        const int pad = fill_mode == 1 ? 0 : WARP_PAD;       // ('constant': scipy filters the plane itself)
+    double* d_c = nullptr;
+    if (order == 3) {
+        const int pad = fill_mode == 0 ? WARP_PAD : 0;       // (every mode but 'nearest': scipy filters the plane itself)
         const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-        double* d_c = nullptr;
         PSEG_TRY(mem.alloc(&d_c, (size_t)Hp * Wp));
         warp_pad_kernel<<<dim3(cdiv(Wp, 256), Hp), 256>>>(d_s, H, W, d_c, pad);
-        spline3_prefilter_kernel<0><<<cdiv(Wp, 64), 64>>>(d_c, Hp, Wp);     // axis 0 first, as scipy's spline_filter
-        spline3_prefilter_kernel<1><<<cdiv(Hp, 64), 64>>>(d_c, Hp, Wp);
-        if (fill_mode == 1) affine_warp_const_kernel<3><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1], cval);
-        else affine_warp_kernel<3><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1]);
+        spline3_prefilter_kernel<0><<<cdiv(Wp, 64), 64>>>(d_c, Hp, Wp, fill_mode == 2);     // axis 0 first, as scipy's spline_filter
+        spline3_prefilter_kernel<1><<<cdiv(Hp, 64), 64>>>(d_c, Hp, Wp, fill_mode == 2);
     }
+#define PSEG_WARP(ORD_)                                                                                                                  \
+    switch (fill_mode) {                                                                                                                 \
+        case 0: affine_warp_kernel<ORD_><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1]); break;             \
+        case 1: affine_warp_mode_kernel<ORD_, WARP_CONST><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1], cval); break;   \
+        case 2: affine_warp_mode_kernel<ORD_, WARP_REFLECT><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1], cval); break; \
+        default: affine_warp_mode_kernel<ORD_, WARP_WRAP><<<grid, 256>>>(d_c, d_s, H, W, d_d, m[0], m[1], m[2], m[3], off[0], off[1], cval); break;   \
+    }
+    if (order == 0) { PSEG_WARP(0) } else { PSEG_WARP(3) }
+#undef PSEG_WARP
     PSEG_HIP(hipGetLastError());
     PSEG_HIP(hipMemcpy(dst, d_d, n * 4, hipMemcpyDeviceToHost));
+    return PSEG_OK;
+}
+
+// keras-preprocessing 1.1.2 apply_brightness_shift(x, brightness, scale=False) on one image plane (lib/trainer.py:21,33: the
+// brightness_range of AugmentationSettings reaches the IMAGE generator only):
+//   lo, hi = min(x), max(x); local = lo < 0 or hi > 255
+//   u = uint8(local ? (x - lo) / (hi - lo) * 255 : x)                     array_to_img (float32 arithmetic, C cast = truncation)
+//   v = PIL ImageEnhance.Brightness: blend(black, u, b) = b in [0, 1] ? uint8(b * u) : clip(b * u, 0, 255) truncated   (float32)
+//   y = local ? v / 255 * (hi - lo) + lo : v                               img_to_array, float32
+__global__ __launch_bounds__(256) void brightness_minmax_kernel(const float* x, size_t n, unsigned* mm) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const float v = x[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if ((threadIdx.x & 63) == 0) {
+        // order-preserving map float -> unsigned so that atomicMin / atomicMax work on the bits
+        auto key = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+        atomicMin(&mm[0], key(lo));
+        atomicMax(&mm[1], key(hi));
+    }
+}
+__global__ __launch_bounds__(256) void brightness_apply_kernel(const float* x, float* y, size_t n, const unsigned* mm, float b) {
+    auto unkey = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); };
+    const float lo = unkey(mm[0]), hi = unkey(mm[1]);
+    const bool local = lo < 0.0f || hi > 255.0f;
+    const float span = hi - lo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = x[i];
+        if (local) { v = v - lo; if (span != 0.0f) v = v / span; v = v * 255.0f; }
+        const float u = (float)(unsigned char)(int)v;          // astype('uint8'): truncation (values are in range here)
+        const float t = b * u;
+        float w;
+        if (b >= 0.0f && b <= 1.0f) w = (float)(unsigned char)(int)t;
+        else w = t <= 0.0f ? 0.0f : (t >= 255.0f ? 255.0f : (float)(unsigned char)(int)t);
+        y[i] = local ? w / 255.0f * span + lo : w;
+    }
+}
+
+int pseg_brightness_shift(int device, const float* src, int64_t n, float brightness, float* dst) {
+    if (!src || !dst || n < 1) return fail(PSEG_EINVAL, "NULL argument / empty plane");
+    PSEG_TRY(rz_set_dev(device));
+    DevMem mem;
+    float *d_s = nullptr, *d_d = nullptr;
+    unsigned* d_mm = nullptr;
+    PSEG_TRY(mem.alloc(&d_s, (size_t)n));
+    PSEG_TRY(mem.alloc(&d_d, (size_t)n));
+    PSEG_TRY(mem.alloc(&d_mm, 2));
+    const unsigned init[2] = {0xffffffffu, 0u};
+    PSEG_HIP(hipMemcpy(d_mm, init, 8, hipMemcpyHostToDevice));
+    PSEG_HIP(hipMemcpy(d_s, src, (size_t)n * 4, hipMemcpyHostToDevice));
+    const int grid = (int)std::min<size_t>(((size_t)n + 255) / 256, 2048);
+    brightness_minmax_kernel<<<grid, 256>>>(d_s, (size_t)n, d_mm);
+    brightness_apply_kernel<<<grid, 256>>>(d_s, d_d, (size_t)n, d_mm, brightness);
+    PSEG_HIP(hipGetLastError());
+    PSEG_HIP(hipMemcpy(dst, d_d, (size_t)n * 4, hipMemcpyDeviceToHost));
     return PSEG_OK;
 }
 

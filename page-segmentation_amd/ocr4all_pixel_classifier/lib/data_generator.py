@@ -2,9 +2,11 @@
 ImageDataGenerator).  Only what the reference's augmentation uses is restated (lib/trainer.py:14-56,
 lib/network.py:109-125,149-161): rotation / shift / shear / zoom parameters drawn from NumPy's global
 RandomState in keras-preprocessing's order, horizontal / vertical flips, one affine warp per sample with
-`fill_mode='nearest'` (the reference default) or `'constant'` with `cval`; the warp itself runs on the GPU
-(pseg_affine_warp_fill: cubic B-spline for the image, nearest for binary and mask).  Brightness / channel shifts, the fill
-modes 'reflect' / 'wrap' and featurewise statistics raise.
+any of keras-preprocessing's four fill modes ('nearest' -- the reference default --, 'constant' with `cval`, 'reflect', 'wrap');
+the warp itself runs on the GPU (pseg_affine_warp_fill: cubic B-spline for the image, nearest for binary and mask), and so does
+the brightness shift of `brightness_range` (pseg_brightness_shift: one factor per sample, drawn after the flips; the reference
+hands the range to the IMAGE generator only, lib/trainer.py:40-50).  Channel shifts and featurewise statistics raise (no field
+of AugmentationSettings reaches them).
 keras-preprocessing and the scipy release it ran on are absent offline: parity unpinned (tests compare the
 warp with the installed scipy, the parameter stream with its published algorithm)."""
 import numpy as np
@@ -17,10 +19,15 @@ class ImageDataGeneratorCustom:
                  data_format='channels_last', validation_split=0.0, dtype='float32', interpolation_order=1, **unused):
         if data_format != 'channels_last':
             raise Exception("only data_format='channels_last' is built")
-        if fill_mode not in ('nearest', 'constant'):
-            raise Exception("fill_mode 'nearest' (the reference default) and 'constant' are built on the GPU, not %r" % (fill_mode,))
-        if brightness_range is not None or channel_shift_range:
-            raise Exception("brightness / channel shifts are not built (the reference default is None)")
+        if fill_mode not in ('nearest', 'constant', 'reflect', 'wrap'):
+            raise Exception("Unknown fill_mode %r (keras-preprocessing takes 'constant', 'nearest', 'reflect', 'wrap')" % (fill_mode,))
+        if channel_shift_range:
+            raise Exception("channel shifts are not built (no field of AugmentationSettings sets them)")
+        if brightness_range is not None:
+            # keras_preprocessing/image/image_data_generator.py: the same check, the same message
+            if not isinstance(brightness_range, (tuple, list)) or len(brightness_range) != 2:
+                raise ValueError('`brightness_range should be tuple or list of two floats. Received: %s' % (brightness_range,))
+        self.brightness_range = brightness_range
         if interpolation_order not in (0, 3):
             raise Exception("interpolation orders 0 (binary, mask) and 3 (image) are built")
         self.rotation_range = rotation_range
@@ -63,8 +70,13 @@ class ImageDataGeneratorCustom:
             zx, zy = np.random.uniform(self.zoom_range[0], self.zoom_range[1], 2)
         flip_horizontal = (np.random.random() < 0.5) * self.horizontal_flip
         flip_vertical = (np.random.random() < 0.5) * self.vertical_flip
+        # (channel_shift_range would draw here; it is 0)  brightness: the LAST draw -- generators without the range (binary,
+        # mask) see the same affine parameters under the shared seed
+        brightness = None
+        if self.brightness_range is not None:
+            brightness = np.random.uniform(self.brightness_range[0], self.brightness_range[1])
         return {'theta': theta, 'tx': tx, 'ty': ty, 'shear': shear, 'zx': zx, 'zy': zy,
-                'flip_horizontal': flip_horizontal, 'flip_vertical': flip_vertical}
+                'flip_horizontal': flip_horizontal, 'flip_vertical': flip_vertical, 'brightness': brightness}
 
     @staticmethod
     def affine_matrix(params, h, w):
@@ -105,7 +117,10 @@ class ImageDataGeneratorCustom:
             x = x[:, ::-1]
         if params.get('flip_vertical', False):
             x = x[::-1]
-        return np.ascontiguousarray(x)
+        x = np.ascontiguousarray(x)
+        if params.get('brightness') is not None:      # after the warp and the flips, as ImageDataGenerator.apply_transform orders them
+            x = _eng.brightness_shift(x, params['brightness'])
+        return x
 
     def random_transform(self, x, seed=None):
         return self.apply_transform(x, self.get_random_transform(x.shape, seed))

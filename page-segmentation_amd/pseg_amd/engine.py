@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "pseg_masks", "pseg_masks_device", "pseg_masks_device_u8", "pseg_bbox_fill_device_u8",
     "pseg_otsu_char_height",
     "pseg_rescale_shape", "pseg_gaussian_kernel", "pseg_resize_nearest", "pseg_resize_nearest_device", "pseg_scale_image",
-    "pseg_prepare_images", "pseg_affine_warp", "pseg_affine_warp_fill",
+    "pseg_prepare_images", "pseg_affine_warp", "pseg_affine_warp_fill", "pseg_brightness_shift",
     "pseg_eval_confusion", "pseg_cc_label", "pseg_cc_tables",
 )
 
@@ -121,6 +121,7 @@ def lib():
     L.pseg_prepare_images.argtypes = [i, vp, vp, i, i, i, i, vp, i, vp, i, i, i, vp, i, vp, i, vp, vp, vp, vp]
     L.pseg_affine_warp.argtypes = [i, vp, i, i, vp, vp, i, vp]
     L.pseg_affine_warp_fill.argtypes = [i, vp, i, i, vp, vp, i, i, ctypes.c_float, vp]
+    L.pseg_brightness_shift.argtypes = [i, vp, i64, ctypes.c_float, vp]
     L.pseg_cc_vote_device.argtypes = [i, vp, vp, i, i, i, vp]
     L.pseg_cc_vote_device_u8.argtypes = [i, vp, vp, i, i, i, vp]
     L.pseg_release_workspace.argtypes = [i]
@@ -691,14 +692,15 @@ def prepare_images(image, binary, scale, max_width=None, device=0, want_stage1=F
     return (o_img, o_bin, o_orig, st1) if want_stage1 else (o_img, o_bin, o_orig)
 
 
-FILL_MODES = {"nearest": 0, "constant": 1}
+FILL_MODES = {"nearest": 0, "constant": 1, "reflect": 2, "wrap": 3}
 
 
 def affine_warp(plane, matrix, offset, order, device=0, fill_mode="nearest", cval=0.0):
     """scipy.ndimage.affine_transform(plane, matrix, offset, order=order, mode=fill_mode, cval=cval) for a float32 (H,W)
-    plane, order 0 or 3, fill_mode 'nearest' or 'constant', on the GPU (the augmentation warp of lib/data_generator.py)."""
+    plane, order 0 or 3, fill_mode 'nearest', 'constant', 'reflect' or 'wrap' (the four keras-preprocessing accepts), on the GPU
+    (the augmentation warp of lib/data_generator.py)."""
     if fill_mode not in FILL_MODES:
-        raise PsegError("affine_warp: fill_mode %r is not built ('nearest' and 'constant' are)" % (fill_mode,))
+        raise PsegError("affine_warp: unknown fill_mode %r" % (fill_mode,))
     a = np.ascontiguousarray(plane, dtype=np.float32)
     if a.ndim != 2:
         raise PsegError("affine_warp takes one (H,W) plane")
@@ -707,6 +709,15 @@ def affine_warp(plane, matrix, offset, order, device=0, fill_mode="nearest", cva
     out = np.empty_like(a)
     _check(lib().pseg_affine_warp_fill(int(device), _ptr(a), a.shape[0], a.shape[1], _ptr(m), _ptr(o), int(order),
                                        FILL_MODES[fill_mode], float(cval), _ptr(out)))
+    return out
+
+
+def brightness_shift(x, brightness, device=0):
+    """keras-preprocessing 1.1.2 apply_brightness_shift(x, brightness, scale=False) on a float array (H,W[,C]) -> float32,
+    on the GPU (pseg_brightness_shift; lib/trainer.py:21 brightness_range)."""
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(a)
+    _check(lib().pseg_brightness_shift(int(device), _ptr(a), a.size, float(brightness), _ptr(out)))
     return out
 
 

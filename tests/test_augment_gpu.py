@@ -59,7 +59,7 @@ def test_affine_warp_constant_fill_matches_scipy(gpu, shape, order):
                 assert edge.mean() <= 0.01
                 assert np.abs(got - want)[~edge].max(initial=0.0) <= 2e-3 * 255
     with pytest.raises(E.PsegError):
-        E.affine_warp(x, np.eye(2), np.zeros(2), order, fill_mode="reflect")
+        E.affine_warp(x, np.eye(2), np.zeros(2), order, fill_mode="mirror")        # not a keras-preprocessing mode
     from ocr4all_pixel_classifier.lib.data_generator import ImageDataGeneratorCustom as G
     g = G(rotation_range=5, fill_mode="constant", cval=7.0, interpolation_order=order)
     img = np.stack([x, x[::-1]], -1)
@@ -68,7 +68,89 @@ def test_affine_warp_constant_fill_matches_scipy(gpu, shape, order):
     m, off = G.affine_matrix(p, shape[0], shape[1])
     assert np.array_equal(out[..., 1], E.affine_warp(np.ascontiguousarray(img[..., 1]), m, off, order, fill_mode="constant", cval=7.0))
     with pytest.raises(Exception):
-        G(fill_mode="wrap")
+        G(fill_mode="grid-wrap")
+
+
+@pytest.mark.parametrize("shape", [(64, 96), (33, 50), (7, 5), (1, 9), (200, 31)])
+@pytest.mark.parametrize("order", [0, 3])
+@pytest.mark.parametrize("mode", ["reflect", "wrap"])
+def test_affine_warp_reflect_and_wrap_fill_match_scipy(gpu, shape, order, mode):
+    """fill_mode 'reflect' / 'wrap' (the other two values lib/trainer.py:23-25's *_fill_mode fields may carry) against the
+    installed scipy.ndimage.affine_transform: coordinates mapped by the mode (reflect: half-sample symmetric; wrap: scipy's
+    period n - 1), the prefilter with the mode's boundary (reflect exact; wrap: mirror), tap indices mapped by the prefilter's
+    boundary.  Large shifts and rotations so that several periods are crossed."""
+    from pseg_amd import engine as E
+    rng = np.random.default_rng(shape[0] * 10 + order + (7 if mode == "wrap" else 3))
+    x = (rng.random(shape) * 255).astype(np.float32)
+    if order == 0:
+        x = np.round(x / 50)
+    for theta, tx, ty, zx, zy in [(2.5, 1.6, -2.4, 0.95, 1.05), (0.0, 3.0, 2.0, 1.0, 1.0), (40.0, 5.0, -7.0, 0.7, 1.4), (-170.0, 90.5, -140.25, 2.5, 0.4)]:
+        m, off = _params(shape[0], shape[1], theta, tx, ty, zx, zy)
+        got = E.affine_warp(x, m, off, order, fill_mode=mode)
+        want = A.affine_transform_mode(x, m, off, order, mode)
+        assert got.dtype == np.float32 and got.shape == want.shape
+        if order == 0:
+            assert (got != want).mean() <= 0.01                 # exact .5 coordinate ties / coordinates within rounding of a period's seam
+        else:
+            d = np.abs(got - want)
+            seam = d > 2e-3 * 255                               # a coordinate within float64 rounding of a seam lands on the other side
+            assert seam.mean() <= 0.01 and np.median(d) <= 1e-3
+    from ocr4all_pixel_classifier.lib.data_generator import ImageDataGeneratorCustom as G
+    from ocr4all_pixel_classifier.lib.trainer import AugmentationSettings
+    s = AugmentationSettings(image_fill_mode=mode, binary_fill_mode=mode, mask_fill_mode=mode)
+    g = G(**(s.to_image_params() if order == 3 else s.to_mask_params()), data_format='channels_last')
+    assert g.fill_mode == mode
+    p = {'theta': 5.0, 'tx': 2.0, 'ty': -1.0, 'shear': 0.0, 'zx': 0.9, 'zy': 1.1, 'flip_horizontal': False, 'flip_vertical': False}
+    out = g.apply_transform(x[..., None], p)
+    m, off = G.affine_matrix(p, shape[0], shape[1])
+    assert np.array_equal(out[..., 0], E.affine_warp(x, m, off, order, fill_mode=mode))
+
+
+@pytest.mark.parametrize("case", ["in_range", "overshoot", "negative", "flat", "rgb"])
+def test_brightness_shift_matches_the_pillow_restatement(gpu, case):
+    """AugmentationSettings.brightness_range (lib/trainer.py:21): pseg_brightness_shift against oracle.augment.apply_brightness_shift
+    (keras-preprocessing 1.1.2's apply_brightness_shift(x, b, scale=False) run through the installed Pillow), bit for bit:
+    planes inside [0, 255] (truncation to uint8, truncating blend), planes the cubic warp pushed outside it (stretch to 8 bit and
+    back), factors below and above one (the clipped extrapolation branch), a constant plane, three channels."""
+    from pseg_amd import engine as E
+    rng = np.random.default_rng(len(case))
+    H, W = 37, 53
+    x = {"in_range": lambda: rng.random((H, W, 1)) * 255, "overshoot": lambda: rng.random((H, W, 1)) * 280 - 10,
+         "negative": lambda: rng.random((H, W, 1)) * 200 - 60, "flat": lambda: np.full((H, W, 1), 93.7),
+         "rgb": lambda: rng.random((H, W, 3)) * 262 - 3}[case]().astype(np.float32)
+    for b in (0.0, 0.37, 0.8, 1.0, 1.2, 1.9, 3.5):
+        got = E.brightness_shift(x, b)
+        want = A.apply_brightness_shift(x, b)
+        assert got.dtype == np.float32 and got.shape == want.shape
+        assert np.array_equal(got, want), (case, b, float(np.abs(got - want).max()))
+
+
+def test_generator_brightness_range_reaches_the_image_only(gpu):
+    """The brightness draw is the last of get_random_transform: image, binary and mask generators (lib/network.py:149-153 share one
+    seed) still see the same affine parameters, and only the image generator has a 'brightness'; flow() applies it after warp
+    and flips."""
+    from ocr4all_pixel_classifier.lib.data_generator import ImageDataGeneratorCustom as G
+    from ocr4all_pixel_classifier.lib.trainer import AugmentationSettings
+    from pseg_amd import engine as E
+    s = AugmentationSettings(brightness_range=[0.6, 1.4], horizontal_flip=True)
+    gi, gm = G(**s.to_image_params(), data_format='channels_last'), G(**s.to_mask_params(), data_format='channels_last')
+    assert gi.brightness_range == [0.6, 1.4] and gm.brightness_range is None
+    pi, pm = gi.get_random_transform((64, 96, 1), seed=11), gm.get_random_transform((64, 96, 1), seed=11)
+    assert 0.6 <= pi['brightness'] <= 1.4 and pm['brightness'] is None
+    assert all(pi[k] == pm[k] for k in pm if k != 'brightness')
+    np.random.seed(11)
+    rs = np.random.RandomState(11)
+    for _ in range(3): rs.uniform(-1, 1)
+    rs.uniform(0.95, 1.05, 2); rs.random_sample(); rs.random_sample()
+    assert pi['brightness'] == rs.uniform(0.6, 1.4)                    # theta, tx, ty, (zx, zy), two flip draws, then brightness
+    x = (np.random.default_rng(2).random((1, 64, 96, 1)) * 255).astype(np.float32)
+    out = next(gi.flow(x, seed=5, batch_size=1))[0]
+    np.random.seed(5); np.random.permutation(1)
+    p = gi.get_random_transform((64, 96, 1))
+    no_b = dict(p, brightness=None)
+    assert np.array_equal(out, E.brightness_shift(gi.apply_transform(x[0], no_b), p['brightness']))
+    with pytest.raises(ValueError):
+        G(brightness_range=0.5)
 
 
 def test_generator_parameter_stream_and_flow(gpu):

@@ -519,6 +519,45 @@ def test_engines_keep_their_own_knob_snapshot(gpu, oracle_mod, monkeypatch):
     b.close()
 
 
+def test_plan_switch_in_the_environment_does_not_reach_a_product_engine(gpu, oracle_mod, monkeypatch):
+    """the property itself, on the product path.  PSEG_NO_SKIPLOG is a plan switch (not in pseg_env_knobs()): set
+    in the process environment it must NOT change an engine created through pseg_create / pseg_create_ex / an empty plan -- its
+    conv2 tensor stays fused away (skip-logits fusion) -- while the same switch passed as a plan does materialise the tensor;
+    a LISTED knob (PSEG_NO_WS) in the environment does reach the engine (it still computes the same labels)."""
+    import ctypes
+    from pseg_amd import engine as E
+    Wt = oracle_mod.init_weights("fcn_skip", 3, seed=5, gain=1.5, bias_scale=0.05)
+    img = np.random.default_rng(6).integers(0, 256, size=(96, 160), dtype=np.uint8)
+    assert "PSEG_NO_SKIPLOG" not in E.lib().pseg_env_knobs().decode().split("\n")
+    monkeypatch.setenv("PSEG_NO_SKIPLOG", "1")
+    a = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16, plan="")                  # product path: pseg_create_plan(..., "") = pseg_create_ex
+    a.set_weights(Wt)
+    la = a.predict(img, want_logits=False, want_probs=False)[2]
+    with pytest.raises(gpu.PsegError):
+        a.activation("conv2d_1")                                                # still fused: the environment did not reach the plan
+    # ... and through the bare C entry
+    h = ctypes.c_void_p()
+    E._check(E.lib().pseg_create(E.ARCH_IDS["fcn_skip"], 3, 1, 0, gpu.MODE_BF16, ctypes.byref(h)))
+    c = gpu.Engine.__new__(gpu.Engine)
+    c._h, c.arch, c.n_classes, c.in_channels, c.device, c.mode, c.batch_norm = h, "fcn_skip", 3, 1, 0, gpu.MODE_BF16, False
+    c.set_weights(Wt)
+    lc = c.predict(img, want_logits=False, want_probs=False)[2]
+    with pytest.raises(gpu.PsegError):
+        c.activation("conv2d_1")
+    b = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16, plan={"PSEG_NO_SKIPLOG": "1"})
+    b.set_weights(Wt)
+    b.predict(img, want_logits=False, want_probs=False)
+    assert b.activation("conv2d_1").shape[-1] == 30                             # the plan switch does what the environment could not
+    monkeypatch.delenv("PSEG_NO_SKIPLOG")
+    monkeypatch.setenv("PSEG_NO_WS", "1")                                       # a listed knob: read from the environment at creation
+    d = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16, plan="")
+    d.set_weights(Wt)
+    ld = d.predict(img, want_logits=False, want_probs=False)[2]
+    assert np.array_equal(la, lc) and np.array_equal(la, ld)
+    for e in (a, b, c, d):
+        e.close()
+
+
 _GIVE_UP_SCRIPT = r"""
 import os, sys, json
 import numpy as np

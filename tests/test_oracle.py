@@ -246,3 +246,33 @@ def test_conv_chain_is_blocked_in_slabs_of_16_channels(oracle_mod):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (Cin, Cout, k)
         if Cin > 16:
             assert not np.array_equal(chain(plain).view(np.uint32), want.view(np.uint32)), "the two orders agree everywhere: the case does not discriminate"
+
+
+def test_brightness_shift_oracle_is_the_published_arithmetic():
+    """oracle.augment.apply_brightness_shift runs keras-preprocessing 1.1.2's apply_brightness_shift(x, b, scale=False) through the
+    installed Pillow; here against the closed form of the same steps (array_to_img's truncation to uint8, ImagingBlend with a black
+    image: truncating interpolation for b in [0, 1], clipped truncating extrapolation otherwise, the stretch to 8 bit and back for
+    planes outside [0, 255]) -- the form csrc/pseg_resize.hip's kernel follows."""
+    from oracle import augment as A
+
+    def closed_form(x, b):
+        x = np.asarray(x, np.float32)
+        lo, hi = np.min(x), np.max(x)
+        local = lo < 0 or hi > 255
+        y = x.copy()
+        if local:
+            y = y - lo
+            m = np.max(y)
+            if m != 0:
+                y /= m
+            y *= np.float32(255)
+        u = y.astype('uint8').astype(np.float32)
+        t = np.float32(b) * u
+        w = np.where(t <= 0, 0, np.where(t >= 255, 255, np.floor(t))).astype(np.float32)
+        return (w / np.float32(255) * (hi - lo) + lo).astype(np.float32) if local else w
+
+    rng = np.random.default_rng(0)
+    for scale, shift in ((255, 0), (280, 10), (200, 60), (1, -93), (262, 3)):
+        x = (rng.random((31, 41, 1)) * scale - shift).astype(np.float32)
+        for b in (0.0, 0.37, 0.8, 1.0, 1.2, 1.9, 3.5):
+            assert np.array_equal(A.apply_brightness_shift(x, b), closed_form(x, b)), (scale, shift, b)

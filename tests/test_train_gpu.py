@@ -321,3 +321,67 @@ def test_c_abi_allreduce_single_rank(gpu, oracle_mod):
         engines[1].train_allreduce()
     for e in engines:
         e.close()
+
+
+_RCCL_RANK_SCRIPT = r"""
+import os, sys
+import numpy as np
+root = os.environ["PSEG_ROOT"]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "page-segmentation_amd"))
+import pseg_amd
+from pseg_amd import synth
+rank, world = int(os.environ["PSEG_T_RANK"]), int(os.environ["PSEG_T_WORLD"])
+uid = bytes.fromhex(os.environ["PSEG_T_UID"])
+e = pseg_amd.Engine("fcn_skip", 3, device=rank, mode=pseg_amd.MODE_F32_EXACT)
+e.set_weights(synth.glorot_weights(e.weight_specs(), seed=3, gain=1.0, bias_scale=0.02))
+e.train_init(clipnorm=1.0)
+img, _, mask = synth.synth_page(10 + rank, 96, 128, 3)        # a different page per rank (SURVEY 8e: DP over pages)
+e.allreduce_init(rank, world, uid)                              # collective: every rank
+e.train_forward_backward(img, mask)
+own = e.gradients()
+e.train_allreduce()                                             # in place, on the engine's stream
+summed = e.gradients()
+np.savez(os.path.join(os.environ["PSEG_T_OUT"], "rank%d.npz" % rank), **{"own/" + k: v for k, v in own.items()}, **{"sum/" + k: v for k, v in summed.items()})
+e.allreduce_destroy()
+e.close()
+"""
+
+
+def test_c_abi_allreduce_two_devices(gpu, tmp_path):
+    """The C-ABI data-parallel exchange on REAL ranks: two fresh processes, one per device, pseg_allreduce_unique_id (here) ->
+    pseg_allreduce_init -> pseg_train_forward_backward on a page of their own -> pseg_train_allreduce; every rank's gradient
+    buffer then holds the sum of the two per-page gradients, bit for bit (a two-rank float sum is order-free) -- the averaged
+    batch gradient of SURVEY 8e once pseg_train_apply scales by 1/world.  Needs two visible devices: skipped, with the reason,
+    on the one-GPU box (pseg_allreduce_init with world = 1 is test_c_abi_allreduce_single_rank)."""
+    import os
+    import subprocess
+    import sys
+    ndev = gpu.device_count()
+    if ndev < 2:
+        pytest.skip("pseg_device_count() = %d: the two-rank RCCL path of the C ABI needs two devices" % ndev)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    uid = gpu.Engine.allreduce_unique_id()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ)
+        env.update({"PSEG_ROOT": root, "PSEG_T_RANK": str(r), "PSEG_T_WORLD": "2", "PSEG_T_UID": uid.hex(), "PSEG_T_OUT": str(tmp_path),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, "-c", _RCCL_RANK_SCRIPT], env=env, stderr=subprocess.PIPE, text=True))
+    errs = []
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        errs.append(err)
+    assert all(p.returncode == 0 for p in procs), [e[-1500:] for e in errs]
+    ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(2)]
+    names = [k[4:] for k in ranks[0].files if k.startswith("own/")]
+    assert names
+    for k in names:
+        want = ranks[0]["own/" + k] + ranks[1]["own/" + k]
+        assert np.abs(want).max() > 0 or k.endswith("bias")
+        for r in range(2):
+            assert np.array_equal(ranks[r]["sum/" + k], want), (k, r)

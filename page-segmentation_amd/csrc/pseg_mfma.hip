@@ -2924,6 +2924,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 asm volatile("" ::: "memory");
                 const int d0 = flags[4], d1 = flags[5], d2 = flags[6], d3 = flags[7];
                 if (__builtin_amdgcn_readfirstlane(min(min(d0, d1), min(d2, d3))) >= need) break;
+                // the ring is full: what has been issued lands while this wave waits -- publish it now, not `lag` groups behind the next issue
+                if (pub < q) { sp_wait_vmcnt<0>(); pub = q; if (lane == 0) flags[lw] = pub; }
                 if (it >= spin_limit) { give_up(2, need, min(min(d0, d1), min(d2, d3)), q); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -3214,6 +3216,473 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef SP_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_sp2_kernel: conv_sp_kernel with TWO compute teams (two compute waves per SIMD) on one weight stream.
+// Why: one compute wave per SIMD issues its MT + NT fragment reads, the counter look-ups and the MFMAs of a k-step from a single
+// in-order stream -- 28-30 cycles per MFMA measured in conv_sp_kernel's k-loop against 16.7 for the MFMAs alone (tools/sp_trace.py;
+// tools/microtests/kloop.hip: 22-25 for the bare loop, 18 with a second wave on the SIMD whose MFMAs fill the first one's read
+// issue).  Splitting a tile's pixels or output channels over two waves raises the fragment reads per MFMA (built and removed in
+// round 4: the LDS array was the limit); splitting K changes the summation order.  So the second team takes ANOTHER TILE:
+//   * waves 0-3 = team 0, waves 4-7 = team 1 (one wave of each per SIMD); tile pair p of the workgroup = tiles 2p (team 0) and
+//     2p + 1 (team 1); each wave keeps conv_sp_kernel's two rows x TWK pixels x NT cout tiles, k order, start value: the same bits;
+//   * ONE weight ring feeds both teams: a ring group is free once all eight compute waves are past it, so the teams stay within a
+//     ring's depth of each other (they read the same weight fragments at about the same time -- per pixel the weight stream from
+//     L2 and its LDS-DMA writes are halved);
+//   * the halo tiles go through a pool of FOUR block slots (one channel block each): the blocks of a pair are loaded in the order
+//     (block 0, team 0), (block 0, team 1), (block 1, team 0) ... -- index jb, slot jb % 4 -- so each team has its current block
+//     and the next one resident; a slot is free once the four waves of ITS team are past that block (tdone counts a team's own blocks);
+//   * waves 8-9 stream the weights, waves 10-11 stage the blocks (two block loads in flight, published behind counted vmcnt waits);
+//   * the epilogue goes through a 16-pixel LDS patch of the wave (whole 128-byte lines per store instruction), one pixel tile at a time.
+// A launch with an odd tile count gives the last pair's team 1 a virtual tile: zero-filled loads, no stores.
+// Counter words (ints at lds_flag_off): [0,1] ready  [2,3] tready  [4..11] done  [12..19] tdone.
+// ---------------------------------------------------------------------------------------------
+constexpr int SP2_NSLOT = 4;
+// Bank conflicts of the pixel fragment reads.  A ds_read_b128 is served in four groups of sixteen lanes (MI355X_MICROARCH.md, LDS); with a
+// pixel pitch of four slots (64 bytes: the dense block of a 32-channel slab) and lane group g reading chunk g, lanes p and p + 4 of a
+// group fall on the same banks: every pixel fragment read takes the LDS array 8 cycles instead of 4 (tools/lds_conflicts.py; the same
+// for pitches of 3, 5 and 7 slots, not for 6 -- conv_mfma_kernel's choice, which costs half as many slots again).  Here a four-chunk block
+// keeps its dense pitch and is stored SWIZZLED: chunk c of the pixel at halo column x sits in slot c ^ 2 ((x >> 2) & 1) of that pixel -- the
+// tile loaders permute the SOURCE chunk of each LDS-DMA lane (the destination stays linear), and the k-chunk table gives every lane
+// the offset for ITS column parity: [k-step][lane group g][p & 7] instead of [k-step][g] (the parity of column p + kx is that of (p & 7) +
+// kx: sixteen columns further on it repeats).  Conflict-free by the bank model for every tile alignment.  Five-chunk blocks (conv5)
+// keep the pair order the host's bank model picks at their own pitch.
+template <int NT, int SG, int FL, int TWK>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_sp2_kernel(SConv a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(TWK == 32 || TWK == 24, "tile rows of two or one and a half 16-pixel MFMA tiles");
+    static_assert((FL & SP_DQ) == 0, "the fused transposed conv stays with conv_sp_kernel");
+    constexpr int TW = TWK;
+    constexpr int MT = TWK == 32 ? 4 : 3, TH = 8, KS = 5, THH = TH + KS - 1, TWH = TW + KS - 1, PS2 = SG * 16;
+    constexpr int ROWP = sp_row_pitch(SG, TWK);
+    constexpr int WSTEP = NT * 1024;
+    constexpr bool POOL = (FL & SP_POOL) != 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const ring = smem + a.lds_ring_off;
+    typedef __attribute__((address_space(3))) int lds_int;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) i32x4* lds_i32x4p;
+    lds_int* const flags = (lds_int*)(smem + a.lds_flag_off);
+    const lds_i32x4p flagsv = (lds_i32x4p)(smem + a.lds_flag_off);
+    const int tiles_x = (a.Wout + TW - 1) / TW;
+    const int npairs = (a.ntiles + 1) >> 1;
+    const int n_my = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tile pairs of this workgroup (>= 1)
+    auto xcd_pair = [&](int p) {
+        if (a.xq < 0) return p;
+        const int x = p & 7, j = p >> 3;
+        return x * a.xq + min(x, a.xr) + j;
+    };
+    // tile of pair i of this workgroup and team T; ok = false: the virtual tile behind an odd tile count
+    auto origin = [&](int i, int T, int& oy, int& ox, int& pg, bool& ok) {
+        const int t = 2 * xcd_pair((int)blockIdx.x + i * (int)gridDim.x) + T;
+        ok = t < a.ntiles;
+        const int tc = ok ? t : 0;
+        pg = tc / a.tiles_per_page;
+        const int tl = tc - pg * a.tiles_per_page;
+        const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+        oy = ty * TH; ox = tx * TW;
+    };
+    auto give_up = [&](int code, int need, int have, int need2 = 0, int have2 = 0) {
+        if (lane == 0 && atomicCAS(a.err, 0, code) == 0) { a.err[1] = wave; a.err[2] = need; a.err[3] = have; a.err[4] = need2; a.err[5] = have2; a.err[6] = (int)blockIdx.x; a.err[7] = a.layer_id; }
+    };
+    const int spin_limit = (PSEG_DIAG && (a.dbg & 8)) ? 64 : SP_SPIN_LIMIT;
+    // PSEG_SP_TRACE (developer aid, tools/sp2_trace.py): s_memtime stamps, 16 slots per workgroup -- [0] start; team 0's wave 0: [1] / [4] first
+    // fragments of tile 0 / 1 ready, [2] / [5] k-loop end, [3] / [6] epilogue end, [7] wave end, [11] cycles in slow waits; team 1's wave 4:
+    // [8] ready, [9] k-loop end, [10] epilogue end of tile 0, [12] slow-wait cycles; [13] tile loader 0 end, [14] weight loader 0 end
+    unsigned long long* const trc = (PSEG_DIAG && a.trace) ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
+#define SP2_STAMP(i) if (trc && lane == 0) trc[i] = __builtin_amdgcn_s_memtime();
+    if (wave == 0) { SP2_STAMP(0) }
+    if (lane == 0) {
+        if (wave < 8) { flags[4 + wave] = 0; flags[12 + wave] = 0; }
+        else flags[wave - 8] = 0;
+    }
+    lds_barrier();
+
+    if (wave >= 10) {
+        // =============================== TILE LOADERS ===============================
+        const int tw = wave - 10;
+        __builtin_amdgcn_s_setprio(2);
+        constexpr unsigned OOB = 0xfffffff0u;
+        constexpr int ROW_SLOTS = TWH * SG, J = (ROW_SLOTS + 63) >> 6;
+        constexpr int PER_BLOCK = (THH / 2) * J;              // DMA instructions of one wave per block
+        static_assert(THH % 2 == 0 && 2 * PER_BLOCK < 64, "counted vmcnt waits of the tile loaders");
+        const unsigned inv = 65536u / (unsigned)SG + 1u;
+        const int nblocks = n_my * a.nblk * 2;
+        if (tw == 0) {
+            const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)a.tab, 0, (unsigned)(a.K + 2) * 128u, 0x00020000);
+            for (int pc = 0; pc * 1024 < (a.K + 2) * 128; ++pc)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void*)(smem + a.lds_tab_off + pc * 1024), 16, (unsigned)(pc * 1024 + lane * 16), 0, 0, 0);
+            sp_wait_vmcnt<0>();        // (counted waits below count block loads only)
+        }
+        auto stage = [&](int jb) {
+            if (PSEG_DIAG && (a.dbg & 2)) return;
+            const int T = jb & 1, q = jb >> 1;
+            const int i = q / a.nblk, b = q - i * a.nblk;
+            int oy0, ox0, pg; bool ok;
+            origin(i, T, oy0, ox0, pg, ok);
+            const int iy0 = oy0 - a.pt, ix0 = ox0 - a.pl;
+            char* const in_t = smem + (jb & (SP2_NSLOT - 1)) * a.TBLK;
+            const int c0 = b * a.nc_full, nc = b == a.nblk - 1 ? a.nc_last : a.nc_full;
+            const bool s1 = c0 >= a.nch0;
+            const int nchs = s1 ? a.nch1 : a.nch0, cs0 = s1 ? c0 - a.nch0 : c0;
+            const unsigned pbytes = s1 ? a.bytes1 : a.bytes0;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(s1 ? a.src1 : a.src0) + (size_t)pg * pbytes), 0, pbytes, 0x00020000);
+            unsigned col[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int sl = j * 64 + lane;
+                const int px = (int)(((unsigned)sl * inv) >> 16), cs = sl - px * SG;
+                const int cc = SG == 4 ? cs ^ (((px >> 2) & 1) << 1) : cs;      // the chunk that lives in this slot (see above)
+                const int ix = ix0 + px;
+                col[j] = (ok && cc < nc && ix >= 0 && ix < a.Win && sl < ROW_SLOTS) ? (unsigned)(ix * nchs + cs0 + cc) * 16u : OOB;
+            }
+            const unsigned rowb = (unsigned)a.Win * (unsigned)(nchs * 16);
+            for (int py = tw; py < THH; py += 2) {
+                const int iy = iy0 + py;
+                const bool rowv = iy >= 0 && iy < a.Hin;
+                const unsigned rb = rowv ? (unsigned)iy * rowb : OOB;
+                char* drow = in_t + py * ROWP;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const unsigned o = (col[j] == OOB || !rowv) ? OOB : rb + col[j];
+                    if (j * 64 + lane < ROW_SLOTS)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(drow + j * 1024), 16, o, 0, 0, 0);
+                }
+            }
+        };
+        int unpub = -1;                                       // the block issued last, not yet published
+        for (int jb = 0; jb < nblocks; ++jb) {
+            if (jb >= SP2_NSLOT) {
+                // the slot's previous block jb - 4 belongs to the same team (jb & 1); it is its block number (jb - 4) >> 1
+                const int need = ((jb - SP2_NSLOT) >> 1) + 1;
+                const lds_i32x4p td = (lds_i32x4p)(smem + a.lds_flag_off + 48 + (jb & 1) * 16);
+                for (int it = 0;; ++it) {
+                    asm volatile("" ::: "memory");
+                    const i32x4 d = *td;
+                    if (__builtin_amdgcn_readfirstlane(min(min(d.x, d.y), min(d.z, d.w))) >= need) break;
+                    if (unpub >= 0) { sp_wait_vmcnt<0>(); if (lane == 0) flags[2 + tw] = unpub + 1; unpub = -1; }   // stalled anyway: publish what has landed
+                    if (it >= spin_limit) { give_up(1, need, min(min(d.x, d.y), min(d.z, d.w)), jb); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                asm volatile("" ::: "memory");
+            }
+            stage(jb);
+            if (unpub >= 0) { sp_wait_vmcnt<PER_BLOCK>(); if (lane == 0) flags[2 + tw] = unpub + 1; }
+            unpub = jb;
+            // start-up (every workgroup of the launch fetches at once: ~11 B/clk/CU): team 0's first block alone, then team 1's, the rest behind them
+            if (jb <= 1) { sp_wait_vmcnt<0>(); if (lane == 0) flags[2 + tw] = jb + 1; unpub = -1; }
+        }
+        sp_wait_vmcnt<0>();
+        if (lane == 0) flags[2 + tw] = nblocks;
+        if (tw == 0) { SP2_STAMP(13) }
+        return;
+    }
+    if (wave >= 8) {
+        // =============================== WEIGHT LOADERS ===============================
+        const int lw = wave - 8;
+        const int gpt = a.S / SP_GK;                          // groups per tile pair
+        const int total = n_my * gpt;
+        const int NS = a.RK / SP_GK;                          // ring slots (groups), >= 5 (host)
+        // groups of this wave's loads in flight behind the newest published one: the slowest compute wave inside group c sees c + 1 once the
+        // loader is at q >= c + 1 + lag, and the ring lets it reach q = c + NS - 1 -- one slot of slack at lag = NS - 3 (a five-slot ring: two
+        // groups in flight; one would make the stream latency-bound: 8 KiB per ~1 k cycles for the 8 B/clk a conv5 pair needs)
+        const int lag = min(3, NS - 3);
+        __builtin_amdgcn_s_setprio(2);                        // a loader issues little and what it issues is late if it waits for an issue slot
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (unsigned)a.S * (unsigned)(NT * 1024), 0x00020000);
+        const unsigned vo = (unsigned)lane * 16u;
+        int qt = 0, slot = 0;
+        auto issue = [&]() {
+            const unsigned so = (unsigned)(qt * (SP_GK * NT) + lw) * 1024u;
+            char* dstb = ring + (slot * (SP_GK * NT) + lw) * 1024;
+            if (!(PSEG_DIAG && (a.dbg & 1))) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dstb + j * 2048), 16, vo, so + (unsigned)j * 2048u, 0, 0);
+            }
+            qt = qt + 1 == gpt ? 0 : qt + 1;
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        };
+        const int pre = min(NS, total);
+        const int pre0 = min(2, pre);
+        for (int q = 0; q < pre0; ++q) issue();
+        sp_wait_vmcnt<0>();
+        if (lane == 0) flags[lw] = pre0;
+        for (int it = 0; it < spin_limit; ++it) {             // the rest behind the first tile blocks
+            asm volatile("" ::: "memory");
+            const int t0 = flags[2], t1 = flags[3];
+            if (__builtin_amdgcn_readfirstlane(min(t0, t1)) >= 1) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        for (int q = pre0; q < pre; ++q) issue();
+#define SP_PUB(REM)                                                                              \
+        if (pre - pre0 > (REM)) { sp_wait_vmcnt<(REM) * NT>(); if (lane == 0) flags[lw] = pre - (REM); }
+        SP_PUB(5) SP_PUB(4) SP_PUB(3) SP_PUB(2) SP_PUB(1) SP_PUB(0)
+#undef SP_PUB
+        int pub = pre;
+        if (PSEG_DIAG && (a.dbg & 8)) return;
+        const lds_i32x4p dn = (lds_i32x4p)(smem + a.lds_flag_off + 16);
+        long long wl_poll = 0;
+        for (int q = pre; q < total; ++q) {
+            const int need = q - NS + 1;                      // every compute wave of both teams has finished group q - NS
+            const long long tp0 = trc ? __builtin_amdgcn_s_memtime() : 0;
+            for (int it = 0;; ++it) {
+                asm volatile("" ::: "memory");
+                const i32x4 d0 = dn[0], d1 = dn[1];
+                const int mn = min(min(min(d0.x, d0.y), min(d0.z, d0.w)), min(min(d1.x, d1.y), min(d1.z, d1.w)));
+                if (__builtin_amdgcn_readfirstlane(mn) >= need) break;
+                // the ring is full: what has been issued lands while this wave waits -- publish it now, not `lag` groups behind the next
+                // issue (the consumers look at the counters a trip ahead of their need: a group published late is a slow wait)
+                if (pub < q) { sp_wait_vmcnt<0>(); pub = q; if (lane == 0) flags[lw] = pub; }
+                if (it >= spin_limit) { give_up(2, need, mn, q); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            if (trc) wl_poll += __builtin_amdgcn_s_memtime() - tp0;
+            issue();
+            if (lag == 3) sp_wait_vmcnt<3 * NT>(); else if (lag == 2) sp_wait_vmcnt<2 * NT>(); else sp_wait_vmcnt<NT>();
+            if (q - lag + 1 > pub) { pub = q - lag + 1; if (lane == 0) flags[lw] = pub; }
+        }
+        sp_wait_vmcnt<0>();
+        if (lane == 0) flags[lw] = total;
+        if (lw == 0) { SP2_STAMP(14) if (trc && lane == 0) trc[10] = (unsigned long long)wl_poll; }
+        return;
+    }
+    // =============================== COMPUTE ===============================
+    const int team = wave >> 2, tw4 = wave & 3;
+    const int p16 = lane & 15, g = lane >> 4;
+    float4 biasr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) biasr[t] = *(const float4*)(a.bias + t * 16 + 4 * g);
+    auto PR = [](int m, int p) { return TWK == 32 ? (m >> 1) : (m < 2 ? m : (p >> 3)); };
+    auto PC = [](int m, int p) { return TWK == 32 ? (m & 1) * 16 + p : (m < 2 ? p : 16 + (p & 7)); };
+    // pixel tiles of this wave: TWK 32: tile m at + (m >> 1) * ROWP + (m & 1) * 16 * PS2 from the lane's base (immediates); TWK 24: tiles 0 / 1
+    // likewise (rows 0 / 1, columns 0-15), tile 2 straddles the two rows (columns 16-23): a lane base of its own
+    const char* const xbase = smem + (tw4 * 2) * ROWP + p16 * PS2;
+    const char* const xbase2 = smem + (tw4 * 2 + (p16 >> 3)) * ROWP + (16 + (p16 & 7)) * PS2;
+    const char* const wb0 = ring + lane * 16;
+    const char* const tb = smem + a.lds_tab_off + (g * 8 + (p16 & 7)) * 4;       // table: [k-step][g][p & 7]
+    const int K = a.K, RK = a.RK;
+    const int CsO = a.nch_out * 8;
+    constexpr unsigned OOBS = 0xfffffff0u;
+    long long sw_cyc = 0, sw_w = 0;
+    auto slow_wait = [&](int needw, int needt) {
+        const long long tq0 = trc ? __builtin_amdgcn_s_memtime() : 0;
+        bool for_w = false;
+        for (int it = 0;; ++it) {
+            asm volatile("" ::: "memory");
+            const int r0 = flags[0], r1 = flags[1], t0 = flags[2], t1 = flags[3];
+            if (it == 0) for_w = __builtin_amdgcn_readfirstlane(min(r0, r1)) < needw;
+            if (__builtin_amdgcn_readfirstlane(min(r0, r1)) >= needw && __builtin_amdgcn_readfirstlane(min(t0, t1)) >= needt) break;
+            if (it >= spin_limit) { give_up(3, needw, min(r0, r1), needt, min(t0, t1)); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        if (trc) { const long long dt = __builtin_amdgcn_s_memtime() - tq0; sw_cyc += dt; if (for_w) sw_w += dt; }
+    };
+    int kg = 0, pos0 = 0;
+    for (int i = 0; i < n_my; ++i) {
+        int oy0, ox0, pg; bool tile_ok;
+        origin(i, team, oy0, ox0, pg, tile_ok);
+        const int q0 = i * a.nblk;                            // blocks of this team before this tile
+        // block b of this tile: load index jb = (q0 + b) * 2 + team, slot jb % 4 = team + 2 * ((q0 + b) & 1)
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{biasr[n].x, biasr[n].y, biasr[n].z, biasr[n].w};
+        bf16x8 xa[MT], wa[NT], xb[MT], wbq[NT];
+        bool abl_x = false, abl_w = false;    // diagnostic build (PSEG_SP_DBG 32 / 64, wrong results): fragment reads only in front of the loop
+#define SP_LOAD(XF, WF, POS, OFF)                                                                 \
+        {                                                                                        \
+            const char* wbp_ = wb0 + (POS) * WSTEP;                                              \
+            const char* xp_ = xbase + (OFF);                                                     \
+            if (!(PSEG_DIAG && abl_w)) WF[0] = *(const bf16x8*)(wbp_);                            \
+            if (!(PSEG_DIAG && abl_x)) {                                                         \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                       \
+                XF[m] = (TWK == 24 && m == 2) ? *(const bf16x8*)(xbase2 + (OFF))                 \
+                                              : *(const bf16x8*)(xp_ + (TWK == 32 ? (m >> 1) * ROWP + (m & 1) * 16 * PS2 : m * ROWP)); \
+            }                                                                                    \
+            if (!(PSEG_DIAG && abl_w)) {                                                         \
+            _Pragma("unroll") for (int t = 1; t < NT; ++t)                                       \
+                WF[t] = *(const bf16x8*)(wbp_ + t * 1024);                                       \
+            }                                                                                    \
+        }
+#define SP_MMA(XF, WF)                                                                           \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                           \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                       \
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[t], XF[m], acc[m][t], 0, 0, 0);
+#define SP_INTERLEAVE                                                                            \
+        _Pragma("unroll") for (int q_ = 0; q_ < MT * NT; ++q_) {                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        }
+        // Loop control is branch-free except for the slow wait, the block change and the two exec-masked counter stores: per trip ~75
+        // scalar / branch instructions (block trackers as while loops, clamps, two needs recomputed) left the matrix pipe idle for a
+        // third of a trip -- with the fragment reads AND the DMAs switched off the loop still took 28 cycles per MFMA per SIMD (tools/
+        // gpu_r05_sp2_abl.sh).  Now: the table has two rows beyond K (no clamp), the block of a step is "current or next" by one compare.
+#define SP_TABX(X) (*(const int*)(tb + (X) * 128))
+        const int sb_lo = team * a.TBLK, sb_hi = (team + 2) * a.TBLK;
+        int sb_cur = ((q0 & 1) ? sb_hi : sb_lo), sb_next = sb_lo + sb_hi - sb_cur;
+        int bcur = 0, bnd = a.nblk > 1 ? a.blk_steps : 0x7fffffff;   // block of step s; first step of block bcur + 1
+        int nt_cur = q0 * 2 + team + 1;                       // tready value that says block bcur of this tile has landed (next block: + 2)
+        slow_wait(((kg + min(2, K - 1)) >> 1) + 1, nt_cur + ((2 >= bnd) ? 2 : 0));
+        if (wave == 0 && i < 2) { SP2_STAMP(1 + 3 * i) }
+        if (wave == 4 && i < 1) { SP2_STAMP(8) }
+        int pos1 = pos0 + 1 == RK ? 0 : pos0 + 1, pos2 = pos1 + 1 == RK ? 0 : pos1 + 1;
+        int offa = SP_TABX(0) + sb_cur, offb = SP_TABX(1) + (1 >= bnd ? sb_next : sb_cur);
+        SP_LOAD(xa, wa, pos0, offa)
+        if (PSEG_DIAG) { SP_LOAD(xb, wbq, pos1, offb) abl_x = (a.dbg & 32) != 0; abl_w = (a.dbg & 64) != 0; }
+        int myprio = 0;
+        for (int s = 0; s < K; s += 2) {                      // K is even
+            __builtin_amdgcn_sched_barrier(0);
+            const i32x4 fv = *flagsv;
+            const int pd = flags[4 + (wave ^ 4)];             // groups the partner wave on this SIMD is past (looked at behind the trip's MFMAs)
+            offa = SP_TABX(s + 2) + (s + 2 >= bnd ? sb_next : sb_cur);
+            SP_LOAD(xb, wbq, pos1, offb)
+            SP_MMA(xa, wa)
+            SP_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+            offb = SP_TABX(s + 3) + (s + 3 >= bnd ? sb_next : sb_cur);
+            SP_LOAD(xa, wa, pos2, offa)
+            SP_MMA(xb, wbq)
+            SP_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+            const int mine = ((kg + s) >> 1) + 1;
+            if (lane == 0) flags[4 + wave] = mine;
+            if (s + 2 >= bnd) {                               // (rare) steps s, s + 1 were the last of block bcur (or s + 1 already the next one's first)
+                ++bcur;
+                if (lane == 0) flags[12 + wave] = q0 + bcur;
+                sb_cur = sb_next; sb_next = sb_lo + sb_hi - sb_cur;
+                nt_cur += 2;
+                bnd = bcur + 1 < a.nblk ? bnd + a.blk_steps : 0x7fffffff;
+            }
+            // needs of steps s + 3 and s + 4 (requested by the next trip): their weight group, and the block of s + 4
+            const int needw = ((kg + min(s + 4, K - 1)) >> 1) + 1, needt = nt_cur + (s + 4 >= bnd ? 2 : 0);
+            if (__builtin_amdgcn_readfirstlane(min(fv.x, fv.y)) < needw || __builtin_amdgcn_readfirstlane(min(fv.z, fv.w)) < needt)
+                slow_wait(needw, needt);
+            // The two compute waves of a SIMD (this wave and wave ^ 4) are arbitrated by priority, then age: left alone, the older team
+            // sprints to the end of the ring, stalls in slow_wait, and the younger one runs on alone -- two waves per SIMD in name only.
+            // The wave that is BEHIND its partner takes the priority: the teams advance group by group together.
+            if (!(PSEG_DIAG && (a.dbg & 16))) {
+                const int want = __builtin_amdgcn_readfirstlane(pd) < mine ? 0 : 1;
+                if (want != myprio) {
+                    myprio = want;
+                    if (want) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                }
+            }
+            asm volatile("" ::: "memory");
+            pos1 = pos2 + 1 == RK ? 0 : pos2 + 1;
+            pos2 = pos1 + 1 == RK ? 0 : pos1 + 1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#undef SP_TABX
+#undef SP_INTERLEAVE
+#undef SP_MMA
+#undef SP_LOAD
+        if (lane == 0) flags[12 + wave] = q0 + a.nblk;        // the tile's last block: read to the end
+        if (wave == 0 && i < 2) { SP2_STAMP(2 + 3 * i) }
+        if (wave == 4 && i < 1) { SP2_STAMP(9) }
+        // the whole stream of this pair is behind this wave (padding steps included): hand it back before the epilogue
+        kg += a.S;
+        asm volatile("" ::: "memory");
+        if (lane == 0) flags[4 + wave] = kg >> 1;
+        pos0 = (pos0 + a.S) % RK;
+        __builtin_amdgcn_s_setprio(0);
+        // ---- epilogue from registers: one 16-pixel tile at a time through this wave's LDS patch ------------------------
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        if (tile_ok) {
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.dst + (size_t)pg * a.dst_bytes), 0, a.dst_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(POOL ? (char*)a.pool_dst + (size_t)pg * a.pool_bytes : (char*)a.dst), 0, POOL ? a.pool_bytes : 0u, 0x00020000);
+            constexpr int PP = NT * 32 + 8;                   // patch bytes per pixel (+ 8: conflict-free 8-byte writes)
+            constexpr int PPX = NT * 2;                       // 16-byte pieces per pixel
+            constexpr int NP = 8 * PPX;                       // pieces of half a pixel tile (eight pixels: <= 64, one store per lane)
+            static_assert(NP <= 64, "one piece per lane");
+            char* const patch = smem + a.lds_patch_off + wave * (8 * PP);
+            float pv[POOL ? NT : 1][POOL ? MT : 1][4];        // (pool: the values of the tiles, paired below)
+            const int px8 = min(lane / PPX, 7), pc = lane - (lane / PPX) * PPX;   // this lane's piece of a half tile: pixel, 16-byte piece
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                uint2 pk[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float v[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
+                    if (a.relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = vmax(v[r], 0.0f);
+                    }
+                    if constexpr (POOL) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[t][m][r] = v[r];
+                    }
+                    pk[t] = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+                }
+                if (a.dst_bytes) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {             // pixels 8 h ... 8 h + 7 of the tile
+                        if ((p16 >> 3) == h) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) *(uint2*)(patch + (p16 & 7) * PP + t * 32 + g * 8) = pk[t];
+                        }
+                        asm volatile("" ::: "memory");        // (the patch is this wave's own: a wave's LDS operations execute in order)
+                        const char* sp = patch + px8 * PP + pc * 16;
+                        const uint2 lo = *(const uint2*)sp, hi = *(const uint2*)(sp + 8);
+                        const int px = h * 8 + px8;
+                        const int y = oy0 + tw4 * 2 + PR(m, px), x = ox0 + PC(m, px);
+                        const bool ok = lane < NP && y < a.Hout && x < a.Wout && pc * 16 < CsO * 2;
+                        const unsigned o = ok ? (unsigned)(y * a.Wout + x) * (unsigned)(CsO * 2) + (unsigned)(pc * 16) : OOBS;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_uint4(lo.x, lo.y, hi.x, hi.y)), rd, o, 0, 0);
+                        asm volatile("" ::: "memory");
+                    }
+                }
+            }
+            if constexpr (POOL) {
+                const int Wo2 = a.Wout >> 1, Ho2 = a.Hout >> 1;
+                const int y = (oy0 >> 1) + tw4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int n = t * 16 + 4 * g;
+                    const unsigned noff = n < CsO ? (unsigned)n * 2u : OOBS;
+                    // vertical pairs: TWK 32: tiles (0, 2) and (1, 3); TWK 24: tiles (0, 1), and the two lane halves of tile 2
+                    constexpr int NPAIR = TWK == 32 ? 2 : 2;
+#pragma unroll
+                    for (int pr = 0; pr < NPAIR; ++pr) {
+                        float q[4];
+                        int xcol; bool lane_ok;
+                        if (TWK == 32) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) q[r] = vmax_xor1(vmax(pv[t][pr][r], pv[t][pr + 2][r]));
+                            xcol = pr * 16 + p16; lane_ok = !(p16 & 1);
+                        } else if (pr == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) q[r] = vmax_xor1(vmax(pv[t][0][r], pv[t][1][r]));
+                            xcol = p16; lane_ok = !(p16 & 1);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float w = pv[t][MT - 1][r];
+                                // the other row's value of the same column sits eight lanes away in the 16-lane row: DPP row_ror:8
+                                const float o8 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w), 0x128, 0xF, 0xF, false));
+                                q[r] = vmax_xor1(vmax(w, o8));
+                            }
+                            xcol = 16 + (p16 & 7); lane_ok = !(p16 & 1) && p16 < 8;
+                        }
+                        const int x = (ox0 + xcol) >> 1;
+                        const bool ok = lane_ok && y < Ho2 && x < Wo2 && noff != OOBS;
+                        const unsigned o = ok ? (unsigned)(y * Wo2 + x) * (unsigned)(CsO * 2) + noff : OOBS;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_uint2(pk_bf16(q[0], q[1]), pk_bf16(q[2], q[3]))), rp, o, 0, 0);
+                    }
+                }
+            }
+        }
+        if (wave == 0 && i < 2) { SP2_STAMP(3 + 3 * i) }
+    }
+    if (wave == 0) { SP2_STAMP(7) if (trc && lane == 0) { trc[11] = (unsigned long long)sw_cyc; trc[15] = (unsigned long long)sw_w; } }
+    if (wave == 4 && trc && lane == 0) trc[12] = (unsigned long long)sw_cyc;
+#undef SP2_STAMP
+}
+
 // =============================================================================================
 // host side: plans, packing, launches
 // =============================================================================================
@@ -3269,7 +3738,18 @@ struct MfmaPlan {
     struct SpNarrow { bool ok = false; int row_pitch = 0, TBLK = 0, RK = 0, ring_off = 0, patch_off = 0, tab_off = 0, flag_off = 0, lds = 0; int* d_tab = nullptr; } sp24;
     int* d_sp_tab = nullptr;
     uint16_t* d_sp_wpk = nullptr;
+    // conv_sp2_kernel (two compute teams, four block slots): [0] tiles of 8 x 32, [1] of 8 x 24; block-relative k-chunk tables, the same weight stream
+    struct Sp2 { bool ok = false; int TBLK = 0, RK = 0, ring_off = 0, patch_off = 0, tab_off = 0, flag_off = 0, lds = 0; int* d_tab = nullptr; } sp2[2];
 };
+
+static bool sp2_off() {
+    const char* v = PSEG_KNOB("PSEG_SP2");
+    return v && atoi(v) == 0;
+}
+static bool tracing_req(const Op& op) {
+    const char* trl = PSEG_KNOB("PSEG_SP_TRACE");
+    return trl && op.layer == trl;
+}
 
 void mfma_free_op(Op& op) {
     auto* p = (MfmaPlan*)op.plan;
@@ -3282,7 +3762,7 @@ void mfma_free_op(Op& op) {
     (void)hipFree(p->d_skiplog);
     (void)hipFree(p->d_dq_w); (void)hipFree(p->d_dq_bias);
     (void)hipFree(p->d_q_w); (void)hipFree(p->d_q_bias); (void)hipFree(p->d_t2_wD); (void)hipFree(p->d_t2_wC);
-    (void)hipFree(p->d_sp_tab); (void)hipFree(p->sp24.d_tab); (void)hipFree(p->d_sp_wpk);
+    (void)hipFree(p->d_sp_tab); (void)hipFree(p->sp24.d_tab); (void)hipFree(p->d_sp_wpk); (void)hipFree(p->sp2[0].d_tab); (void)hipFree(p->sp2[1].d_tab);
     delete p;
     op.plan = nullptr;
 }
@@ -3996,6 +4476,37 @@ int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vect
                     PSEG_TRY(upload(&N.d_tab, tabn));
                 }
             }
+            // conv_sp2_kernel: two compute teams on a pool of four block slots (NT 3 / 4 layers; the fused transposed conv stays above)
+            if (!dq && NT <= 4 && !sp2_off()) {
+                for (int v = 0; v < 2; ++v) {
+                    auto& Q = P->sp2[v];
+                    const int twv = v == 0 ? 32 : 24, rowpv = sp_row_pitch(sg, twv), TBLKv = round_up((8 + KS - 1) * rowpv, 16);
+                    const int patchv = 8 * 8 * (NT * 32 + 8), tabv = round_up((K + 2) * 128, 1024);     // table: [k-step][lane group][column & 7]
+                    const int rkv = std::min((LDS_MAX - SP2_NSLOT * TBLKv - patchv - tabv - 128) / (NT * 1024), 16) & ~1;
+                    if (rkv < 10) continue;
+                    Q.ok = true; Q.TBLK = TBLKv; Q.RK = rkv;
+                    Q.ring_off = SP2_NSLOT * TBLKv; Q.patch_off = Q.ring_off + rkv * NT * 1024; Q.tab_off = Q.patch_off + patchv;
+                    Q.flag_off = Q.tab_off + tabv; Q.lds = Q.flag_off + 128;
+                    std::vector<int> tabq((size_t)(K + 2) * 32, 0);       // (two rows beyond K: the loop looks its offsets up two steps ahead, unclamped)
+                    for (int b = 0; b < P->nblk; ++b) {
+                        const bool last = b == P->nblk - 1;
+                        const auto& ord = last ? o_last : o_full;
+                        const int ksb = last ? ksl : ksf, st0 = b * ksf;
+                        for (int st = 0; st < ksb; ++st)
+                            for (int gi = 0; gi < 4; ++gi) {
+                                const Chunk c = ord[(size_t)st * 4 + gi];
+                                if (c.cc < 0) continue;
+                                for (int p7 = 0; p7 < 8; ++p7) {
+                                    // four-chunk blocks are stored swizzled: chunk c of halo column x in slot c ^ 2 ((x >> 2) & 1); x = p + kx (+ 16)
+                                    const int slot = sg == 4 ? c.cc ^ ((((p7 + c.tap % KS) >> 2) & 1) << 1) : c.cc;
+                                    tabq[((size_t)(st0 + st) * 4 + gi) * 8 + p7] = (c.tap / KS) * rowpv + (c.tap % KS) * sg * 16 + slot * 16;   // inside the block's slot
+                                }
+                            }
+                    }
+                    for (int r = K; r < K + 2; ++r) std::copy(tabq.begin() + (size_t)(K - 1) * 32, tabq.begin() + (size_t)K * 32, tabq.begin() + (size_t)r * 32);
+                    PSEG_TRY(upload(&Q.d_tab, tabq));
+                }
+            }
             if (!e.d_sp_err) {   // the engine's give-up record of conv_sp_kernel (engine_status)
                 PSEG_HIP(hipMalloc((void**)&e.d_sp_err, 32));
                 PSEG_HIP(hipMemset(e.d_sp_err, 0, 32));
@@ -4548,6 +5059,78 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         c.dst = a.dst; c.dst_bytes = a.dst_bytes; c.nch_out = a.nch_out; c.pool_dst = a.pool_dst; c.pool_bytes = a.pool_bytes;
         c.dq_bias = a.dq_bias; c.dq_dst = a.dq_dst; c.dq_bytes = a.dq_bytes; c.dq_nch = a.dq_nch; c.dq_relu = a.dq_relu;
         const int npg = e.batch_pages > 1 ? e.batch_pages : 1;               // page slots of this launch: a tile index carries the page
+        // ---- two compute teams (conv_sp2_kernel): the 40- / 60-channel layers once every CU gets a tile pair --------------------------
+        // Tile width by rounds of pairs x width, as above: a 2048x1536 page at 1/4 resolution is 768 tiles of 8 x 32 (1.5 pairs per CU: two
+        // rounds) or 1024 of 8 x 24 (exactly two pairs per CU).
+        if ((!tracing_req(op) || PSEG_DIAG_KNOB("PSEG_SP2_TRACE")) && (P->sp2[0].ok || P->sp2[1].ok) && !sp2_off()) {
+            const char* const sp2_sw = PSEG_KNOB("PSEG_SP2");   // plan switch (tests, A/B): 0 off, 1 every eligible launch, 24 / 32 likewise with that tile width
+            int bestv = -1, best_cost = 1 << 30, best_tiles = 0;
+            for (int v = 0; v < 2; ++v) {
+                if (!P->sp2[v].ok) continue;
+                const int twv = v == 0 ? 32 : 24;
+                const int tl = cdiv(a.Wout, twv) * cdiv(a.Hout, 8);
+                const int cost = cdiv((tl * npg + 1) / 2, cus_sp) * twv;
+                if (cost < best_cost) { best_cost = cost; bestv = v; best_tiles = tl; }
+            }
+            if (sp2_sw && (atoi(sp2_sw) == 24 || atoi(sp2_sw) == 32)) {
+                const int v = atoi(sp2_sw) == 24 ? 1 : 0;
+                if (P->sp2[v].ok) { bestv = v; best_tiles = cdiv(a.Wout, v == 0 ? 32 : 24) * cdiv(a.Hout, 8); }
+            }
+            const int npairs = (best_tiles * npg + 1) / 2;
+            // Where it runs by default: measured on the 2048x1536 page and in 32-page units against conv_mfma_kernel (tools/gpu_r05_sp2_ab.sh,
+            // gpu_r05_sp2_pages.sh, us per page): deconv3 60.8-61.9 vs 60.6 / 47.7-48.4 vs 50.2-50.7; conv6 41.2-41.9 vs 41.8-42.3 / 33.1 vs
+            // 30.2; conv5 32.1-32.5 vs 31.5-32.0 (before its table took the ring's room) -- a tie on the single page, a gain only for the
+            // three-cout-tile layer in page units.  PSEG_SP2=1 / 24 / 32 (plan switch): every eligible layer.
+            if (bestv >= 0 && ((npairs >= cus_sp && P->sp_NT == 3 && npg > 1) || sp2_sw)) {
+                const auto& Q = P->sp2[bestv];
+                SConv d = c;
+                d.tab = Q.d_tab; d.TBLK = Q.TBLK; d.RK = Q.RK; d.row_pitch = sp_row_pitch(P->sp_sigma, bestv == 0 ? 32 : 24);
+                d.lds_ring_off = Q.ring_off; d.lds_patch_off = Q.patch_off; d.lds_tab_off = Q.tab_off; d.lds_flag_off = Q.flag_off;
+                d.ntiles = best_tiles * npg; d.tiles_per_page = best_tiles;
+                d.xq = a.xq < 0 ? -1 : npairs / 8; d.xr = npairs % 8;
+                d.err = e.d_sp_err;
+                d.layer_id = (int)(&op - e.ops.data());
+                d.dbg = PSEG_DIAG_KNOB("PSEG_SP_DBG") ? atoi(PSEG_DIAG_KNOB("PSEG_SP_DBG")) : 0;
+                const dim3 g2((unsigned)std::min<int>(npairs, cus_sp));
+                const int fl2 = P->sp_fl & SP_POOL;
+                bool done2 = false;
+                const bool trace2 = PSEG_DIAG_KNOB("PSEG_SP2_TRACE") && tracing_req(op);   // diagnostic build: stamps -> gpurun_out/sp2_trace_<layer>.bin
+                if (trace2) {
+                    PSEG_HIP(hipMalloc((void**)&d.trace, (size_t)g2.x * 16 * 8));
+                    PSEG_HIP(hipMemset(d.trace, 0, (size_t)g2.x * 16 * 8));
+                }
+                if (PSEG_KNOB("PSEG_LOG_SP")) fprintf(stderr, "[pseg] conv_sp2 launch %s: tw %d tiles %d pairs %d grid %u RK %d lds %d\n", op.layer.c_str(), bestv ? 24 : 32, d.ntiles, npairs, g2.x, d.RK, Q.lds);
+#define PSEG_SP2(NT_, SG_, FL_, TW_)                                                                                \
+                if (!done2 && P->sp_NT == NT_ && P->sp_sigma == SG_ && fl2 == (FL_) && (bestv == 1) == (TW_ == 24)) {    \
+                    static bool attr_set[64] = {false};                                                               \
+                    if (!attr_set[dev & 63]) {                                                                        \
+                        PSEG_HIP(hipFuncSetAttribute((const void*)conv_sp2_kernel<NT_, SG_, (FL_), TW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                        attr_set[dev & 63] = true;                                                                    \
+                    }                                                                                                 \
+                    conv_sp2_kernel<NT_, SG_, (FL_), TW_><<<g2, 768, Q.lds, st>>>(d);                                  \
+                    PSEG_HIP(hipGetLastError());                                                                      \
+                    done2 = true;                                                                                     \
+                }
+                PSEG_SP2(4, 5, 0, 24)           // conv5 (its 8 x 32 blocks leave no room for a ring)
+                PSEG_SP2(4, 4, SP_POOL, 24) PSEG_SP2(4, 4, SP_POOL, 32)   // conv6
+                PSEG_SP2(4, 4, 0, 24) PSEG_SP2(4, 4, 0, 32)
+                PSEG_SP2(4, 5, SP_POOL, 24)
+                PSEG_SP2(3, 4, 0, 24) PSEG_SP2(3, 4, 0, 32)               // deconv3
+#undef PSEG_SP2
+                if (done2 && trace2) {
+                    PSEG_HIP(hipStreamSynchronize(st));
+                    std::vector<unsigned long long> hbuf((size_t)g2.x * 16);
+                    PSEG_HIP(hipMemcpy(hbuf.data(), d.trace, hbuf.size() * 8, hipMemcpyDeviceToHost));
+                    (void)hipFree(d.trace);
+                    const std::string fn = std::string("gpurun_out/sp2_trace_") + op.layer + ".bin";
+                    if (FILE* f = fopen(fn.c_str(), "wb")) { fwrite(hbuf.data(), 8, hbuf.size(), f); fclose(f); }
+                }
+                if (done2) {
+                    if (PSEG_KNOB("PSEG_SP_CHECK")) PSEG_TRY(engine_status(e, st));
+                    return PSEG_OK;
+                }
+            }
+        }
         c.ntiles = tiles_pp * npg; c.tiles_per_page = tiles_pp;
         c.xq = a.xq < 0 ? -1 : c.ntiles / 8; c.xr = c.ntiles % 8;
         c.err = e.d_sp_err;

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64) void spline3_prefilter_kernel(double* c, int Hp
     if (line >= nlines) return;
     double* p = AXIS == 1 ? c + (size_t)line * Wp : c + line;
     const size_t st = AXIS == 1 ? 1 : (size_t)Wp;
+    if (n == 1) return;                             // (scipy leaves a line of one sample as it is)
     const double z = -0.2679491924311227;          // sqrt(3) - 2
     for (int i = 0; i < n; ++i) p[i * st] *= 6.0;   // gain (1 - z)(1 - 1/z)
     if (reflect) {

@@ -104,9 +104,10 @@ int pseg_predict_device(pseg_engine* e, const uint8_t* d_img, int H, int W, floa
 
 /* Predictor.predict's page loop (lib/predictor.py:27-30) for n_pages pages of ONE shape that are resident on the device:
  * d_imgs = the pages one behind the other (n_pages * H * W * in_channels bytes), d_labels / d_labels_u8 = the label maps
- * one behind the other (either may be NULL).  bf16 fcn / fcn_skip engines keep a page slot per page in every activation
- * tensor and give the low-resolution layers all slots in one launch (a page alone leaves them a partly filled chip); any
- * other engine runs the pages one after the other.  Each map equals pseg_predict_device's for that page.  Asynchronous
+ * one behind the other (either may be NULL).  bf16 engines keep a page slot per page in every activation tensor and give
+ * the low-resolution layers (from 1/4 resolution down: fcn / fcn_skip's conv5 ... deconv3, the plain convolutions of unet /
+ * res_unet) all slots in one launch (a page alone leaves them a partly filled chip); float32 engines run the pages one after
+ * the other.  Each map equals pseg_predict_device's for that page.  Asynchronous
  * on `stream`.  The slots per unit (16, PSEG_BATCH_PAGES) are cut to what the device's free memory holds, and halved
  * again when an allocation fails all the same (PSEG_ENOMEM only when a single slot does not fit). */
 int pseg_predict_pages_device(pseg_engine* e, const uint8_t* d_imgs, int n_pages, int H, int W, int64_t* d_labels,

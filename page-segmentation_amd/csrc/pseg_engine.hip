@@ -904,7 +904,13 @@ static int run_bf16_pages(Engine& e, const uint8_t* d_imgs, int n, int64_t* d_la
             case OP_CONV: PSEG_TRY(mfma_launch_conv(e, op, st)); break;
             case OP_DECONV2: PSEG_TRY(mfma_launch_deconv2(e, op, st)); break;
             case OP_POOL: PSEG_TRY(mfma_launch_pool(e, op, st)); break;
-            default: return fail(PSEG_EUNSUPPORTED, "page batches run the fcn / fcn_skip graphs (layer %s)", op.layer.c_str());
+            case OP_BN: {
+                const Tensor& s0 = e.tensors[op.src0];
+                PSEG_TRY(bn_infer_bf16((const uint16_t*)s0.d, (uint16_t*)e.tensors[op.dst].d, (size_t)e.tH(s0) * e.tW(s0), s0.Cs, op.d_w, op.relu, st));
+                break;
+            }
+            case OP_LOGITS: PSEG_TRY(mfma_launch_logits(e, op, nullptr, nullptr, e.cur_labels, e.cur_labels_u8, st)); break;   // (the slot's label maps)
+            default: return fail(PSEG_EUNSUPPORTED, "page units: unknown op type (layer %s)", op.layer.c_str());
         }
         PSEG_HIP(hipGetLastError());
         return time_end(e, op, st, ev0);
@@ -913,6 +919,14 @@ static int run_bf16_pages(Engine& e, const uint8_t* d_imgs, int n, int64_t* d_la
     std::vector<Op*> live;
     for (auto& op : e.ops)
         if (!op.fused_away) live.push_back(&op);
+    // graphs whose first layer is not fused into its consumer (unet, res_unet, 3-channel input) read the pre-processed page from the
+    // input TENSOR: every slot's is written once, up front; the fused first layer reads the uint8 page itself (cur_img, set per slot below)
+    bool input_tensor_read = false;
+    for (auto& op : e.ops)
+        if (!op.fused_away && (op.src0 == e.input_tensor || op.src1 == e.input_tensor) && op.fuse1 < 0) input_tensor_read = true;
+    // (mfma_preprocess launches nothing where every reader of the input is a special first-layer kernel that takes the page bytes)
+    if (input_tensor_read)
+        for (int p = 0; p < n && rc == PSEG_OK; ++p) { slot(p); rc = mfma_preprocess(e, d_imgs + (size_t)p * npx * e.in_ch, st); }
     for (size_t i = 0; i < live.size() && rc == PSEG_OK;) {
         if (mfma_op_batchable(e, *live[i])) {
             slot(0);
@@ -926,7 +940,7 @@ static int run_bf16_pages(Engine& e, const uint8_t* d_imgs, int n, int64_t* d_la
         while (j < live.size() && !mfma_op_batchable(e, *live[j])) ++j;
         for (int p = 0; p < n && rc == PSEG_OK; ++p) {
             slot(p);
-            rc = mfma_preprocess(e, d_imgs + (size_t)p * npx * e.in_ch, st);     // (sets the page the fused first layer reads)
+            e.cur_img = d_imgs + (size_t)p * npx * e.in_ch;                     // (the page a fused / special first layer reads)
             for (size_t k = i; k < j && rc == PSEG_OK; ++k) rc = launch(*live[k]);
         }
         i = j;
@@ -947,18 +961,14 @@ int predict_device_pages(Engine& e, const uint8_t* d_imgs, int n, int H, int W, 
     return run_bf16_pages(e, d_imgs, n, d_labels, d_labels_u8, st);
 }
 
-// true when this engine's graph can run page batches (run_bf16_pages): bf16 mode, every live layer a conv / transposed conv of
-// the fcn family whose first layer is fused (no separate pre-process pass, no stand-alone logits layer)
+// true when this engine's graph can run page units (run_bf16_pages): bf16 mode and at least one layer whose kernel takes several page
+// slots in one launch (the fcn family's 1/4- and 1/8-resolution layers; the plain convs of unet / res_unet from 1/4 resolution down)
 bool pages_capable(Engine& e) {
-    if (e.mode != PSEG_MODE_BF16 || e.in_ch != 1 || PSEG_KNOB("PSEG_NO_PAGE_BATCH")) return false;
+    if (e.mode != PSEG_MODE_BF16 || PSEG_KNOB("PSEG_NO_PAGE_BATCH")) return false;
     if (e.weights_dirty) return false;        // (plans exist after the first upload: the caller's first page goes alone)
     bool any = false;
-    for (auto& op : e.ops) {
-        if (op.fused_away) continue;
-        if (op.type != OP_CONV && op.type != OP_DECONV2) return false;
-        if (op.src0 == e.input_tensor && op.fuse1 < 0) return false;
-        any |= mfma_op_batchable(e, op);
-    }
+    for (auto& op : e.ops)
+        if (!op.fused_away) any |= mfma_op_batchable(e, op);
     return any;
 }
 

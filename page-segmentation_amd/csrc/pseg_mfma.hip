@@ -3535,6 +3535,18 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         SP_LOAD(xa, wa, pos0, offa)
         if (PSEG_DIAG) { SP_LOAD(xb, wbq, pos1, offb) abl_x = (a.dbg & 32) != 0; abl_w = (a.dbg & 64) != 0; }
         int myprio = 0;
+        if (PSEG_DIAG && (a.dbg & 128)) {                     // (diagnostic build, wrong results) the bare loop: MFMAs (+ fragment reads unless 32 / 64), no control
+            for (int s = 0; s < K; s += 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                SP_LOAD(xb, wbq, pos1, offb)
+                SP_MMA(xa, wa)
+                SP_INTERLEAVE
+                __builtin_amdgcn_sched_barrier(0);
+                SP_LOAD(xa, wa, pos2, offa)
+                SP_MMA(xb, wbq)
+                SP_INTERLEAVE
+            }
+        } else
         for (int s = 0; s < K; s += 2) {                      // K is even
             __builtin_amdgcn_sched_barrier(0);
             const i32x4 fv = *flagsv;
@@ -5280,6 +5292,10 @@ bool mfma_op_batchable(const Engine& e, const Op& op) {
         op.src0 == e.input_tensor || op.src1 == e.input_tensor)
         return false;
     if (P->pp) return false;
+    // layer-major launches pay where one page leaves the chip partly filled or its launch is mostly ramp and drain: from 1/4 resolution
+    // down (a 2048x1536 page: 768 tiles there).  The full- and half-resolution layers of the 3x3 graphs stay page-major: a page's
+    // tensors are in the caches for its next layer.
+    if (e.tensors[op.dst].s < 2) return false;
     if (op.dq_fuse >= 0) return P->sp && (P->sp_fl & SP_DQ) != 0;
     return true;
 }

@@ -645,12 +645,14 @@ __global__ __launch_bounds__(NW * 64) void vote_tile_kernel(const uint8_t* __res
 // unions of the open components across tile edges, on the root slot ids: a wave per tile takes the tile's task list (written by
 // vote_tile_kernel from its masks -- the binarisation is not read again), looks the neighbour's slot up in ITS rim table (places
 // >= 2 CT_W: the left neighbour's right column, else the upper neighbour's bottom row) and joins.
-__global__ __launch_bounds__(64) void vote_border_kernel(const uint8_t* __restrict__ rimtab, const unsigned short* __restrict__ tasks,
-                                                         const int* __restrict__ taskn, int* P, int tiles_x) {
-    const int tile = blockIdx.x;
+// (a wave per tile, four tiles per workgroup: 12 288 one-wave workgroups of which most find an empty list were 17 us of dispatch)
+__global__ __launch_bounds__(256) void vote_border_kernel(const uint8_t* __restrict__ rimtab, const unsigned short* __restrict__ tasks,
+                                                          const int* __restrict__ taskn, int* P, int tiles_x, int tiles) {
+    const int tile = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= tiles) return;
     const int n = taskn[tile];
-    if ((int)threadIdx.x >= n) return;
-    const unsigned t = tasks[(size_t)tile * V_TASK_MAX + threadIdx.x];
+    if (lane >= n) return;
+    const unsigned t = tasks[(size_t)tile * V_TASK_MAX + lane];
     const int place = (int)(t >> 8), nb = place >= 2 * CT_W ? tile - 1 : tile - tiles_x;
     uf_union(P, tile * V_OPEN_MAX + (int)(t & 255u), nb * V_OPEN_MAX + rimtab[(size_t)nb * V_RIM + place]);
 }
@@ -658,8 +660,9 @@ __global__ __launch_bounds__(64) void vote_border_kernel(const uint8_t* __restri
 // counts of the root slots that a border union redirected: added to the final root's row (and the slot pointed straight at
 // it: the unions are over, the runs' finds end after one hop).  One wave per tile; the lanes of a wave that share their final
 // root (a figure's percolating component: thousands of slots on the page, one root) are summed first, one lane adds.
-__global__ __launch_bounds__(64) void vote_merge_kernel(int* P, int* hist, const int* rootn, int ncls) {
-    const int tile = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void vote_merge_kernel(int* P, int* hist, const int* rootn, int ncls, int tiles) {
+    const int tile = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= tiles) return;
     const int n = rootn[tile];
     for (int base = 0; base < n; base += 64) {
         int id = 0, r = -1;
@@ -803,8 +806,8 @@ static int cc_vote_device(LT* d_pred, const uint8_t* d_bin, int H, int W, int nc
         vote_tile_kernel<LT, 4><<<tiles, 256, lds, st>>>(d_bin, d_pred, d_par, d_hist, d_rim, d_rootn, d_runs, d_runn, d_tasks, d_taskn, H, W, ncls);
         const int nby = (H - 1) / CT_H, nbx = (W - 1) / CT_W;
         if (nby * W + nbx * H > 0) {                      // (a one-tile page has no open component)
-            vote_border_kernel<<<tiles, 64, 0, st>>>(d_rim, d_tasks, d_taskn, d_par, cdiv(W, CT_W));
-            vote_merge_kernel<<<tiles, 64, 0, st>>>(d_par, d_hist, d_rootn, ncls);
+            vote_border_kernel<<<cdiv(tiles, 4), 256, 0, st>>>(d_rim, d_tasks, d_taskn, d_par, cdiv(W, CT_W), tiles);
+            vote_merge_kernel<<<cdiv(tiles, 4), 256, 0, st>>>(d_par, d_hist, d_rootn, ncls, tiles);
             vote_apply_runs_kernel<LT><<<tiles, 256, 0, st>>>(d_par, d_hist, d_runs, d_runn, d_pred, W, ncls);
         }
     }

@@ -58,13 +58,15 @@ def test_config2_one_rank_share_32_full_size_pages(gpu):
     eng.close()
 
 
-@pytest.mark.parametrize("arch,C", [("fcn_skip", 3), ("fcn", 3), ("fcn_skip", 6), ("unet", 3)])
+@pytest.mark.parametrize("arch,C", [("fcn_skip", 3), ("fcn", 3), ("fcn_skip", 6), ("unet", 3), ("res_unet", 3)])
 def test_page_units_equal_page_by_page(gpu, monkeypatch, arch, C):
     """Page slots (pseg_predict_pages_device; the units of pseg_predict_batch): every activation tensor holds one slot per page of a
     unit, the low-resolution layers take all slots in one launch (conv_sp_kernel: the tile index carries the page; conv_mfma_kernel:
     the slot is blockIdx.z), the others run per slot -- each label map must be the one pseg_predict_device gives for that page.
     Ragged shapes (pad-to-32 canvases), one-tile pages, a list that mixes shapes (units break at a shape change), uint8 and
-    int64 maps, a unit size that does not divide the list, a graph without page support (unet: falls back to a page loop)."""
+    int64 maps, a unit size that does not divide the list.  unet / res_unet (round 5): their plain convolutions from 1/4 resolution
+    down take a unit's slots in one launch (blockIdx.z), everything else -- first layer, pools, up-sampling and residual layers, the
+    stand-alone logits layer -- runs per slot; the input tensor of every slot is pre-processed up front."""
     import torch
     rng = np.random.default_rng(11)
     monkeypatch.setenv("PSEG_SP_CHECK", "1")

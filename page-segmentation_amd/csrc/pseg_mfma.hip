@@ -3458,8 +3458,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     auto PC = [](int m, int p) { return TWK == 32 ? (m & 1) * 16 + p : (m < 2 ? p : 16 + (p & 7)); };
     // pixel tiles of this wave: TWK 32: tile m at + (m >> 1) * ROWP + (m & 1) * 16 * PS2 from the lane's base (immediates); TWK 24: tiles 0 / 1
     // likewise (rows 0 / 1, columns 0-15), tile 2 straddles the two rows (columns 16-23): a lane base of its own
-    const char* const xbase = smem + (tw4 * 2) * ROWP + p16 * PS2;
-    const char* const xbase2 = smem + (tw4 * 2 + (p16 >> 3)) * ROWP + (16 + (p16 & 7)) * PS2;
+    // (diagnostic build, PSEG_SP_DBG & 256, wrong results: every lane of a lane group reads the same address -- fragment reads free of bank conflicts by construction)
+    const bool abl_bc = PSEG_DIAG && (a.dbg & 256);
+    const char* const xbase = smem + (tw4 * 2) * ROWP + (abl_bc ? 0 : p16 * PS2);
+    const char* const xbase2 = smem + (tw4 * 2 + (abl_bc ? 0 : (p16 >> 3))) * ROWP + (abl_bc ? 16 * PS2 : (16 + (p16 & 7)) * PS2);
     const char* const wb0 = ring + lane * 16;
     const char* const tb = smem + a.lds_tab_off + (g * 8 + (p16 & 7)) * 4;       // table: [k-step][g][p & 7]
     const int K = a.K, RK = a.RK;

@@ -235,3 +235,30 @@ def test_predictor_chain_falls_back_for_foreign_postprocessors(gpu, oracle_mod):
     lab_o = oracle_mod.predict_single_data("fcn_skip", Wt, data.image, "f32")[2]
     want = oracle_mod.vote_connected_component_class(lab_o, data.binary)
     assert np.array_equal(p.labels, np.where(want == 1, 2, want))
+
+
+def test_engine_trim_and_status(gpu, oracle_mod):
+    """pseg_engine_trim frees every page slot of the activation tensors (an engine otherwise keeps the largest canvas x slot count it
+    has seen) and the next call allocates what its page needs -- same label maps before and after, for a single page and for a unit;
+    pseg_engine_status on a healthy engine is PSEG_OK and a NULL engine an error."""
+    import ctypes
+    from pseg_amd import synth
+    from pseg_amd import engine as E
+    eng = gpu.Engine("fcn_skip", 3, mode=gpu.MODE_BF16)
+    eng.set_weights(synth.glorot_weights(eng.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+    pages = [synth.synth_page(30 + i, 160, 224, 3)[0] for i in range(6)]
+    one = [eng.predict(p, want_logits=False, want_probs=False)[2] for p in pages]
+    unit = eng.predict_batch(pages, dtype=np.uint8)                      # grows the tensors to several slots
+    assert all(np.array_equal(u, o) for u, o in zip(unit, one))
+    eng.status()
+    eng.trim()
+    with pytest.raises(gpu.PsegError):
+        eng.activation("conv2d_2")                                       # no canvas: nothing to read back
+    again = eng.predict(pages[3], want_logits=False, want_probs=False)[2]
+    assert np.array_equal(again, one[3])
+    unit2 = eng.predict_batch(pages, dtype=np.uint8)
+    assert all(np.array_equal(u, o) for u, o in zip(unit2, one))
+    eng.trim(); eng.trim()                                               # idempotent
+    eng.status()
+    assert E.lib().pseg_engine_status(None, None) != 0 and E.lib().pseg_engine_trim(None) != 0
+    eng.close()

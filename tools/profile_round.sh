@@ -6,7 +6,7 @@ export PSEG_PLAN_FROM_ENV=1   # PSEG_* variables set below become the plan switc
 #   3. separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ busy + MFMA busy cycles), no tracing beside them
 # Raw output lands in gpurun_out/<tag>_*; the summaries to keep are copied to profiles/ by tools/pmc_traffic.py and by hand.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 stats() {   # stats <name> <program args...>

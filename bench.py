@@ -514,7 +514,7 @@ def run_rank(args):
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
         # runs, gfx950 correction applied) recorded under profiles/ by tools/pmc_traffic.py -- replayed, not measured here
         traffic, traffic_src = None, None
-        for fn in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01e_traffic.json"):
+        for fn in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01e_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     tr = json.load(f).get(name)

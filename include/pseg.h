@@ -133,6 +133,11 @@ int pseg_engine_trim(pseg_engine* e);
  * be NULL, not both.  Host pointers; returns when every page is back. */
 int pseg_predict_batch(pseg_engine* e, int n_pages, const uint8_t* const* imgs, const int* H,
                        const int* W, int64_t* const* labels, uint8_t* const* labels_u8);
+/* How pseg_predict_batch cuts a page list into units (host logic, no device needed): runs of consecutive same-shape pages, at
+ * most `cap` per unit, unit sizes 1, 2, 4 ... at the head of the list and ... 4, 2, 1 at its tail (the first upload and the last
+ * download have no compute beside them).  Returns the number of units (>= 0) and fills unit_first / unit_count (each may be NULL),
+ * or a negative PSEG_E*.  lib/predictor.py:27-30 has no such notion: the reference loops page by page. */
+int pseg_batch_units(int n_pages, const int* H, const int* W, int cap, int* unit_first, int* unit_count, int max_units);
 
 /* ---- Predictor chain: lib/predictor.py:32-54 ---------------------------------------------------------------- */
 

@@ -1044,6 +1044,28 @@ static void batch_free(Engine& e) {
 int predict_device_pages(Engine& e, const uint8_t* d_imgs, int n, int H, int W, int64_t* d_labels, uint8_t* d_labels_u8, hipStream_t st);
 bool pages_capable(Engine& e);
 
+// units of a page list (see predict_batch): runs of same-shape pages, at most `cap` per unit, sizes 1, 2, 4 ... at the head and
+// ... 4, 2, 1 at the tail of the list
+static void plan_units(int n, const int* H, const int* W, int cap, std::vector<int>& ub, std::vector<int>& ug) {
+    for (int i = 0; i < n;) {
+        int run = 1;
+        while (i + run < n && H[i + run] == H[i] && W[i + run] == W[i]) ++run;
+        std::vector<int> front, back;
+        int left = run;
+        if (cap > 1) {
+            const bool ramp_up = i == 0, ramp_down = i + run == n;
+            for (int g = 1; g < cap && left > 0 && (ramp_up || ramp_down); g *= 2) {
+                if (ramp_up && left >= g) { front.push_back(g); left -= g; }
+                if (ramp_down && left >= g) { back.push_back(g); left -= g; }
+            }
+        }
+        std::vector<int> sizes = front;
+        while (left > 0) { const int g = std::min(cap, left); sizes.push_back(g); left -= g; }
+        for (auto it = back.rbegin(); it != back.rend(); ++it) sizes.push_back(*it);
+        for (int g : sizes) { ub.push_back(i); ug.push_back(g); i += g; }
+    }
+}
+
 static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int* H, const int* W,
                          int64_t* const* labels, uint8_t* const* labels_u8) {
     PSEG_HIP(hipSetDevice(e.device));
@@ -1093,23 +1115,7 @@ static int predict_batch(Engine& e, int n, const uint8_t* const* imgs, const int
     // Same box, 32 / 8 pages of 2048x1536, ms per page, ramped against equal units: pinned uint8 0.410-0.445 vs 0.430 / 0.458 vs 0.466,
     // pageable arrays through the ring 0.456 vs 0.57 / 0.51-0.52 vs 0.55 (tools/gpu_r05_hostpath.sh).
     std::vector<int> ub, ug;                 // first page, page count of every unit
-    for (int i = 0; i < n;) {
-        int run = 1;
-        while (i + run < n && H[i + run] == H[i] && W[i + run] == W[i]) ++run;
-        std::vector<int> front, back;
-        int left = run;
-        if (cap > 1) {
-            const bool ramp_up = i == 0, ramp_down = i + run == n;
-            for (int g = 1; g < cap && left > 0 && (ramp_up || ramp_down); g *= 2) {
-                if (ramp_up && left >= g) { front.push_back(g); left -= g; }
-                if (ramp_down && left >= g) { back.push_back(g); left -= g; }
-            }
-        }
-        std::vector<int> sizes = front;
-        while (left > 0) { const int g = std::min(cap, left); sizes.push_back(g); left -= g; }
-        for (auto it = back.rbegin(); it != back.rend(); ++it) sizes.push_back(*it);
-        for (int g : sizes) { ub.push_back(i); ug.push_back(g); i += g; }
-    }
+    plan_units(n, H, W, cap, ub, ug);
     const int nu = (int)ub.size();
     auto upx = [&](int u) { return (size_t)H[ub[u]] * W[ub[u]]; };
     auto lab_off8 = [&](int u, int k) { return (size_t)k * upx(u) * 8; };                                   // int64 map of page k of the unit
@@ -1463,6 +1469,18 @@ int pseg_predict_batch(pseg_engine* h, int n_pages, const uint8_t* const* imgs, 
     KnobScope knob_scope(h->e);
     if (!labels && !labels_u8) return fail(PSEG_EINVAL, "no output requested");
     return predict_batch(h->e, n_pages, imgs, H, W, labels, labels_u8);
+}
+
+int pseg_batch_units(int n_pages, const int* H, const int* W, int cap, int* unit_first, int* unit_count, int max_units) {
+    if (n_pages < 0 || (n_pages > 0 && (!H || !W)) || cap < 1) return fail(PSEG_EINVAL, "bad argument");
+    std::vector<int> ub, ug;
+    plan_units(n_pages, H, W, cap, ub, ug);
+    if ((int)ub.size() > max_units && (unit_first || unit_count)) return fail(PSEG_EINVAL, "%zu units, room for %d", ub.size(), max_units);
+    for (size_t u = 0; u < ub.size(); ++u) {
+        if (unit_first) unit_first[u] = ub[u];
+        if (unit_count) unit_count[u] = ug[u];
+    }
+    return (int)ub.size();
 }
 
 int pseg_host_alloc(void** p, size_t bytes) {

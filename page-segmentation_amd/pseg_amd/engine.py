@@ -16,7 +16,7 @@ FLAG_BATCHNORM = 1
 EXPORTED_SYMBOLS = (
     "pseg_abi_version", "pseg_last_error", "pseg_device_count", "pseg_create", "pseg_create_ex", "pseg_create_plan", "pseg_env_knobs", "pseg_destroy",
     "pseg_num_weights", "pseg_weight_info", "pseg_set_weights", "pseg_get_weights",
-    "pseg_predict", "pseg_predict_device", "pseg_predict_pages_device", "pseg_engine_status", "pseg_engine_trim", "pseg_rccl_abi_pinned", "pseg_predict_batch", "pseg_predict_chain", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
+    "pseg_predict", "pseg_predict_device", "pseg_predict_pages_device", "pseg_engine_status", "pseg_engine_trim", "pseg_batch_units", "pseg_rccl_abi_pinned", "pseg_predict_batch", "pseg_predict_chain", "pseg_get_activation", "pseg_flops_per_pixel", "pseg_engine_stream",
     "pseg_host_alloc", "pseg_host_free", "pseg_host_register", "pseg_host_unregister",
     "pseg_predict_margin_device", "pseg_predict_exact_labels_device", "pseg_predict_exact_labels", "pseg_label_exact_stats", "pseg_label_exact_stats_ex",
     "pseg_timing_enable", "pseg_timing_reset", "pseg_timing_num_slots", "pseg_timing_get",
@@ -710,6 +710,17 @@ def affine_warp(plane, matrix, offset, order, device=0, fill_mode="nearest", cva
     _check(lib().pseg_affine_warp_fill(int(device), _ptr(a), a.shape[0], a.shape[1], _ptr(m), _ptr(o), int(order),
                                        FILL_MODES[fill_mode], float(cval), _ptr(out)))
     return out
+
+
+def batch_units(shapes, cap=8):
+    """The units pseg_predict_batch would cut a list of page shapes into: [(first page, page count), ...] (host logic, no GPU)."""
+    n = len(shapes)
+    H = (ctypes.c_int * max(n, 1))(*[int(s[0]) for s in shapes])
+    W = (ctypes.c_int * max(n, 1))(*[int(s[1]) for s in shapes])
+    first, count = (ctypes.c_int * max(n, 1))(), (ctypes.c_int * max(n, 1))()
+    nu = lib().pseg_batch_units(n, H, W, int(cap), first, count, n)
+    _check(min(nu, 0))
+    return [(first[u], count[u]) for u in range(nu)]
 
 
 def brightness_shift(x, brightness, device=0):

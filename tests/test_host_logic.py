@@ -247,3 +247,28 @@ def test_prediction_probabilities_can_be_lazy():
     assert prob.shape == (2, 2, 3) and p.probabilities is prob and p[1] is prob and calls == [1] and data == "data"
     q = Prediction(labels, prob, data)
     assert q.probabilities is prob and len(q) == 3 and q._fields == ("labels", "probabilities", "data")
+
+
+def test_batch_units_ramp_at_head_and_tail():
+    """pseg_batch_units (the partition pseg_predict_batch uses; lib/predictor.py:27-30 is a page-by-page loop): units cover the list
+    in order, never mix shapes, never exceed the cap; a same-shape run that opens the list starts 1, 2, 4 ..., one that closes it
+    ends ... 4, 2, 1; interior runs go in units of `cap`."""
+    from pseg_amd import engine as E
+    A, B = (2048, 1536), (1000, 700)
+    assert E.batch_units([], 8) == []
+    assert E.batch_units([A], 8) == [(0, 1)]
+    u = E.batch_units([A] * 32, 8)
+    assert [c for _, c in u] == [1, 2, 4, 8, 8, 2, 4, 2, 1] and [f for f, _ in u] == [0, 1, 3, 7, 15, 23, 25, 29, 31]
+    assert [c for _, c in E.batch_units([A] * 8, 2)] == [1, 2, 2, 2, 1]
+    assert [c for _, c in E.batch_units([A] * 5, 1)] == [1] * 5
+    mixed = [A] * 10 + [B] * 3 + [A] * 20 + [B] * 11
+    u = E.batch_units(mixed, 8)
+    assert sum(c for _, c in u) == len(mixed) and all(f == sum(c for _, c in u[:i]) for i, (f, _) in enumerate(u))
+    for f, c in u:
+        assert 1 <= c <= 8 and len({mixed[i] for i in range(f, f + c)}) == 1
+    heads = [c for f, c in u if f < 10]
+    assert heads[:3] == [1, 2, 4]                               # the opening run ramps up ...
+    assert [c for f, c in u if 13 <= f < 33] == [8, 8, 4]       # ... an interior run does not
+    assert [c for f, c in u if f >= 33][-3:] == [4, 2, 1]       # ... the closing run ramps down
+    with pytest.raises(E.PsegError):
+        E.batch_units([A], 0)

@@ -265,3 +265,29 @@ def test_bench_self_launch_two_ranks(gpu):
     import torch
     if torch.cuda.device_count() < 2:
         assert r2.returncode != 0 and "rank" in r2.stderr
+
+
+def test_page_units_three_channel_input(gpu, monkeypatch):
+    """Page units with a 3-channel page (lib/network.py:28,56 input_image_dimension = 3): no fused first layer -- every slot's input
+    tensor is pre-processed up front -- and the maps equal the page-by-page ones (device entry and host list)."""
+    import torch
+    from pseg_amd import synth
+    rng = np.random.default_rng(12)
+    monkeypatch.setenv("PSEG_SP_CHECK", "1")
+    monkeypatch.setenv("PSEG_BATCH_PAGES", "4")
+    eng = gpu.Engine("fcn_skip", 3, in_channels=3, mode=gpu.MODE_BF16)
+    eng.set_weights(synth.glorot_weights(eng.weight_specs(), seed=42, gain=1.5, bias_scale=0.05))
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    H, W, n = 130, 200, 6
+    pages = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    want = [eng.predict(pages[i], want_logits=False, want_probs=False)[2] for i in range(n)]
+    assert len({w.tobytes() for w in want}) == n
+    d = torch.from_numpy(pages).to(dev)
+    out8 = torch.zeros((n, H, W), dtype=torch.uint8, device=dev)
+    eng.predict_pages_device(d.data_ptr(), n, H, W, d_labels_u8=out8.data_ptr(), stream=st)
+    eng.status(st)
+    assert all(np.array_equal(out8[i].cpu().numpy(), want[i]) for i in range(n))
+    got = eng.predict_batch([pages[i] for i in range(n)], dtype=np.uint8)
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    eng.close()

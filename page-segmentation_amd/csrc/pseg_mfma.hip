@@ -4829,6 +4829,12 @@ static int launch_generic_any2(const MConv& a, const MfmaPlan& P, dim3 grid, hip
     if (fl & FL_SKIPLOG) return fail(PSEG_EUNSUPPORTED, "skip-logits fusion has no kernel instance for this shape");
     if (fl & FL_DQ) return fail(PSEG_EUNSUPPORTED, "the fused transposed conv has no kernel instance for this shape (MT %d NT %d k %d sigma %d flags %d)", P.MT, P.NT, ks, sg, fl);
     PSEG_TRY_INST(4, 4, 2, 1, 6, MODE_CONV, FL_UP0)       // unet: UpSampling2D + k2 conv
+    // single-block stride-2 layers with resident weights as PERSISTENT workgroups (res_unet 32 -> 64): a tile of theirs is 9 k-steps --
+    // tools/trace_layers.py: ring issue 1.6 k + table 2.1 k + tile stage 5.5 k + wait 1.0 k cycles around a k-loop of 3.3 k; the walk stages
+    // weights and table once per workgroup: 103 -> 96 and 99 -> 85 us on one box.  (The 32 -> 32 full-resolution layer lost as a
+    // persistent instance, 152 -> 157-167 us: it gives up the epilogue's LDS store patch, which lives in the resident weights' place.)
+    PSEG_TRY_INST(2, 4, 3, 2, 4, MODE_CONV, FL_PERSIST)
+    PSEG_TRY_INST(2, 4, 3, 2, 4, MODE_CONV, FL_INRELU | FL_PERSIST)
     PSEG_TRY_INST(2, 4, 3, 2, 4, MODE_CONV, 0)            // res_unet encoder: stride-2 shortcut conv (four-row tiles, dense de-interleaved tile)
     PSEG_TRY_INST(2, 4, 3, 2, 4, MODE_CONV, FL_INRELU)    // res_unet encoder: stride-2 first conv of the block
     PSEG_TRY_INST(4, 4, 3, 2, 4, MODE_CONV, 0)            // (eight-row tiles: PSEG_NO_S2_MT2)
@@ -5283,6 +5289,15 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         const int cus = device_cus();
         a.ntiles = (int)grid.x;
         grid.x = std::min<unsigned>(grid.x, 2u * (unsigned)cus);
+    }
+    // ... and the k3 single-block layers whose instances exist (launch_generic_any2): many tiles, nine k-steps each
+    if (op.fuse1 < 0 && P->NB == 1 && P->nblk == 1 && P->nblocks_n == 1 && P->KS == 3 && a.sigma == 4 && !a.deconv && !a.tail && !a.up0 && !a.up1 &&
+        !a.pool_dst && !a.dst2 && !a.skip_logits && !a.tail_wa && !a.dq_w && e.batch_pages <= 1 &&
+        P->MT == 2 && P->NT == 4 && op.stride == 2 && !a.add &&
+        !PSEG_KNOB("PSEG_NO_PERSIST") && !PSEG_KNOB("PSEG_GENERIC")) {
+        const int cus = device_cus();
+        const unsigned slots = (P->wg3 ? 3u : 2u) * (unsigned)cus;
+        if (grid.x > 2 * slots) { a.ntiles = (int)grid.x; grid.x = slots; }
     }
     if (e.batch_pages > 1) grid.z = (unsigned)e.batch_pages;   // (mfma_op_batchable layers only: the page slot is blockIdx.z)
     return launch_generic_any(a, *P, grid, st, op.layer.c_str());

@@ -3662,10 +3662,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int t = 0; t < NT; ++t) {
                     const int n = t * 16 + 4 * g;
                     const unsigned noff = n < CsO ? (unsigned)n * 2u : OOBS;
-                    // vertical pairs: TWK 32: tiles (0, 2) and (1, 3); TWK 24: tiles (0, 1), and the two lane halves of tile 2
-                    constexpr int NPAIR = TWK == 32 ? 2 : 2;
+                    // two vertical pairs either way: TWK 32: tiles (0, 2) and (1, 3); TWK 24: tiles (0, 1), and the two lane halves of tile 2
 #pragma unroll
-                    for (int pr = 0; pr < NPAIR; ++pr) {
+                    for (int pr = 0; pr < 2; ++pr) {
                         float q[4];
                         int xcol; bool lane_ok;
                         if (TWK == 32) {

@@ -533,6 +533,12 @@ def run_rank(args):
                                        "with event timing on, whose sum prices whole_net_frac_kernel_sum",
                 "whole_net_frac_kernel_sum": round(eng.flops_per_pixel() * H * W / (total_ms * 1e-3) / 1e12 / peak, 5),
                 "per_kernel_ms": {s[0]: round(per_page(s), 5) for s in slots}}
+        if args.mode == "bf16":
+            # context, not the contract's `peak`: what the chip sustains on this instruction stream (tools/microtests/kloop_tiles.hip, round 5)
+            roof["measured_ceiling"] = {"TFLOP/s": 1596.0, "frac_of_it": round(achieved / 1596.0, 5),
+                                        "what": "bare v_mfma_f32_16x16x32_bf16 loop, two waves per SIMD, random operands, every CU busy: the clock the chip "
+                                                "holds under that load gives 0.64 of the nominal 2 500 (profiles/r05_kloop_tiles_microbench.txt); `achieved` is "
+                                                "algorithmic work -- the dominant launch issues 1.30 x that (K 500 -> 520, Cout 30 -> 32, conv1 on the halo)"}
         if paged:
             roof["per_kernel_ms_what"] = "per page: the layer's time over the pages of the pass (launches of the low-resolution layers cover a unit of pages)"
         ksize = {n.split("/")[0]: sh[0] for n, sh in eng.weight_specs() if n.endswith("kernel")}

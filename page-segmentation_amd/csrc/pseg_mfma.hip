@@ -2774,7 +2774,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         oy = ty * TH; ox = tx * TW;
     };
     // PSEG_SP_TRACE (developer aid): s_memtime stamps of wave 0 / 4 / 6, 16 slots per workgroup (tools/sp_trace.py)
-    unsigned long long* const trc = a.trace ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
+    unsigned long long* const trc = (PSEG_DIAG && a.trace) ? a.trace + (size_t)blockIdx.x * 16 : nullptr;   // (diagnostic build only: the release kernel holds no stamp)
 #define SP_STAMP(i) if (trc && lane == 0) trc[i] = __builtin_amdgcn_s_memtime();
     if (trc && lane == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); ((unsigned short*)&trc[14])[wave] = (unsigned short)hw; }   // where the wave runs: bits 5:4 = SIMD
     // the FIRST wait that gave up leaves its code and what it was waiting for: err[0] code, [1] wave, [2] needed, [3] had, [4] second need, [5] second had
@@ -3764,7 +3764,7 @@ static bool sp2_off() {
     return v && atoi(v) == 0;
 }
 static bool tracing_req(const Op& op) {
-    const char* trl = PSEG_KNOB("PSEG_SP_TRACE");
+    const char* trl = PSEG_DIAG_KNOB("PSEG_SP_TRACE");
     return trl && op.layer == trl;
 }
 
@@ -5160,7 +5160,7 @@ int mfma_launch_conv(Engine& e, Op& op, hipStream_t st) {
         c.layer_id = (int)(&op - e.ops.data());
         c.dbg = PSEG_DIAG_KNOB("PSEG_SP_DBG") ? atoi(PSEG_DIAG_KNOB("PSEG_SP_DBG")) : 0;
         const dim3 gs((unsigned)std::min<int>(c.ntiles, cus_sp));
-        const char* trl = PSEG_KNOB("PSEG_SP_TRACE");
+        const char* trl = PSEG_DIAG_KNOB("PSEG_SP_TRACE");     // diagnostic build only: the release library neither stamps nor writes files
         const bool tracing = sp_pays && trl && op.layer == trl;
         if (tracing) {
             PSEG_HIP(hipMalloc((void**)&c.trace, (size_t)gs.x * 16 * 8));

@@ -1,5 +1,5 @@
-"""Phase stamps of conv_sp_kernel (PSEG_SP_TRACE=<layer>), one layer at a time, 2048x1536 fcn_skip page:
-    python tools/sp_trace.py [layers...]"""
+"""Phase stamps of conv_sp_kernel (diagnostic build, PSEG_SP_TRACE=<layer>), one layer at a time, 2048x1536 fcn_skip page:
+    PSEG_LIB=page-segmentation_amd/csrc/libpseg_diag.so python tools/sp_trace.py [layers...]"""
 import os, sys
 os.environ.setdefault("PSEG_PLAN_FROM_ENV", "1")   # PSEG_* of the environment -> plan switches of the engines created here
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

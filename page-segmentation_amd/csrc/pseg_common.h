@@ -159,6 +159,7 @@ struct Engine;
 // host-side packing + upload; w = correlation-form f32 weights as uploaded for the exact path
 int mfma_pack_op(Engine& e, Op& op, const std::vector<float>& w, const std::vector<float>& bias);
 void mfma_free_op(Op& op);
+void mfma_trim_op(Op& op);                                   // frees the plan's canvas-sized buffers (pseg_engine_trim)
 int mfma_plan_graph(Engine& e);                              // pool fusion etc., once per engine
 int mfma_launch_conv(Engine& e, Op& op, hipStream_t st);     // OP_CONV
 int mfma_launch_deconv2(Engine& e, Op& op, hipStream_t st);  // OP_DECONV2

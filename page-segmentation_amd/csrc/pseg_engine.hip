@@ -1457,6 +1457,7 @@ int pseg_engine_trim(pseg_engine* h) {
     PSEG_HIP(hipSetDevice(e.device));
     PSEG_HIP(hipDeviceSynchronize());
     for (auto& t : e.tensors) { free_dev(t.base); t.d = nullptr; t.bytes = 0; t.page_bytes = 0; }
+    for (auto& op : e.ops) mfma_trim_op(op);                 // (the skip-logits planes grow with canvas x slots too)
     e.Hp = e.Wp = 0;
     e.pages = 1;
     free_dev((void*&)e.d_logits_tmp); e.logits_tmp_bytes = 0;

@@ -3784,6 +3784,15 @@ void mfma_free_op(Op& op) {
     op.plan = nullptr;
 }
 
+// pseg_engine_trim: the canvas-sized buffers a plan owns (the skip-logits planes: 16 B per canvas pixel and page slot)
+void mfma_trim_op(Op& op) {
+    auto* p = (MfmaPlan*)op.plan;
+    if (!p) return;
+    (void)hipFree(p->d_skiplog);
+    p->d_skiplog = nullptr;
+    p->skiplog_bytes = 0;
+}
+
 static int producer_of(const Engine& e, int tensor) {
     for (size_t i = 0; i < e.ops.size(); ++i)
         if (e.ops[i].dst == tensor) return (int)i;

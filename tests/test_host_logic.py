@@ -272,3 +272,26 @@ def test_batch_units_ramp_at_head_and_tail():
     assert [c for f, c in u if f >= 33][-3:] == [4, 2, 1]       # ... the closing run ramps down
     with pytest.raises(E.PsegError):
         E.batch_units([A], 0)
+
+
+def test_augmentation_settings_reach_the_generators_as_in_the_reference():
+    """lib/trainer.py:14-56: to_image_params carries brightness_range and interpolation order 3, to_binary_params / to_mask_params
+    order 0 WITHOUT the brightness key; every fill mode keras-preprocessing accepts is taken, anything else raises; the brightness
+    draw is the last of get_random_transform (the affine parameters under a shared seed stay equal across the three generators)."""
+    from ocr4all_pixel_classifier.lib.trainer import AugmentationSettings
+    from ocr4all_pixel_classifier.lib.data_generator import ImageDataGeneratorCustom as G
+    s = AugmentationSettings(brightness_range=[0.7, 1.3], image_fill_mode='reflect', binary_fill_mode='wrap', mask_fill_mode='constant', mask_cval=9)
+    pi, pb, pm = s.to_image_params(), s.to_binary_params(), s.to_mask_params()
+    assert pi['brightness_range'] == [0.7, 1.3] and pi['interpolation_order'] == 3 and pi['fill_mode'] == 'reflect'
+    assert 'brightness_range' not in pb and pb['interpolation_order'] == 0 and pb['fill_mode'] == 'wrap'
+    assert 'brightness_range' not in pm and pm['fill_mode'] == 'constant' and pm['cval'] == 9
+    gi, gb, gm = (G(**p, data_format='channels_last') for p in (pi, pb, pm))
+    ti, tb, tm = (g.get_random_transform((100, 140, 1), seed=77) for g in (gi, gb, gm))
+    assert tb['brightness'] is None and tm['brightness'] is None and 0.7 <= ti['brightness'] <= 1.3
+    assert all(ti[k] == tb[k] == tm[k] for k in ('theta', 'tx', 'ty', 'shear', 'zx', 'zy', 'flip_horizontal', 'flip_vertical'))
+    for bad in ('mirror', 'grid-wrap', ''):
+        with pytest.raises(Exception):
+            G(fill_mode=bad)
+    with pytest.raises(ValueError):
+        G(brightness_range=1.2)
+    assert AugmentationSettings().brightness_range is None          # the reference default: no brightness draw at all
